@@ -1,0 +1,102 @@
+"""ctypes binding of libfithubert_hip.so (include/fithubert_hip.h).
+
+The HIP library is the product: there is NO fallback.  Importing symbols from a missing or
+stale library raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfithubert_hip.so")
+
+R_CONTIG, R_STRIDED = 0, 1
+ACT_NONE, ACT_GELU = 0, 1
+DT_F32, DT_BF16 = 0, 1
+
+
+class Drop(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32)]
+
+
+class GemmOperand(C.Structure):
+    _fields_ = [
+        ("p", C.c_void_p), ("layout", C.c_int), ("ld", C.c_long), ("rpb", C.c_int), ("bstride", C.c_long),
+        ("gstride", C.c_long), ("nseg", C.c_int), ("tshift", C.c_int * 2), ("tvalid", C.c_int),
+        ("segoff", C.c_long * 2),
+    ]
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [
+        ("alpha", C.c_float), ("bias", C.c_void_p), ("bias_gstride", C.c_long), ("bias_mod", C.c_int),
+        ("preact", C.c_void_p), ("act", C.c_int), ("drop", Drop), ("gelu_aux", C.c_void_p),
+        ("residual", C.c_void_p), ("row_len", C.c_void_p), ("out_f32", C.c_int), ("atomic", C.c_int),
+        ("idiv", C.c_int), ("si1", C.c_long), ("si0", C.c_long), ("jdiv", C.c_int), ("sj1", C.c_long),
+        ("sj0", C.c_long),
+    ]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("X", GemmOperand), ("Y", GemmOperand), ("C", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
+        ("Kseg", C.c_int), ("ldc", C.c_long), ("c_rpb", C.c_int), ("c_bstride", C.c_long),
+        ("c_gstride", C.c_long), ("groups", C.c_int), ("splitk", C.c_int), ("ep", GemmEpilogue),
+    ]
+
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m fithubert_amd.build` "
+                "(fithubert_amd has no CPU / eager fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(l: C.CDLL) -> None:
+    l.fh_gemm.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
+    l.fh_gemm.restype = C.c_int
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")
+
+
+def operand(t_ptr, layout, ld, rpb=0, bstride=0, gstride=0, nseg=1, tshift=(0, 0), tvalid=0, segoff=(0, 0)):
+    o = GemmOperand()
+    o.p = t_ptr
+    o.layout = layout
+    o.ld = ld
+    o.rpb = rpb
+    o.bstride = bstride
+    o.gstride = gstride
+    o.nseg = nseg
+    o.tshift[0], o.tshift[1] = tshift
+    o.tvalid = tvalid
+    o.segoff[0], o.segoff[1] = segoff
+    return o
+
+
+def epilogue(**kw):
+    e = GemmEpilogue()
+    e.alpha = 1.0
+    for k, v in kw.items():
+        if k == "drop":
+            e.drop.p, e.drop.seed, e.drop.site = v
+        else:
+            setattr(e, k, v)
+    return e

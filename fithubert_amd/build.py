@@ -1,0 +1,69 @@
+"""Build libfithubert_hip.so (gfx950) from fithubert_amd/csrc/*.hip with hipcc.
+
+In-tree build: the .so sits next to this file, is git-ignored and travels to the GPU box
+with the repo snapshot.  No torch headers are involved: the library is a plain C-ABI
+(include/fithubert_hip.h) over HIP.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libfithubert_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+
+
+def _deps_hash(src: str) -> str:
+    h = hashlib.sha1()
+    for f in [src] + sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cuh"))
+                            + glob.glob(os.path.join(HERE, "..", "include", "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    stamp = obj + ".sha1"
+    want = _deps_hash(src)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
+        return obj
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(want)
+    return obj
+
+
+def build(verbose: bool = True, jobs: int = 6) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    if not srcs:
+        raise RuntimeError("no HIP sources found")
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(_compile, srcs))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[fithubert_amd.build] {LIB} ({os.path.getsize(LIB) >> 10} KiB) from {len(srcs)} sources")
+    return LIB
+
+
+if __name__ == "__main__":
+    build()
+    sys.exit(0)

@@ -1,0 +1,139 @@
+// Common device helpers for the FitHuBERT gfx950 kernels.
+// Element type T is either float (exact-parity mode, f32 MFMA) or bf16 (bf16 MFMA, f32 accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fithubert_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define FH_WAVE 64
+
+#define FH_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return (int)e__;                 \
+  } while (0)
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int VEC = 4;   // elements per 16 bytes
+  static constexpr int DT = 0;
+};
+template <> struct ElemTraits<bf16> {
+  static constexpr int VEC = 8;
+  static constexpr int DT = 1;
+};
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+// 16-byte vector of T, as 4 dwords
+struct alignas(16) V16 {
+  uint32_t w[4];
+};
+__device__ __forceinline__ V16 v16_zero() {
+  V16 v;
+  v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u;
+  return v;
+}
+__device__ __forceinline__ V16 ld16(const void* p) { return *reinterpret_cast<const V16*>(p); }
+__device__ __forceinline__ void st16(void* p, const V16& v) { *reinterpret_cast<V16*>(p) = v; }
+
+// unpack / pack a 16-byte vector into VEC floats
+template <typename T> __device__ __forceinline__ void unpack16(const V16& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const V16& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v.w[i]);
+}
+template <> __device__ __forceinline__ void unpack16<bf16>(const V16& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v.w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint32_t bf16_bits(float x) {
+  bf16 b = (bf16)x;
+  return (uint32_t) * reinterpret_cast<uint16_t*>(&b);
+}
+template <typename T> __device__ __forceinline__ V16 pack16(const float* f);
+template <> __device__ __forceinline__ V16 pack16<float>(const float* f) {
+  V16 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v.w[i] = __float_as_uint(f[i]);
+  return v;
+}
+template <> __device__ __forceinline__ V16 pack16<bf16>(const float* f) {
+  V16 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v.w[i] = bf16_bits(f[2 * i]) | (bf16_bits(f[2 * i + 1]) << 16);
+  return v;
+}
+
+// load / store 4 consecutive T elements as floats (8 B for bf16, 16 B for float)
+__device__ __forceinline__ void ld4(const float* p, float* f) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+__device__ __forceinline__ void ld4(const bf16* p, float* f) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  f[0] = __uint_as_float(v.x << 16);
+  f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16);
+  f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float* f) {
+  *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void st4(bf16* p, const float* f) {
+  uint2 v;
+  v.x = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
+  v.y = bf16_bits(f[2]) | (bf16_bits(f[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- counter-based dropout
+// mask(seed, site, idx) is a pure function, so backward regenerates the forward's mask.
+__device__ __forceinline__ uint32_t fh_mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+typedef fh_drop DropCfg;  // {p, seed, site}
+__device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
+  uint32_t k = fh_mix32(d.seed * 0x9E3779B9u + d.site * 0x85ebca6bu + (uint32_t)(idx >> 32) * 0xc2b2ae35u + 0x27d4eb2fu);
+  uint32_t h = fh_mix32((uint32_t)idx ^ k);
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u >= d.p ? 1.0f / (1.0f - d.p) : 0.0f;
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,299 @@
+// First conv layer of the waveform frontend, fused with its GroupNorm and GELU.
+//
+//   reference: modules/module.py:65-71 (Conv1d(1, C0, k, stride, bias=False) -> Dropout(0) ->
+//              Fp32GroupNorm(C0 groups, C0 channels) -> GELU), applied at module.py:99-100.
+//
+// Cin = 1 makes this layer HBM-bound (reads S floats, writes T0*C0 elements per utterance), so it is
+// not a GEMM: each thread owns one output channel (10 taps in registers) and walks time; the waveform
+// chunk is staged once in LDS and broadcast.  GroupNorm with one channel per group normalises every
+// (utterance, channel) over time, so the un-normalised conv output is never written: pass 1 computes
+// chunk-local (mean, M2) with a pivot (no catastrophic cancellation), a tiny kernel merges chunks with
+// Chan's formula in fp64, pass 2 recomputes the conv (10 FMA/elem) and writes GELU(GN(.)) once.
+// Backward mirrors it: one reduction pass + one pass that accumulates dW (the waveform needs no grad).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TCH = 256;   // output time steps per block
+constexpr int MAXK = 16;
+
+struct Conv0Args {
+  const float* wave;  // [B][S]
+  const float* w;     // [C0][K]
+  const float* gamma; // [C0]
+  const float* beta;  // [C0]
+  int B, S, T0, C0, K, stride, nchunk;
+};
+
+// stage the waveform chunk of block (b, chunk) in LDS; returns number of valid output steps
+__device__ __forceinline__ int stage_wave(const Conv0Args& a, int b, int chunk, float* sw) {
+  const int t0 = chunk * TCH;
+  const int nt = min(TCH, a.T0 - t0);
+  const int nsamp = (nt - 1) * a.stride + a.K;
+  const float* src = a.wave + (long)b * a.S + (long)t0 * a.stride;
+  for (int i = threadIdx.x; i < nsamp; i += blockDim.x) sw[i] = src[i];
+  __syncthreads();
+  return nt;
+}
+
+__device__ __forceinline__ float conv_at(const float* sw, const float* w, int t, int K, int stride) {
+  float v = 0.f;
+  const float* x = sw + t * stride;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j)
+    if (j < K) v = fmaf(w[j], x[j], v);
+  return v;
+}
+
+// ---------------------------------------------------------------- forward pass 1: chunk statistics
+__global__ void __launch_bounds__(256) conv0_stats_kernel(Conv0Args a, float2* part /*[B][nchunk][C0] (mean, M2)*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sw = smem;                                   // waveform chunk
+  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [2][256]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int nt = stage_wave(a, b, chunk, sw);
+  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
+  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
+  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
+    const int c = cbase + cl;
+    float w[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
+    const float pivot = conv_at(sw, w, 0, a.K, a.stride);
+    float s = 0.f, ss = 0.f;
+    for (int t = tl; t < nt; t += nlan) {
+      const float d = conv_at(sw, w, t, a.K, a.stride) - pivot;
+      s += d;
+      ss = fmaf(d, d, ss);
+    }
+    red[threadIdx.x] = s;
+    red[256 + threadIdx.x] = ss;
+    __syncthreads();
+    if (tl == 0) {
+      for (int l = 1; l < nlan; ++l) {
+        s += red[l * cpb + cl];
+        ss += red[256 + l * cpb + cl];
+      }
+      const float n = (float)nt;
+      const float mean_d = s / n;
+      float2 o;
+      o.x = pivot + mean_d;
+      o.y = fmaxf(ss - s * mean_d, 0.f);
+      part[((long)b * a.nchunk + chunk) * a.C0 + c] = o;
+    }
+    __syncthreads();
+  }
+}
+
+// merge chunk statistics (Chan et al.) in fp64 -> mean, rstd per (b, c)
+__global__ void conv0_stats_final_kernel(const float2* part, float* mean, float* rstd, int B, int nchunk, int C0, int T0,
+                                         float eps) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C0; c += blockDim.x) {
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float2 p = part[((long)b * nchunk + k) * C0 + c];
+      const double nb = (double)min(TCH, T0 - k * TCH);
+      const double delta = (double)p.x - mu;
+      const double nn = n + nb;
+      mu += delta * nb / nn;
+      m2 += (double)p.y + delta * delta * n * nb / nn;
+      n = nn;
+    }
+    mean[b * C0 + c] = (float)mu;
+    rstd[b * C0 + c] = (float)(1.0 / sqrt(m2 / n + (double)eps));
+  }
+}
+
+// ---------------------------------------------------------------- forward pass 2: conv + GN + GELU -> y
+template <typename T>
+__global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const float* mean, const float* rstd, T* y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sw = smem;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int nt = stage_wave(a, b, chunk, sw);
+  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
+  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
+  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
+    const int c = cbase + cl;
+    float w[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
+    const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
+    const float sc = rs * a.gamma[c], sh = a.beta[c] - mu * rs * a.gamma[c];
+    T* yp = y + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
+    for (int t = tl; t < nt; t += nlan) {
+      const float v = conv_at(sw, w, t, a.K, a.stride);
+      yp[(long)t * a.C0] = from_f<T>(gelu_f(fmaf(v, sc, sh)));
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward pass 1: per-(b,c) sums of g and g*xhat
+template <typename T>
+__global__ void __launch_bounds__(256) conv0_bwd_reduce_kernel(Conv0Args a, const float* mean, const float* rstd,
+                                                               const T* dy, float2* part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sw = smem;
+  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int nt = stage_wave(a, b, chunk, sw);
+  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
+  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
+  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
+    const int c = cbase + cl;
+    float w[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
+    const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
+    const float ga = a.gamma[c], be = a.beta[c];
+    const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = tl; t < nt; t += nlan) {
+      const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
+      const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
+      s1 += g;
+      s2 = fmaf(g, xh, s2);
+    }
+    red[threadIdx.x] = s1;
+    red[256 + threadIdx.x] = s2;
+    __syncthreads();
+    if (tl == 0) {
+      for (int l = 1; l < nlan; ++l) {
+        s1 += red[l * cpb + cl];
+        s2 += red[256 + l * cpb + cl];
+      }
+      part[((long)b * a.nchunk + chunk) * a.C0 + c] = make_float2(s1, s2);
+    }
+    __syncthreads();
+  }
+}
+
+// per (b, c): A = gamma * mean_t(g), Bq = gamma * mean_t(g * xhat); dgamma += sum g*xhat, dbeta += sum g
+__global__ void conv0_bwd_final_kernel(const float2* part, const float* gamma, float2* ab, float* dgamma, float* dbeta,
+                                       int B, int nchunk, int C0, int T0) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C0; c += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float2 p = part[((long)b * nchunk + k) * C0 + c];
+      s1 += p.x;
+      s2 += p.y;
+    }
+    const double g = gamma[c];
+    ab[b * C0 + c] = make_float2((float)(g * s1 / T0), (float)(g * s2 / T0));
+    atomicAdd(dbeta + c, (float)s1);
+    atomicAdd(dgamma + c, (float)s2);
+  }
+}
+
+// ---------------------------------------------------------------- backward pass 2: dW[c][j] += sum_t dv[t] * wave[stride*t + j]
+template <typename T>
+__global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, const float* mean, const float* rstd,
+                                                               const float2* ab, const T* dy, float scale, float* dw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sw = smem;
+  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [256]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int nt = stage_wave(a, b, chunk, sw);
+  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
+  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
+  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
+    const int c = cbase + cl;
+    float w[MAXK], acc[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
+      acc[j] = 0.f;
+    }
+    const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
+    const float ga = a.gamma[c], be = a.beta[c];
+    const float2 abv = ab[b * a.C0 + c];
+    const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
+    for (int t = tl; t < nt; t += nlan) {
+      const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
+      const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
+      const float dv = rs * (g * ga - abv.x - xh * abv.y);
+      const float* x = sw + t * a.stride;
+#pragma unroll
+      for (int j = 0; j < MAXK; ++j)
+        if (j < a.K) acc[j] = fmaf(dv, x[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      if (j < a.K) {
+        red[threadIdx.x] = acc[j];
+        __syncthreads();
+        if (tl == 0) {
+          float s = acc[j];
+          for (int l = 1; l < nlan; ++l) s += red[l * cpb + cl];
+          atomicAdd(dw + c * a.K + j, s * scale);
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+size_t smem_bytes(int stride, int K, bool red2) {
+  size_t sw = ((size_t)((TCH - 1) * stride + K) + 3) / 4 * 4;
+  return (sw + (red2 ? 512 : 256)) * sizeof(float);
+}
+
+}  // namespace
+
+int fh_conv0_nchunk(int T0) { return (T0 + TCH - 1) / TCH; }
+
+int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, float2* part, int B, int S, int C0, int K, int stride, float eps,
+                        hipStream_t st) {
+  if (K > MAXK || C0 % 64 != 0 || (C0 > 256 && C0 % 256 != 0) || (C0 < 256 && 256 % C0 != 0)) return -201;
+  Conv0Args a;
+  a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta;
+  a.B = B; a.S = S; a.C0 = C0; a.K = K; a.stride = stride;
+  a.T0 = (S - K) / stride + 1;
+  a.nchunk = fh_conv0_nchunk(a.T0);
+  dim3 grid(a.nchunk, B), block(256);
+  hipLaunchKernelGGL(conv0_stats_kernel, grid, block, smem_bytes(stride, K, true), st, a, part);
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv0_stats_final_kernel, dim3(B), dim3(256), 0, st, part, mean, rstd, B, a.nchunk, C0, a.T0, eps);
+  FH_CHECK_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(conv0_apply_kernel<float>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (float*)y);
+  else
+    hipLaunchKernelGGL(conv0_apply_kernel<bf16>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (bf16*)y);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta,
+                        const void* dy, const float* mean, const float* rstd, float2* part, float2* ab, float* dw,
+                        float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
+                        hipStream_t st) {
+  if (K > MAXK || C0 % 64 != 0 || (C0 > 256 && C0 % 256 != 0) || (C0 < 256 && 256 % C0 != 0)) return -201;
+  Conv0Args a;
+  a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta;
+  a.B = B; a.S = S; a.C0 = C0; a.K = K; a.stride = stride;
+  a.T0 = (S - K) / stride + 1;
+  a.nchunk = fh_conv0_nchunk(a.T0);
+  dim3 grid(a.nchunk, B), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(conv0_bwd_reduce_kernel<float>, grid, block, smem_bytes(stride, K, true), st, a, mean, rstd,
+                       (const float*)dy, part);
+  else
+    hipLaunchKernelGGL(conv0_bwd_reduce_kernel<bf16>, grid, block, smem_bytes(stride, K, true), st, a, mean, rstd,
+                       (const bf16*)dy, part);
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3(B), dim3(256), 0, st, part, gamma, ab, dgamma, dbeta, B, a.nchunk, C0,
+                     a.T0);
+  FH_CHECK_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(conv0_bwd_weight_kernel<float>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
+                       (const float*)dy, grad_scale, dw);
+  else
+    hipLaunchKernelGGL(conv0_bwd_weight_kernel<bf16>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
+                       (const bf16*)dy, grad_scale, dw);
+  FH_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,208 @@
+"""GPU: the generic MFMA GEMM (fithubert_amd/csrc/gemm.hip) through the C ABI against torch fp32/fp64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fithubert_amd import _lib as L  # noqa: E402
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _tdt(dt):
+    return torch.float32 if dt == L.DT_F32 else torch.bfloat16
+
+
+def _tol(dt, K):
+    # fp32: exact-fma chains, order differs from the reference -> ~1e-6 * sqrt(K); bf16: inputs are
+    # bf16-exact in the test, so only the output rounding (2^-9 relative) + accumulation order remain
+    return (2e-5, 1e-5) if dt == L.DT_F32 else (1e-2, 1e-2)
+
+
+def _run(desc, dt):
+    L.check(L.lib().fh_gemm(desc, dt, _stream()), "fh_gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("xl,yl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 480, 480), (98, 768, 480), (264, 96, 200)])
+def test_gemm_layouts(dt, xl, yl, M, N, K):
+    torch.manual_seed(M * 7 + N * 3 + K + xl * 2 + yl)
+    dev = "cuda"
+    X = torch.randn(M, K, device=dev).to(_tdt(dt))
+    Y = torch.randn(N, K, device=dev).to(_tdt(dt))
+    ref = (X.double() @ Y.double().t())
+    Xs = X if xl == 0 else X.t().contiguous()  # R_STRIDED: stored [K][M]
+    Ys = Y if yl == 0 else Y.t().contiguous()
+    Cout = torch.full((M, N), float("nan"), device=dev, dtype=_tdt(dt))
+    d = L.GemmDesc()
+    d.X = L.operand(Xs.data_ptr(), xl, K if xl == 0 else M)
+    d.Y = L.operand(Ys.data_ptr(), yl, K if yl == 0 else N)
+    d.C = Cout.data_ptr()
+    d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+    d.ep = L.epilogue()
+    if (xl == 1 and M % 8) or (yl == 1 and N % 8):
+        pytest.skip("R_STRIDED needs the operand extent to be a multiple of the vector width")
+    _run(d, dt)
+    rtol, atol = _tol(dt, K)
+    err = (Cout.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= atol * scale + rtol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+def test_gemm_asymmetric_identity(dt):
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    dev = "cuda"
+    M = N = K = 128
+    X = torch.eye(M, device=dev).to(_tdt(dt))
+    Y = (torch.arange(N, device=dev)[:, None] * 3 + torch.arange(K, device=dev)[None, :] * 0.25).to(_tdt(dt))
+    Cout = torch.empty(M, N, device=dev, dtype=_tdt(dt))
+    d = L.GemmDesc()
+    d.X = L.operand(X.data_ptr(), 0, K)
+    d.Y = L.operand(Y.data_ptr(), 0, K)
+    d.C = Cout.data_ptr()
+    d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+    d.ep = L.epilogue()
+    _run(d, dt)
+    assert torch.equal(Cout.float(), Y.float().t().contiguous())
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+def test_gemm_epilogue_bias_gelu_preact_residual(dt):
+    dev = "cuda"
+    torch.manual_seed(5)
+    M, N, K = 150, 480, 512
+    X = torch.randn(M, K, device=dev).to(_tdt(dt))
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(_tdt(dt))
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev).to(_tdt(dt))
+    Cout = torch.empty(M, N, device=dev, dtype=_tdt(dt))
+    pre = torch.empty(M, N, device=dev, dtype=_tdt(dt))
+    d = L.GemmDesc()
+    d.X = L.operand(X.data_ptr(), 0, K)
+    d.Y = L.operand(W.data_ptr(), 0, K)
+    d.C = Cout.data_ptr()
+    d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+    d.ep = L.epilogue(bias=bias.data_ptr(), act=L.ACT_GELU, preact=pre.data_ptr(), residual=res.data_ptr())
+    _run(d, dt)
+    z = X.double() @ W.double().t() + bias.double()
+    ref = torch.nn.functional.gelu(z) + res.double()
+    rtol, atol = _tol(dt, K)
+    assert (pre.double() - z).abs().max().item() <= (atol + rtol) * z.abs().max().item()
+    assert (Cout.double() - ref).abs().max().item() <= (atol + rtol) * ref.abs().max().item() * 2
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("k,s,cin,cout,T", [(3, 2, 256, 256, 399), (2, 2, 512, 512, 199), (1, 1, 128, 256, 300)])
+def test_conv1d_as_gemm_fwd_dgrad_wgrad(dt, k, s, cin, cout, T):
+    """Channels-last conv1d = GEMM over overlapping windows; its dgrad (two-segment form for k=3,s=2)
+    and wgrad (atomic fp32, index-mapped to the torch [Cout][Cin][k] layout)."""
+    dev = "cuda"
+    torch.manual_seed(k * 100 + s)
+    B = 3
+    Tout = (T - k) // s + 1
+    x = torch.randn(B, T, cin, device=dev).to(_tdt(dt))
+    w = (torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5).to(_tdt(dt))
+    wf = w.permute(0, 2, 1).contiguous().view(cout, k * cin)  # [co][j*Cin + ci]
+    y = torch.empty(B, Tout, cout, device=dev, dtype=_tdt(dt))
+    d = L.GemmDesc()
+    d.X = L.operand(x.data_ptr(), 0, s * cin, rpb=Tout, bstride=T * cin)
+    d.Y = L.operand(wf.data_ptr(), 0, k * cin)
+    d.C = y.data_ptr()
+    d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = B * Tout, cout, k * cin, cout, 1, 1
+    d.ep = L.epilogue()
+    _run(d, dt)
+    xr = x.double().permute(0, 2, 1).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv1d(xr, wr, stride=s)
+    rtol, atol = _tol(dt, k * cin)
+    assert (y.double() - yr.permute(0, 2, 1)).abs().max().item() <= (atol + rtol) * yr.abs().max().item()
+
+    dy = torch.randn(B, Tout, cout, device=dev).to(_tdt(dt))
+    yr.backward(dy.double().permute(0, 2, 1))
+    dx_ref = xr.grad.permute(0, 2, 1)
+    dw_ref = wr.grad
+
+    # ---- dgrad
+    dx = torch.zeros(B, T, cin, device=dev, dtype=_tdt(dt))  # rows past the last window keep 0
+    if k == s or k == 1:
+        d = L.GemmDesc()
+        d.X = L.operand(dy.data_ptr(), 0, cout)
+        d.Y = L.operand(wf.data_ptr(), 1, k * cin)  # Y(j = kk, r = co) = wf[co][kk]
+        d.C = dx.data_ptr()
+        d.M, d.N, d.Kseg, d.groups, d.splitk = B * Tout, k * cin, cout, 1, 1
+        d.ldc, d.c_rpb, d.c_bstride = s * cin, Tout, T * cin
+        d.ep = L.epilogue()
+        _run(d, dt)
+    else:
+        assert (k, s) == (3, 2)
+        # odd rows: dx[2u+1] = dy[u] @ W_1
+        d = L.GemmDesc()
+        d.X = L.operand(dy.data_ptr(), 0, cout)
+        d.Y = L.operand(wf.data_ptr(), 1, k * cin, segoff=(cin, 0))
+        d.C = dx.data_ptr() + cin * dx.element_size()
+        d.M, d.N, d.Kseg, d.groups, d.splitk = B * Tout, cin, cout, 1, 1
+        d.ldc, d.c_rpb, d.c_bstride = 2 * cin, Tout, T * cin
+        d.ep = L.epilogue()
+        _run(d, dt)
+        # even rows: dx[2u] = dy[u] @ W_0 + dy[u-1] @ W_2,  u = 0..Tout  (two reduction segments)
+        n_even = Tout + 1 if 2 * Tout <= T - 1 else Tout
+        d = L.GemmDesc()
+        d.X = L.operand(dy.data_ptr(), 0, cout, rpb=n_even, bstride=Tout * cout, nseg=2, tshift=(0, -1), tvalid=Tout)
+        d.Y = L.operand(wf.data_ptr(), 1, k * cin, nseg=2, segoff=(0, 2 * cin))
+        d.C = dx.data_ptr()
+        d.M, d.N, d.Kseg, d.groups, d.splitk = B * n_even, cin, cout, 1, 1
+        d.ldc, d.c_rpb, d.c_bstride = 2 * cin, n_even, T * cin
+        d.ep = L.epilogue()
+        _run(d, dt)
+    assert (dx.double() - dx_ref).abs().max().item() <= (atol + rtol) * dx_ref.abs().max().item()
+
+    # ---- wgrad: dW[co][ci][j] += sum_m dy[m][co] * xwin[m][j*Cin+ci]   (atomic, split over the reduction)
+    dw = torch.zeros(cout, cin, k, device=dev, dtype=torch.float32)
+    d = L.GemmDesc()
+    d.X = L.operand(dy.data_ptr(), 1, cout)  # X(i = co, r = m)
+    d.Y = L.operand(x.data_ptr(), 1, s * cin, rpb=Tout, bstride=T * cin)  # Y(j = kk, r = m) = window(m)[kk]
+    d.C = dw.data_ptr()
+    d.M, d.N, d.Kseg, d.groups, d.splitk = cout, k * cin, B * Tout, 1, 3
+    d.ldc = cin * k
+    d.ep = L.epilogue(atomic=1, jdiv=cin, sj1=1, sj0=k)
+    _run(d, dt)
+    assert (dw.double() - dw_ref).abs().max().item() <= (atol + rtol) * dw_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+def test_gemm_groups_dropout_rowmask(dt):
+    dev = "cuda"
+    torch.manual_seed(9)
+    G, B, T, K, N = 3, 2, 50, 480, 480
+    M = B * T
+    X = torch.randn(G, M, K, device=dev).to(_tdt(dt))
+    W = (torch.randn(G, N, K, device=dev) / K ** 0.5).to(_tdt(dt))
+    lens = torch.tensor([50, 37], device=dev, dtype=torch.int32)
+    out = torch.empty(G, M, N, device=dev, dtype=_tdt(dt))
+    d = L.GemmDesc()
+    d.X = L.operand(X.data_ptr(), 0, K, gstride=M * K)
+    d.Y = L.operand(W.data_ptr(), 0, K, gstride=N * K)
+    d.C = out.data_ptr()
+    d.M, d.N, d.Kseg, d.groups, d.splitk = M, N, K, G, 1
+    d.ldc, d.c_rpb, d.c_bstride, d.c_gstride = N, T, T * N, M * N
+    d.ep = L.epilogue(row_len=lens.data_ptr(), drop=(0.25, 1234, 7))
+    _run(d, dt)
+    ref = torch.einsum("gmk,gnk->gmn", X.double(), W.double()).view(G, B, T, N)
+    o = out.double().view(G, B, T, N)
+    assert (o[:, 1, 37:] == 0).all()
+    kept = o != 0
+    frac = kept[:, 0].double().mean().item()
+    assert abs(frac - 0.75) < 0.02, frac
+    rtol, atol = _tol(dt, K)
+    diff = (o - ref / 0.75).abs() * kept
+    assert diff.max().item() <= (atol + rtol) * ref.abs().max().item() * 2
+    # the mask is a pure function of (seed, site, index): a second launch reproduces it bit for bit
+    out2 = torch.empty_like(out)
+    d.C = out2.data_ptr()
+    _run(d, dt)
+    assert torch.equal(out, out2)
