@@ -66,9 +66,50 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+# name -> (restype, argtypes) ; mirrors include/fithubert_hip.h one to one
+SIGNATURES = {
+    "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
+    "fh_conv0_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
+    "fh_conv0_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fh_conv0_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fh_layernorm_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _F, Drop, _P]),
+    "fh_layernorm_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, Drop, Drop, _P]),
+    "fh_colsum": (_I, [_I, _P, _P, _I, _I, _L, _I, _L, _L, _I, _F, _P]),
+    "fh_posconv_prepare": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fh_posconv_forward": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fh_posconv_backward_data": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fh_posconv_backward_weight": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fh_posconv_weightnorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fh_attention_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, Drop, _P]),
+    "fh_attention_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, Drop, _P]),
+    "fh_kd_loss_nblk": (_I, [_I, _I, _I, _I]),
+    "fh_kd_loss": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _P]),
+    "fh_cast": (_I, [_I, _P, _P, _L, _P]),
+    "fh_permute3_cast": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fh_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+}
+
+
 def _declare(l: C.CDLL) -> None:
-    l.fh_gemm.argtypes = [C.POINTER(GemmDesc), C.c_int, C.c_void_p]
-    l.fh_gemm.restype = C.c_int
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise HipLibraryMissing(f"{LIB_PATH} is stale: missing symbols {missing}; rebuild with `python -m fithubert_amd.build`")
+
+
+def drop(p: float = 0.0, seed: int = 0, site: int = 0) -> Drop:
+    d = Drop()
+    d.p, d.seed, d.site = p, seed, site
+    return d
 
 
 def check(rc: int, what: str) -> None:

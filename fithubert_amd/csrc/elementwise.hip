@@ -1,0 +1,105 @@
+// Element-wise kernels: dtype casts / weight re-layouts (per-step weight preparation) and fused AdamW.
+//
+//   reference: optimizer built at train.py:407-421 (s3prl AdamW_with_schedule, yaml optimizer section);
+//   AMP weight casting is implicit in torch.cuda.amp (train.py:469,496).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    float f[4];
+    ld4(src + i4, f);
+    st4(dst + i4, f);
+  } else {
+    for (long i = i4; i < n; ++i) dst[i] = from_f<T>(src[i]);
+  }
+}
+
+// dst[a][b][c] (dims d[p0], d[p1], d[p2]) = src[i0][i1][i2] with (a, b, c) = (i[p0], i[p1], i[p2])
+template <typename T>
+__global__ void permute3_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int d2, int p0, int p1,
+                                int p2) {
+  const int d[3] = {d0, d1, d2};
+  const long n = (long)d0 * d1 * d2;
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  const int e1 = d[p1], e2 = d[p2];
+  int idx[3];
+  idx[p2] = (int)(o % e2);
+  idx[p1] = (int)((o / e2) % e1);
+  idx[p0] = (int)(o / ((long)e1 * e2));
+  dst[o] = from_f<T>(src[((long)idx[0] * d1 + idx[1]) * d2 + idx[2]]);
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                             float bc2, float gscale, const float* __restrict__ decay_mask) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const int cnt = (int)min((long)4, n - i4);
+  float pv[4], gv[4], mv[4], vv[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
+  if (cnt == 4) {
+    ld4(p + i4, pv); ld4(g + i4, gv); ld4(m + i4, mv); ld4(v + i4, vv);
+    if (decay_mask) ld4(decay_mask + i4, dm);
+  } else {
+    for (int e = 0; e < cnt; ++e) {
+      pv[e] = p[i4 + e]; gv[e] = g[i4 + e]; mv[e] = m[i4 + e]; vv[e] = v[i4 + e];
+      if (decay_mask) dm[e] = decay_mask[i4 + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gr = gv[e] * gscale;
+    mv[e] = b1 * mv[e] + (1.f - b1) * gr;
+    vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+    const float mh = mv[e] / bc1, vh = vv[e] / bc2;
+    pv[e] -= lr * (mh / (sqrtf(vh) + eps) + wd * dm[e] * pv[e]);
+  }
+  if (cnt == 4) {
+    st4(p + i4, pv); st4(m + i4, mv); st4(v + i4, vv);
+  } else {
+    for (int e = 0; e < cnt; ++e) {
+      p[i4 + e] = pv[e]; m[i4 + e] = mv[e]; v[i4 + e] = vv[e];
+    }
+  }
+}
+
+}  // namespace
+
+int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)((n / 4 + 1 + 255) / 256)), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(cast_kernel<float>, grid, block, 0, st, src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL(cast_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, n);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int d1, int d2, int p0, int p1, int p2,
+                            hipStream_t st) {
+  const long n = (long)d0 * d1 * d2;
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(permute3_kernel<float>, grid, block, 0, st, src, (float*)dst, d0, d1, d2, p0, p1, p2);
+  else
+    hipLaunchKernelGGL(permute3_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, d0, d1, d2, p0, p1, p2);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                    float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, hipStream_t st) {
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)(((n + 3) / 4 + 255) / 256)), block(256);
+  hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale,
+                     decay_mask);
+  FH_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,55 @@
+// Internal launchers of the non-GEMM kernels (all stream-ordered, no allocation, no sync).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/fithubert_hip.h"
+
+// ---- conv0.hip : Conv1d(1, C0, k, s) + GroupNorm(C0, C0) + GELU
+int fh_conv0_nchunk(int T0);
+int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, float2* part, int B, int S, int C0, int K, int stride, float eps,
+                        hipStream_t st);
+int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta,
+                        const void* dy, const float* mean, const float* rstd, float2* part, float2* ab, float* dw,
+                        float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
+                        hipStream_t st);
+
+// ---- norm.hip
+int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                            float* rstd, int M, int C, float eps, fh_drop drop, hipStream_t st);
+int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
+                            const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
+                            int M, int C, fh_drop out_drop, fh_drop in_drop, hipStream_t st);
+int fh_colsum_launch(int dtype, const void* X, float* out, int M, int N, long ldx, int groups, long x_gstride,
+                     long out_gstride, int mod, float scale, hipStream_t st);
+int fh_zero_rows_launch(int dtype, void* x, int B, int Tn, int C, int from, hipStream_t st);
+
+// ---- posconv.hip : weight-normed grouped positional conv (+ GELU + residual), its backward, weight-norm fwd/bwd
+int fh_posconv_prep_launch(int dtype, const float* g, const float* v, void* w_fwd, void* w_bwd, float* norm, int D,
+                           int groups, int K, hipStream_t st);
+int fh_posconv_fwd_launch(int dtype, const void* x, const void* w_fwd, const float* bias, void* zc, void* y, int B,
+                          int Tn, int D, int groups, int K, hipStream_t st);
+int fh_posconv_bwd_data_launch(int dtype, const void* dsum, const void* zc, const void* w_bwd, void* dzc, void* dx,
+                               int B, int Tn, int D, int groups, int K, hipStream_t st);
+int fh_posconv_bwd_weight_launch(int dtype, const void* dzc, const void* x, float* dw, float* dbias, int B, int Tn,
+                                 int D, int groups, int K, hipStream_t st);
+int fh_posconv_wn_bwd_launch(const float* g, const float* v, const float* norm, const float* dw, float* dg, float* dv,
+                             int D, int groups, int K, hipStream_t st);
+
+// ---- attention.hip : multi-head self-attention on a packed [B][T][3*D] q|k|v tensor
+int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int Tn, int H,
+                            int dh, float scale, fh_drop drop, hipStream_t st);
+int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
+                            float* delta, void* dqkv, const int* key_len, int B, int Tn, int H, int dh, float scale,
+                            fh_drop drop, hipStream_t st);
+
+// ---- loss.hip : layer-wise KD loss (MSE / L1) fused with its gradient
+int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
+                      const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L, int B,
+                      int Tp, int Tt, int P, long teacher_lstride, int loss_type, float grad_scale, hipStream_t st);
+
+// ---- elementwise.hip
+int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t st);
+int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int d1, int d2, int p0, int p1, int p2,
+                            hipStream_t st);
+int fh_adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                    float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, hipStream_t st);

@@ -1,0 +1,288 @@
+// LayerNorm forward / backward over the channel dimension and column sums (bias gradients).
+//
+//   reference: fairseq LayerNorm == nn.LayerNorm(eps=1e-5) at modules/model.py:321,447 (512-wide, after
+//   the conv frontend), modules/module.py:251,281 (encoder.layer_norm), :513,518,569,580 (per layer).
+//
+// HBM-bound: one wave per row, 16-byte vector loads, the row lives in registers, two-pass statistics
+// (mean, then centred sum of squares) reduced with wavefront shuffles -- no LDS, no atomics in forward.
+// Backward keeps dgamma/dbeta partials in registers over a strip of rows and issues one fp32 atomic per
+// column per wave.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
+                                                     int C, float eps, DropCfg drop) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunk = C / VEC;
+  const T* xr = x + (long)row * C;
+  float v[NCH][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int ch = lane + 64 * u;
+    if (ch < nchunk) {
+      unpack16<T>(ld16(xr + ch * VEC), v[u]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += v[u][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    if (lane + 64 * u < nchunk) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float d = v[u][e] - mean;
+        ss = fmaf(d, d, ss);
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  T* yr = y + (long)row * C;
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int ch = lane + 64 * u;
+    if (ch < nchunk) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int c = ch * VEC + e;
+        o[e] = fmaf((v[u][e] - mean) * rstd, gamma[c], beta[c]);
+        if (drop.p > 0.f) o[e] *= drop_scale(drop, (unsigned long long)row * C + c);
+      }
+      st16(yr + ch * VEC, pack16<T>(o));
+    }
+  }
+}
+
+// dy_total = (dy [+ dy2]) [* dropmask(out_drop)]  is the gradient w.r.t. the LayerNorm output.
+// dx -> gradient w.r.t. the LayerNorm input; dx2 (optional) = dx * dropmask(in_drop).
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                     const T* __restrict__ x, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                     T* __restrict__ dx, T* __restrict__ dx2, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int C, int rows_per_wave,
+                                                     DropCfg out_drop, DropCfg in_drop) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nchunk = C / VEC;
+  float dg[NCH][VEC], db[NCH][VEC], gm[NCH][VEC];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int ch = lane + 64 * u;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      dg[u][e] = 0.f;
+      db[u][e] = 0.f;
+      gm[u][e] = ch < nchunk ? gamma[ch * VEC + e] : 0.f;
+    }
+  }
+  const int r0 = wave_global * rows_per_wave;
+  const int r1 = min(M, r0 + rows_per_wave);
+  for (int row = r0; row < r1; ++row) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float g[NCH][VEC], xh[NCH][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunk) {
+        float d[VEC], xv[VEC];
+        unpack16<T>(ld16(dy + (long)row * C + ch * VEC), d);
+        if (dy2) {
+          float d2[VEC];
+          unpack16<T>(ld16(dy2 + (long)row * C + ch * VEC), d2);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) d[e] += d2[e];
+        }
+        unpack16<T>(ld16(x + (long)row * C + ch * VEC), xv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if (out_drop.p > 0.f) d[e] *= drop_scale(out_drop, (unsigned long long)row * C + ch * VEC + e);
+          xh[u][e] = (xv[e] - mean) * rstd;
+          dg[u][e] = fmaf(d[e], xh[u][e], dg[u][e]);
+          db[u][e] += d[e];
+          g[u][e] = d[e] * gm[u][e];
+          s1 += g[u][e];
+          s2 = fmaf(g[u][e], xh[u][e], s2);
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)C;
+    const float c2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunk) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = rstd * (g[u][e] - c1 - xh[u][e] * c2);
+        st16(dx + (long)row * C + ch * VEC, pack16<T>(o));
+        if (dx2) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (in_drop.p > 0.f) o[e] *= drop_scale(in_drop, (unsigned long long)row * C + ch * VEC + e);
+          st16(dx2 + (long)row * C + ch * VEC, pack16<T>(o));
+        }
+      }
+    }
+  }
+  if (r0 < r1) {
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          atomicAdd(dgamma + ch * VEC + e, dg[u][e]);
+          atomicAdd(dbeta + ch * VEC + e, db[u][e]);
+        }
+      }
+    }
+  }
+}
+
+// out[n % mod] += sum_m X[m][n]   (fp32 atomics; one 16-byte column chunk per thread, 128-row strips)
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int M, int N,
+                                                     long ldx, long x_gstride, long out_gstride, int mod, float scale) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch * VEC >= N) return;
+  const T* xp = X + (long)blockIdx.z * x_gstride + ch * VEC;
+  const int r0 = blockIdx.y * 128, r1 = min(M, r0 + 128);
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    float v[VEC];
+    unpack16<T>(ld16(xp + (long)r * ldx), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+  }
+  float* o = out + (long)blockIdx.z * out_gstride;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int n = ch * VEC + e;
+    atomicAdd(o + (mod > 0 ? n % mod : n), acc[e] * scale);
+  }
+}
+
+// zero rows [from, T) of every batch item of a [B][T][C] tensor
+template <typename T>
+__global__ void zero_rows_kernel(T* x, int B, int Tn, int C, int from) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const long per_b = (long)(Tn - from) * C / VEC;
+  const long total = per_b * B;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / per_b, r = i - b * per_b;
+    st16(x + ((long)b * Tn + from) * C + r * VEC, v16_zero());
+  }
+}
+
+template <typename T>
+int ln_fwd_t(const T* x, const float* g, const float* b, T* y, float* mean, float* rstd, int M, int C, float eps,
+             DropCfg drop, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (C % VEC) return -301;
+  const int nch = (C / VEC + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+  if (nch == 1)
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop);
+  else if (nch == 2)
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop);
+  else if (nch <= 4)
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop);
+  else
+    return -302;
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const float* rstd, const float* g, T* dx, T* dx2,
+             float* dgamma, float* dbeta, int M, int C, DropCfg out_drop, DropCfg in_drop, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (C % VEC) return -301;
+  const int nch = (C / VEC + 63) / 64;
+  const int rpw = 8;
+  const int waves = (M + rpw - 1) / rpw;
+  dim3 grid((waves + 3) / 4), block(256);
+  if (nch == 1)
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
+                       rpw, out_drop, in_drop);
+  else if (nch == 2)
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
+                       rpw, out_drop, in_drop);
+  else if (nch <= 4)
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
+                       rpw, out_drop, in_drop);
+  else
+    return -302;
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                            float* rstd, int M, int C, float eps, fh_drop drop, hipStream_t st) {
+  if (M <= 0) return 0;
+  return dtype == 0 ? ln_fwd_t<float>((const float*)x, gamma, beta, (float*)y, mean, rstd, M, C, eps, drop, st)
+                    : ln_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, C, eps, drop, st);
+}
+
+int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
+                            const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
+                            int M, int C, fh_drop out_drop, fh_drop in_drop, hipStream_t st) {
+  if (M <= 0) return 0;
+  return dtype == 0 ? ln_bwd_t<float>((const float*)dy, (const float*)dy2, (const float*)x, mean, rstd, gamma,
+                                      (float*)dx, (float*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st)
+                    : ln_bwd_t<bf16>((const bf16*)dy, (const bf16*)dy2, (const bf16*)x, mean, rstd, gamma, (bf16*)dx,
+                                     (bf16*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st);
+}
+
+int fh_colsum_launch(int dtype, const void* X, float* out, int M, int N, long ldx, int groups, long x_gstride,
+                     long out_gstride, int mod, float scale, hipStream_t st) {
+  if (M <= 0 || N <= 0) return 0;
+  const int vec = dtype == 0 ? 4 : 8;
+  if (N % vec || ldx % vec || x_gstride % vec) return -303;
+  dim3 grid((N / vec + 255) / 256, (M + 127) / 128, groups), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)X, out, M, N, ldx, x_gstride, out_gstride,
+                       mod, scale);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, st, (const bf16*)X, out, M, N, ldx, x_gstride, out_gstride,
+                       mod, scale);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_zero_rows_launch(int dtype, void* x, int B, int Tn, int C, int from, hipStream_t st) {
+  if (from >= Tn || B <= 0) return 0;
+  const int vec = dtype == 0 ? 4 : 8;
+  if (C % vec) return -304;
+  const long total = (long)B * (Tn - from) * C / vec;
+  dim3 grid((unsigned)min((long)2048, (total + 255) / 256)), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(zero_rows_kernel<float>, grid, block, 0, st, (float*)x, B, Tn, C, from);
+  else
+    hipLaunchKernelGGL(zero_rows_kernel<bf16>, grid, block, 0, st, (bf16*)x, B, Tn, C, from);
+  FH_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,434 @@
+// Convolutional positional embedding: weight-normed grouped Conv1d(D, D, k=128, pad=64, groups=16) + SamePad +
+// GELU + residual, with backward.
+//
+//   reference: built at modules/module.py:186-208 (weight_norm(dim=2): w = g * v / ||v||_(0,1) per tap, SamePad
+//   drops the last frame, GELU), applied at module.py:276-278 (x = x + pos_conv(x)).
+//
+// Per group this is a [T x (cg*128)] x [(cg*128) x cg] product with cg = 30 channels: every tap is ONE 16x16x32
+// MFMA K-step over the (zero-padded to 32) input channels of the group.  The input window of a 128-frame tile
+// (128 + 127 rows x 32 channels) is staged once in LDS and re-read for all 128 taps; the per-tap 32x32 weight
+// blocks stream from L2.  Data-gradient = the same kernel on flipped/transposed weights with pad 63 and a fused
+// GELU' on the staged operand; weight-gradient reduces over time with transposing LDS reads (ds_read_b64_tr_b16).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int CP = 32;    // padded channels per group
+constexpr int TT = 128;   // output frames per block (fwd / dgrad)
+constexpr int TS = 256;   // frames per staged tile (wgrad)
+
+template <typename T> struct PC {
+  static constexpr int RS = CP * (int)sizeof(T) + 16;  // LDS row stride in bytes
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// ---------------------------------------------------------------- weight norm forward + re-layout
+__global__ void wn_norm2_kernel(const float* __restrict__ v, float* __restrict__ norm2, int rows, int K) {
+  const int j = threadIdx.x;
+  if (j >= K) return;
+  float s = 0.f;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float x = v[(long)r * K + j];
+    s = fmaf(x, x, s);
+  }
+  atomicAdd(norm2 + j, s);
+}
+
+// w_fwd[g][j][co][ci] = w[g*cg+co][ci][j] ; w_bwd[g][j'][ci][co] = w[g*cg+co][ci][K-1-j']  (zero padded to CP)
+template <typename T>
+__global__ void wn_layout_kernel(const float* __restrict__ gsc, const float* __restrict__ v,
+                                 const float* __restrict__ norm2, T* __restrict__ w_fwd, T* __restrict__ w_bwd,
+                                 float* __restrict__ norm, int G, int cg, int K) {
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)G * K * CP * CP;
+  if (o >= n) return;
+  const int b = (int)(o % CP), a = (int)((o / CP) % CP);
+  const int j = (int)((o / (CP * CP)) % K), g = (int)(o / ((long)CP * CP * K));
+  if (g == 0 && a == 0 && b == 0) norm[j] = sqrtf(norm2[j]);
+  float wf = 0.f, wb = 0.f;
+  if (a < cg && b < cg) {
+    // forward: a = co, b = ci, tap j
+    wf = gsc[j] * v[((long)(g * cg + a) * cg + b) * K + j] * rsqrtf(norm2[j]);
+    // backward: a = ci, b = co, tap K-1-j
+    const int jj = K - 1 - j;
+    wb = gsc[jj] * v[((long)(g * cg + b) * cg + a) * K + jj] * rsqrtf(norm2[jj]);
+  }
+  w_fwd[o] = from_f<T>(wf);
+  w_bwd[o] = from_f<T>(wb);
+}
+
+// ---------------------------------------------------------------- fragment helpers
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+  typedef bf16x8 type;
+  static constexpr int NK = 1;  // fragment loads per 32-channel reduction
+  static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int) {
+    return *reinterpret_cast<const bf16x8*>(lds + row * PC<bf16>::RS + (lane >> 4) * 16);
+  }
+  static __device__ __forceinline__ type gmem_row(const bf16* w, int row, int lane, int) {
+    return *reinterpret_cast<const bf16x8*>(w + (long)row * CP + (lane >> 4) * 8);
+  }
+  static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag<float> {
+  typedef f32x4 type;
+  static constexpr int NK = 2;
+  static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int kr) {
+    return *reinterpret_cast<const f32x4*>(lds + row * PC<float>::RS + kr * 64 + (lane >> 4) * 16);
+  }
+  static __device__ __forceinline__ type gmem_row(const float* w, int row, int lane, int kr) {
+    return *reinterpret_cast<const f32x4*>(w + (long)row * CP + kr * 16 + (lane >> 4) * 4);
+  }
+  static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+    return c;
+  }
+};
+
+__device__ __forceinline__ void ld2(const float* p, float* f) {
+  float2 v = *reinterpret_cast<const float2*>(p);
+  f[0] = v.x; f[1] = v.y;
+}
+__device__ __forceinline__ void ld2(const bf16* p, float* f) {
+  uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+  f[0] = __uint_as_float(v << 16);
+  f[1] = __uint_as_float(v & 0xffff0000u);
+}
+__device__ __forceinline__ void st2(float* p, const float* f) { *reinterpret_cast<float2*>(p) = make_float2(f[0], f[1]); }
+__device__ __forceinline__ void st2(bf16* p, const float* f) {
+  *reinterpret_cast<uint32_t*>(p) = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
+}
+
+// stage `nrows` window rows (frame t_first + row, group g) of `src` into LDS as [row][CP] (zero outside [0,Tn)
+// and for padded channels).  GP: multiply by gelu'(zc) and, for rows in [own0, own1), also write the product to dz.
+template <typename T, bool GP>
+__device__ __forceinline__ void stage_rows(unsigned char* lds, const T* src, const T* zc, T* dz, int b, int Tn, int D,
+                                           int cg, int g, int t_first, int nrows, int own0, int own1) {
+  const int units = CP / 2;
+  const int total = nrows * units;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int row = idx / units, u = idx - row * units;
+    const int t = t_first + row;
+    float f[2] = {0.f, 0.f};
+    if (t >= 0 && t < Tn && 2 * u + 1 < cg) {
+      const long off = ((long)b * Tn + t) * D + g * cg + 2 * u;
+      ld2(src + off, f);
+      if (GP) {
+        float z[2];
+        ld2(zc + off, z);
+        f[0] *= gelu_grad_f(z[0]);
+        f[1] *= gelu_grad_f(z[1]);
+        if (row >= own0 && row < own1) st2(dz + off, f);
+      }
+    }
+    st2(reinterpret_cast<T*>(lds + row * PC<T>::RS) + 2 * u, f);
+  }
+}
+
+// ---------------------------------------------------------------- forward / data-gradient
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, const T* __restrict__ zc_in,
+                                                      const T* __restrict__ w, const float* __restrict__ bias,
+                                                      T* __restrict__ out1, T* __restrict__ out2, int B, int Tn, int D,
+                                                      int cg, int K, int pad_left) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  typedef Frag<T> F;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
+  const int nrows = TT + K - 1;
+  stage_rows<T, BWD>(lds, in, zc_in, out1, b, Tn, D, cg, g, t0 - pad_left, nrows, pad_left, pad_left + TT);
+  __syncthreads();
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const T* wg = w + (long)g * K * CP * CP;
+  const int r = lane & 15;
+#pragma unroll 4
+  for (int j = 0; j < K; ++j) {
+#pragma unroll
+    for (int kr = 0; kr < F::NK; ++kr) {
+      typename F::type wf[2], xf[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) wf[cb] = F::gmem_row(wg + (long)j * CP * CP, cb * 16 + r, lane, kr);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) xf[tt] = F::lds_row(lds, wave * 32 + tt * 16 + r + j, lane, kr);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = F::mma(wf[cb], xf[tt], acc[cb][tt]);
+    }
+  }
+
+  const int q = lane >> 4;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int tl = wave * 32 + tt * 16 + r;
+    const int t = t0 + tl;
+    if (t >= Tn) continue;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int co = cb * 16 + q * 4 + 2 * h;
+        if (co + 1 >= cg + 1) continue;  // co, co+1 < cg (cg is even)
+        if (co >= cg) continue;
+        const long off = ((long)b * Tn + t) * D + g * cg + co;
+        float v[2] = {acc[cb][tt][2 * h], acc[cb][tt][2 * h + 1]};
+        if (!BWD) {
+          v[0] += bias[g * cg + co];
+          v[1] += bias[g * cg + co + 1];
+          st2(out1 + off, v);
+          float xv[2];
+          ld2(reinterpret_cast<const T*>(lds + (tl + pad_left) * PC<T>::RS) + co, xv);
+          v[0] = xv[0] + gelu_f(v[0]);
+          v[1] = xv[1] + gelu_f(v[1]);
+          st2(out2 + off, v);
+        } else {
+          float dv[2];
+          ld2(in + off, dv);
+          v[0] += dv[0];
+          v[1] += dv[1];
+          st2(out2 + off, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dws[g][j][co][ci] += sum_{b,t} dzc[b,t,g*cg+co] * x[b, t + j - pad_left, g*cg+ci]
+template <typename T> struct WgFrag;
+template <> struct WgFrag<bf16> {
+  // 8 consecutive frames k = base + 8*(lane>>4) + e for column (c0 + lane&15): two transposing reads
+  static __device__ __forceinline__ bf16x8 load(const unsigned char* lds, int base_row, int c0, int lane) {
+    const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
+    const unsigned char* a0 = lds + (base_row + 8 * q + qq) * PC<bf16>::RS + (c0 + 4 * pp) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * PC<bf16>::RS));
+    union {
+      struct { s16x4 lo, hi; } s;
+      bf16x8 v;
+    } u;
+    u.s.lo = lo;
+    u.s.hi = hi;
+    return u.v;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict__ dzc, const T* __restrict__ x,
+                                                            float* __restrict__ dws, int B, int Tn, int D, int cg, int K,
+                                                            int pad_left, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RS = PC<T>::RS;
+  unsigned char* ldsA = lds;              // dzc tile  [TS][CP]
+  unsigned char* ldsB = lds + TS * RS;    // x window  [TS + K - 1][CP]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.y;
+  const int jbase = blockIdx.x * 32 + wave * 8;
+  const int ntt = (Tn + TS - 1) / TS;
+  f32x4 acc[8][2][2];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) acc[jj][cb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.z; tile < B * ntt; tile += nsplit) {
+    const int b = tile / ntt, t0 = (tile - b * ntt) * TS;
+    __syncthreads();
+    stage_rows<T, false>(ldsA, dzc, nullptr, nullptr, b, Tn, D, cg, g, t0, TS, 0, 0);
+    stage_rows<T, false>(ldsB, x, nullptr, nullptr, b, Tn, D, cg, g, t0 - pad_left, TS + K - 1, 0, 0);
+    __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll 1
+      for (int ks = 0; ks < TS / 32; ++ks) {
+        bf16x8 fa[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) fa[cb] = WgFrag<bf16>::load(ldsA, ks * 32, cb * 16, lane);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          bf16x8 fb[2];
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib) fb[ib] = WgFrag<bf16>::load(ldsB, ks * 32 + jbase + jj, ib * 16, lane);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+              acc[jj][cb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], fb[ib], acc[jj][cb][ib], 0, 0, 0);
+        }
+      }
+    } else {
+      const int r = lane & 15, q = lane >> 4;
+#pragma unroll 1
+      for (int kk = 0; kk < TS / 4; ++kk) {  // 4 frames per MFMA: frame = 4*kk + q
+        float fa[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          fa[cb] = *reinterpret_cast<const float*>(ldsA + (4 * kk + q) * RS + (cb * 16 + r) * 4);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          float fb[2];
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib)
+            fb[ib] = *reinterpret_cast<const float*>(ldsB + (4 * kk + q + jbase + jj) * RS + (ib * 16 + r) * 4);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+              acc[jj][cb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cb], fb[ib], acc[jj][cb][ib], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int j = jbase + jj;
+    if (j >= K) continue;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = cb * 16 + 4 * q + e, ci = ib * 16 + r;
+          if (co < cg && ci < cg) atomicAdd(dws + (((long)g * K + j) * CP + co) * CP + ci, acc[jj][cb][ib][e]);
+        }
+  }
+}
+
+// ---------------------------------------------------------------- weight norm backward
+__global__ void __launch_bounds__(256) wn_dot_kernel(const float* __restrict__ dws, const float* __restrict__ v,
+                                                     float* __restrict__ dot, int cg, int K) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, g = blockIdx.y;
+  float s = 0.f;
+  for (int idx = threadIdx.x; idx < cg * cg; idx += 256) {
+    const int co = idx / cg, ci = idx - co * cg;
+    s = fmaf(dws[(((long)g * K + j) * CP + co) * CP + ci], v[((long)(g * cg + co) * cg + ci) * K + j], s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dot + j, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void wn_apply_kernel(const float* __restrict__ gsc, const float* __restrict__ v, const float* __restrict__ norm,
+                                const float* __restrict__ dws, const float* __restrict__ dot, float* __restrict__ dg,
+                                float* __restrict__ dv, int G, int cg, int K) {
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)G * cg * cg * K;
+  if (o >= n) return;
+  const int j = (int)(o % K);
+  const int ci = (int)((o / K) % cg);
+  const int oc = (int)(o / ((long)K * cg));  // g*cg + co
+  const int g = oc / cg, co = oc - g * cg;
+  const float nj = norm[j], dj = dot[j];
+  const float dw = dws[(((long)g * K + j) * CP + co) * CP + ci];
+  dv[o] += gsc[j] / nj * (dw - v[o] * dj / (nj * nj));
+  if (oc == 0 && ci == 0) dg[j] += dj / nj;
+}
+
+template <typename T> size_t fwd_lds(int K) { return (size_t)(TT + K - 1) * PC<T>::RS; }
+template <typename T> size_t wg_lds(int K) { return (size_t)(2 * TS + K - 1) * PC<T>::RS; }
+
+}  // namespace
+
+int fh_posconv_prep_launch(int dtype, const float* g, const float* v, void* w_fwd, void* w_bwd, float* norm, int D,
+                           int groups, int K, hipStream_t st) {
+  const int cg = D / groups;
+  if (cg > CP || cg % 2 || K > 1024 || K % 32) return -501;
+  // norm doubles as the ||v||^2 accumulator: [0, K) = norm, [K, 2K) = norm2 scratch
+  float* norm2 = norm + K;
+  hipMemsetAsync(norm2, 0, sizeof(float) * K, st);
+  hipLaunchKernelGGL(wn_norm2_kernel, dim3(64), dim3(K), 0, st, v, norm2, D * cg, K);
+  FH_CHECK_LAUNCH();
+  const long n = (long)groups * K * CP * CP;
+  if (dtype == 0)
+    hipLaunchKernelGGL(wn_layout_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2,
+                       (float*)w_fwd, (float*)w_bwd, norm, groups, cg, K);
+  else
+    hipLaunchKernelGGL(wn_layout_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2,
+                       (bf16*)w_fwd, (bf16*)w_bwd, norm, groups, cg, K);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_posconv_fwd_launch(int dtype, const void* x, const void* w_fwd, const float* bias, void* zc, void* y, int B,
+                          int Tn, int D, int groups, int K, hipStream_t st) {
+  const int cg = D / groups;
+  if (cg > CP || cg % 2 || K % 2) return -501;
+  dim3 grid((Tn + TT - 1) / TT, groups, B), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL((posconv_kernel<float, false>), grid, block, fwd_lds<float>(K), st, (const float*)x, nullptr,
+                       (const float*)w_fwd, bias, (float*)zc, (float*)y, B, Tn, D, cg, K, K / 2);
+  else
+    hipLaunchKernelGGL((posconv_kernel<bf16, false>), grid, block, fwd_lds<bf16>(K), st, (const bf16*)x, nullptr,
+                       (const bf16*)w_fwd, bias, (bf16*)zc, (bf16*)y, B, Tn, D, cg, K, K / 2);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_posconv_bwd_data_launch(int dtype, const void* dsum, const void* zc, const void* w_bwd, void* dzc, void* dx,
+                               int B, int Tn, int D, int groups, int K, hipStream_t st) {
+  const int cg = D / groups;
+  if (cg > CP || cg % 2 || K % 2) return -501;
+  dim3 grid((Tn + TT - 1) / TT, groups, B), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL((posconv_kernel<float, true>), grid, block, fwd_lds<float>(K), st, (const float*)dsum,
+                       (const float*)zc, (const float*)w_bwd, nullptr, (float*)dzc, (float*)dx, B, Tn, D, cg, K,
+                       K - 1 - K / 2);
+  else
+    hipLaunchKernelGGL((posconv_kernel<bf16, true>), grid, block, fwd_lds<bf16>(K), st, (const bf16*)dsum,
+                       (const bf16*)zc, (const bf16*)w_bwd, nullptr, (bf16*)dzc, (bf16*)dx, B, Tn, D, cg, K,
+                       K - 1 - K / 2);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_posconv_bwd_weight_launch(int dtype, const void* dzc, const void* x, float* dws, float* dbias, int B, int Tn,
+                                 int D, int groups, int K, hipStream_t st) {
+  const int cg = D / groups;
+  if (cg > CP || cg % 2 || K % 32) return -501;
+  const int ntt = (Tn + TS - 1) / TS;
+  int nsplit = B * ntt;
+  if (nsplit > 8) nsplit = 8;
+  dim3 grid(K / 32, groups, nsplit), block(256);
+  if (dtype == 0) {
+    hipFuncSetAttribute((const void*)posconv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)wg_lds<float>(K));
+    hipLaunchKernelGGL(posconv_wgrad_kernel<float>, grid, block, wg_lds<float>(K), st, (const float*)dzc,
+                       (const float*)x, dws, B, Tn, D, cg, K, K / 2, nsplit);
+  } else {
+    hipLaunchKernelGGL(posconv_wgrad_kernel<bf16>, grid, block, wg_lds<bf16>(K), st, (const bf16*)dzc, (const bf16*)x,
+                       dws, B, Tn, D, cg, K, K / 2, nsplit);
+  }
+  FH_CHECK_LAUNCH();
+  if (dbias) return fh_colsum_launch(dtype, dzc, dbias, B * Tn, D, D, 1, 0, 0, 0, 1.0f, st);
+  return 0;
+}
+
+int fh_posconv_wn_bwd_launch(const float* g, const float* v, const float* norm, const float* dws, float* dg, float* dv,
+                             int D, int groups, int K, hipStream_t st) {
+  const int cg = D / groups;
+  // dot scratch lives behind norm / norm2: [2K, 3K)
+  float* dot = const_cast<float*>(norm) + 2 * K;
+  hipMemsetAsync(dot, 0, sizeof(float) * K, st);
+  hipLaunchKernelGGL(wn_dot_kernel, dim3(K, groups), dim3(256), 0, st, dws, v, dot, cg, K);
+  FH_CHECK_LAUNCH();
+  const long n = (long)groups * cg * cg * K;
+  hipLaunchKernelGGL(wn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm, dws, dot, dg, dv,
+                     groups, cg, K);
+  FH_CHECK_LAUNCH();
+  return 0;
+}

@@ -80,6 +80,86 @@ typedef struct {
 
 int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Waveform frontend layer 0: Conv1d(1, C0, K, stride, bias=False) + GroupNorm(C0, C0) + GELU.
+ * Replaces modules/module.py:65-71 applied at :99-100.  wave [B][S] fp32, y [B][T0][C0] (dtype),
+ * T0 = (S-K)/stride + 1.  scratch: fh_conv0_scratch_floats() floats.  mean/rstd: [B][C0] fp32 (saved
+ * for backward).  Backward accumulates (+=) into dw [C0][K], dgamma, dbeta (fp32), scaled by grad_scale
+ * (feature_grad_mult, modules/model.py:430-431).
+ * ------------------------------------------------------------------------------------------ */
+long fh_conv0_scratch_floats(int B, int S, int C0, int K, int stride);
+int fh_conv0_forward(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
+                     float* mean, float* rstd, float* scratch, int B, int S, int C0, int K, int stride, float eps,
+                     fh_stream_t stream);
+int fh_conv0_backward(int dtype, const float* wave, const float* w, const float* gamma, const float* beta,
+                      const void* dy, const float* mean, const float* rstd, float* scratch, float* dw, float* dgamma,
+                      float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale, fh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (eps as given), optional dropout on the output; saves mean / rstd.
+ * Replaces fairseq LayerNorm at modules/model.py:447, modules/module.py:281,569,580.
+ * Backward: dy_total = (dy [+ dy2]) [* dropmask(out_drop)]; dx = d/dx; optional dx2 = dx * dropmask(in_drop);
+ * dgamma / dbeta accumulate (+=, fp32 atomics).
+ * ------------------------------------------------------------------------------------------ */
+int fh_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                         float* rstd, int M, int C, float eps, fh_drop drop, fh_stream_t stream);
+int fh_layernorm_backward(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
+                          const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
+                          int M, int C, fh_drop out_drop, fh_drop in_drop, fh_stream_t stream);
+/* out[n % mod] += scale * sum_m X[m][n]  (bias gradients) */
+int fh_colsum(int dtype, const void* X, float* out, int M, int N, long ldx, int groups, long x_gstride,
+              long out_gstride, int mod, float scale, fh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutional positional embedding (modules/module.py:186-208, applied :276-278):
+ *   w = g * v / ||v||  (weight_norm dim=2);  zc = conv1d(x, w, bias, pad=K/2, groups)[..., :-1];  y = x + gelu(zc)
+ * prepare: builds the kernel-layout weights w_fwd / w_bwd ([G][K][32][32] dtype each) and norm (3*K floats scratch).
+ * backward_data: dzc = dsum * gelu'(zc) (written), dx = dsum + conv_transpose(dzc).
+ * backward_weight: dws [G][K][32][32] fp32 += sum dzc * x ; dbias += colsum(dzc).
+ * weightnorm_backward: dg += , dv += from dws.
+ * ------------------------------------------------------------------------------------------ */
+int fh_posconv_prepare(int dtype, const float* g, const float* v, void* w_fwd, void* w_bwd, float* norm, int D,
+                       int groups, int K, fh_stream_t stream);
+int fh_posconv_forward(int dtype, const void* x, const void* w_fwd, const float* bias, void* zc, void* y, int B, int T,
+                       int D, int groups, int K, fh_stream_t stream);
+int fh_posconv_backward_data(int dtype, const void* dsum, const void* zc, const void* w_bwd, void* dzc, void* dx, int B,
+                             int T, int D, int groups, int K, fh_stream_t stream);
+int fh_posconv_backward_weight(int dtype, const void* dzc, const void* x, float* dws, float* dbias, int B, int T, int D,
+                               int groups, int K, fh_stream_t stream);
+int fh_posconv_weightnorm_backward(const float* g, const float* v, const float* norm, const float* dws, float* dg,
+                                   float* dv, int D, int groups, int K, fh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head self-attention on packed qkv [B][T][3*H*dh] -> out [B][T][H*dh]; lse [B][H][T] (log2 domain).
+ * Replaces fairseq MultiheadAttention called at modules/module.py:558-564 (q scaling, key_padding_mask as
+ * per-batch valid key count key_len, fp32 softmax, dropout on probabilities).  Backward writes dqkv.
+ * ------------------------------------------------------------------------------------------ */
+int fh_attention_forward(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int T, int H,
+                         int dh, float scale, fh_drop drop, fh_stream_t stream);
+int fh_attention_backward(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                          void* dqkv, const int* key_len, int B, int T, int H, int dh, float scale, fh_drop drop,
+                          fh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layer-wise KD loss + gradient (train.py:250-293,372-378):  out[l] = mean_{b,t,d} f(pred_l - teacher_{tl[l]}),
+ * out[L] = sum_l w[l] * out[l];  dpred_l = grad_scale * w[l] * f'(.) / (B*Tp*P).  loss_type 0 = mse, 1 = l1.
+ * pred [L][B][Tp][P] (dtype); teacher [..][B][Tt][P] (teacher_dtype), narrowed to Tp frames (train.py:282).
+ * partials: L * fh_kd_loss_nblk() floats; out_losses: L+1 doubles.
+ * ------------------------------------------------------------------------------------------ */
+int fh_kd_loss_nblk(int dtype, int B, int Tp, int P);
+int fh_kd_loss(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
+               const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,
+               long teacher_lstride, int loss_type, float grad_scale, fh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight preparation and optimizer (train.py:407-421; AMP casts implicit at train.py:469,496).
+ * ------------------------------------------------------------------------------------------ */
+int fh_cast(int dtype, const float* src, void* dst, long n, fh_stream_t stream);
+int fh_permute3_cast(int dtype, const float* src, void* dst, int d0, int d1, int d2, int p0, int p1, int p2,
+                     fh_stream_t stream);
+int fh_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+             float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, fh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,346 @@
+"""GPU: every non-GEMM HIP kernel through the C ABI against a plain torch fp64/fp32 reference of the same op.
+
+Tolerances (written per test): dtype 0 (fp32 kernels) ~1e-5 relative to the tensor scale; dtype 1 (bf16 storage,
+fp32 accumulate) ~1e-2 relative to the tensor scale (bf16 has 8 significant bits; inputs are bf16-exact)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from fithubert_amd import _lib as L  # noqa: E402
+
+DEV = "cuda"
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _tdt(dt):
+    return torch.float32 if dt == L.DT_F32 else torch.bfloat16
+
+
+def _tol(dt):
+    return 2e-5 if dt == L.DT_F32 else 1.2e-2
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ------------------------------------------------------------------------------------------ conv0 + GroupNorm + GELU
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("C0,S", [(128, 6400), (128, 32000), (512, 4000)])
+def test_conv0_groupnorm_gelu_fwd_bwd(dt, C0, S):
+    torch.manual_seed(C0 + S)
+    B, K, stride = 2, 10, 5
+    T0 = (S - K) // stride + 1
+    wave = (0.5 * torch.randn(B, S, device=DEV)) + 0.05
+    w = torch.randn(C0, K, device=DEV) * (2.0 / K) ** 0.5
+    gamma = 1 + 0.1 * torch.randn(C0, device=DEV)
+    beta = 0.1 * torch.randn(C0, device=DEV)
+    y = torch.empty(B, T0, C0, device=DEV, dtype=_tdt(dt))
+    mean = torch.empty(B, C0, device=DEV)
+    rstd = torch.empty(B, C0, device=DEV)
+    lib = L.lib()
+    scratch = torch.empty(lib.fh_conv0_scratch_floats(B, S, C0, K, stride), device=DEV)
+    L.check(lib.fh_conv0_forward(dt, _p(wave), _p(w), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(scratch), B, S, C0,
+                                 K, stride, 1e-5, _st()), "conv0 fwd")
+    wr = w.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    conv = F.conv1d(wave.double().unsqueeze(1), wr.unsqueeze(1), stride=stride)
+    ref = F.gelu(F.group_norm(conv, C0, gr, br, 1e-5)).transpose(1, 2)
+    assert _rel(y, ref) < _tol(dt)
+    assert _rel(mean, conv.mean(-1)) < 1e-4 or (mean.double() - conv.mean(-1)).abs().max() < 1e-5
+
+    dy = torch.randn(B, T0, C0, device=DEV).to(_tdt(dt))
+    ref.backward(dy.double())
+    dw = torch.zeros(C0, K, device=DEV)
+    dg = torch.zeros(C0, device=DEV)
+    db = torch.zeros(C0, device=DEV)
+    L.check(lib.fh_conv0_backward(dt, _p(wave), _p(w), _p(gamma), _p(beta), _p(dy), _p(mean), _p(rstd), _p(scratch),
+                                  _p(dw), _p(dg), _p(db), B, S, C0, K, stride, 1.0, _st()), "conv0 bwd")
+    tol = 2e-4 if dt == L.DT_F32 else 2e-2  # long fp32 reductions over T0*B
+    assert _rel(dw, wr.grad) < tol
+    assert _rel(dg, gr.grad) < tol
+    assert _rel(db, br.grad) < tol
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("M,C", [(198, 480), (99, 512), (37, 768)])
+def test_layernorm_fwd_bwd(dt, M, C):
+    torch.manual_seed(M + C)
+    x = (torch.randn(M, C, device=DEV) * 1.5 + 0.3).to(_tdt(dt))
+    gamma = 1 + 0.1 * torch.randn(C, device=DEV)
+    beta = 0.1 * torch.randn(C, device=DEV)
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    lib = L.lib()
+    L.check(lib.fh_layernorm_forward(dt, _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, C, 1e-5, L.drop(), _st()), "ln")
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    assert _rel(y, ref) < _tol(dt)
+    dy = torch.randn(M, C, device=DEV).to(_tdt(dt))
+    dy2 = torch.randn(M, C, device=DEV).to(_tdt(dt))
+    ref.backward(dy.double() + dy2.double())
+    dx = torch.empty_like(x)
+    dg = torch.zeros(C, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    L.check(lib.fh_layernorm_backward(dt, _p(dy), _p(dy2), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), None, _p(dg), _p(db),
+                                      M, C, L.drop(), L.drop(), _st()), "ln bwd")
+    assert _rel(dx, xr.grad) < _tol(dt)
+    assert _rel(dg, gr.grad) < _tol(dt) * 3
+    assert _rel(db, br.grad) < _tol(dt) * 3
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+def test_layernorm_dropout_consistency(dt):
+    """forward dropout mask == the mask the backward regenerates; dx2 carries the input-side mask."""
+    torch.manual_seed(1)
+    M, C = 64, 480
+    x = torch.randn(M, C, device=DEV).to(_tdt(dt))
+    gamma = torch.ones(C, device=DEV)
+    beta = torch.zeros(C, device=DEV)
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    lib = L.lib()
+    d_out = L.drop(0.1, 77, 3)
+    L.check(lib.fh_layernorm_forward(dt, _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, C, 1e-5, d_out, _st()), "ln")
+    keep = (y != 0)
+    assert abs(keep.float().mean().item() - 0.9) < 0.02
+    # recover the mask: a gradient of ones through "LN with gamma=1" is awkward; instead probe the mask via dx2 with
+    # in_drop = the same site on an identity-like setup: dy = 1 -> dx2 == dx * mask_in
+    dy = torch.randn(M, C, device=DEV).to(_tdt(dt))
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x)
+    dg = torch.zeros(C, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    L.check(lib.fh_layernorm_backward(dt, _p(dy), None, _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dx2), _p(dg), _p(db),
+                                      M, C, d_out, d_out, _st()), "ln bwd")
+    # dbeta = sum_rows dy * mask / 0.9 with the forward's mask
+    ref_db = (dy.double() * keep.double() / 0.9).sum(0)
+    assert _rel(db, ref_db) < _tol(dt) * 3
+    assert torch.equal(dx2 != 0, (dx != 0) & keep)
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+def test_colsum(dt):
+    torch.manual_seed(2)
+    G, M, N = 3, 300, 960
+    X = torch.randn(G, M, N, device=DEV).to(_tdt(dt))
+    out = torch.zeros(G, 480, device=DEV)
+    L.check(L.lib().fh_colsum(dt, _p(X), _p(out), M, N, N, G, M * N, 480, 480, 1.0, _st()), "colsum")
+    ref = X.double().sum(1).view(G, 2, 480).sum(1)
+    assert _rel(out, ref) < 1e-5 * 10
+
+
+# ------------------------------------------------------------------------------------------ positional conv
+def _posconv_ref(x, g, v, bias, groups, K):
+    w = g * v / v.norm(2, dim=(0, 1), keepdim=True)
+    zc = F.conv1d(x.transpose(1, 2), w, bias, padding=K // 2, groups=groups)[:, :, :-1].transpose(1, 2)
+    return zc, x + F.gelu(zc)
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("B,T", [(2, 99), (1, 499), (3, 19)])
+def test_posconv_fwd_bwd(dt, B, T):
+    torch.manual_seed(B * 1000 + T)
+    D, G, K = 480, 16, 128
+    cg = D // G
+    lib = L.lib()
+    x = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+    g = 0.5 + torch.rand(1, 1, K, device=DEV)
+    v = torch.randn(D, cg, K, device=DEV) * (4.0 / (K * D)) ** 0.5 * 3
+    bias = 0.1 * torch.randn(D, device=DEV)
+    wf = torch.empty(G, K, 32, 32, device=DEV, dtype=_tdt(dt))
+    wb = torch.empty_like(wf)
+    norm = torch.empty(3 * K, device=DEV)
+    L.check(lib.fh_posconv_prepare(dt, _p(g), _p(v), _p(wf), _p(wb), _p(norm), D, G, K, _st()), "prep")
+    zc = torch.empty_like(x)
+    y = torch.empty_like(x)
+    L.check(lib.fh_posconv_forward(dt, _p(x), _p(wf), _p(bias), _p(zc), _p(y), B, T, D, G, K, _st()), "fwd")
+    xr = x.double().requires_grad_(True)
+    gr = g.double().requires_grad_(True)
+    vr = v.double().requires_grad_(True)
+    br = bias.double().requires_grad_(True)
+    zc_ref, y_ref = _posconv_ref(xr, gr, vr, br, G, K)
+    assert _rel(norm[:K], vr.norm(2, dim=(0, 1))) < 1e-5
+    assert _rel(zc, zc_ref) < _tol(dt)
+    assert _rel(y, y_ref) < _tol(dt)
+
+    dsum = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+    y_ref.backward(dsum.double())
+    dzc = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    # use the reference's zc (cast) so that the check isolates the backward kernels
+    zc_in = zc_ref.detach().to(_tdt(dt)).contiguous()
+    L.check(lib.fh_posconv_backward_data(dt, _p(dsum), _p(zc_in), _p(wb), _p(dzc), _p(dx), B, T, D, G, K, _st()), "dgrad")
+    assert _rel(dx, xr.grad) < _tol(dt) * 1.5
+    dws = torch.zeros(G, K, 32, 32, device=DEV)
+    dbias = torch.zeros(D, device=DEV)
+    L.check(lib.fh_posconv_backward_weight(dt, _p(dzc), _p(x), _p(dws), _p(dbias), B, T, D, G, K, _st()), "wgrad")
+    assert _rel(dbias, br.grad) < _tol(dt) * 3
+    dg = torch.zeros(1, 1, K, device=DEV)
+    dv = torch.zeros_like(v)
+    L.check(lib.fh_posconv_weightnorm_backward(_p(g), _p(v), _p(norm), _p(dws), _p(dg), _p(dv), D, G, K, _st()), "wn bwd")
+    assert _rel(dv, vr.grad) < _tol(dt) * 3
+    assert _rel(dg, gr.grad) < _tol(dt) * 3
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, H, dh, key_len):
+    B, T, _ = qkv.shape
+    D = H * dh
+    q, k, v = qkv.split(D, dim=-1)
+    q = q.view(B, T, H, dh).transpose(1, 2)
+    k = k.view(B, T, H, dh).transpose(1, 2)
+    v = v.view(B, T, H, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    if key_len is not None:
+        mask = torch.arange(T, device=qkv.device)[None, :] >= key_len[:, None].long()
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).transpose(1, 2).reshape(B, T, D), s
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (2, 249, True), (1, 130, False), (3, 70, True)])
+def test_attention_fwd_bwd(dt, B, T, masked):
+    torch.manual_seed(B * 7 + T)
+    H, dh = 12, 40
+    D = H * dh
+    lib = L.lib()
+    qkv = (torch.randn(B, T, 3 * D, device=DEV) * 1.2).to(_tdt(dt))
+    key_len = None
+    if masked:
+        key_len = torch.tensor([T, max(1, T * 3 // 4), max(1, T // 2)][:B], device=DEV, dtype=torch.int32)
+    out = torch.empty(B, T, D, device=DEV, dtype=_tdt(dt))
+    lse = torch.empty(B, H, T, device=DEV)
+    L.check(lib.fh_attention_forward(dt, _p(qkv), _p(out), _p(lse), _p(key_len), B, T, H, dh, dh ** -0.5, L.drop(), _st()), "attn")
+    qr = qkv.double().requires_grad_(True)
+    ref, s = _attn_ref(qr, H, dh, key_len)
+    assert _rel(out, ref) < _tol(dt)
+    lse_ref = torch.logsumexp(s, dim=-1) / math.log(2.0)
+    assert (lse.double() - lse_ref).abs().max().item() < (1e-4 if dt == L.DT_F32 else 5e-2)
+    dout = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+    ref.backward(dout.double())
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(B, H, T, device=DEV)
+    out_in = ref.detach().to(_tdt(dt)).contiguous()
+    L.check(lib.fh_attention_backward(dt, _p(qkv), _p(out_in), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(key_len), B, T, H,
+                                      dh, dh ** -0.5, L.drop(), _st()), "attn bwd")
+    assert not torch.isnan(dqkv.float()).any()
+    tol = _tol(dt) * (1.5 if dt == L.DT_F32 else 2.5)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _rel(dqkv[..., sl], qr.grad[..., sl]) < tol, name
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+def test_attention_dropout_is_consistent_between_fwd_and_bwd(dt):
+    """With dropout, out is linear in v for a fixed mask: finite differences of the forward must match the backward's dv,
+    and the kept fraction must be 1-p."""
+    torch.manual_seed(3)
+    B, T, H, dh = 1, 64, 12, 40
+    D = H * dh
+    lib = L.lib()
+    drop = L.drop(0.25, 99, 5)
+    qkv = torch.randn(B, T, 3 * D, device=DEV).to(_tdt(dt))
+    out = torch.empty(B, T, D, device=DEV, dtype=_tdt(dt))
+    lse = torch.empty(B, H, T, device=DEV)
+    L.check(lib.fh_attention_forward(dt, _p(qkv), _p(out), _p(lse), None, B, T, H, dh, dh ** -0.5, drop, _st()), "attn")
+    # V = identity-ish probe: set v of head 0 to one-hot rows to read P_drop directly
+    probe = qkv.clone()
+    probe[0, :, 2 * D:2 * D + dh] = 0
+    for t in range(dh):
+        probe[0, t, 2 * D + t] = 1.0
+    out_p = torch.empty_like(out)
+    L.check(lib.fh_attention_forward(dt, _p(probe), _p(out_p), _p(lse), None, B, T, H, dh, dh ** -0.5, drop, _st()), "attn")
+    pd = out_p[0, :, :dh].double()  # = P_drop[:, :dh] for head 0
+    q = probe[0, :, :dh].double()
+    k = probe[0, :, D:D + dh].double()
+    p = torch.softmax(q @ k.t() * dh ** -0.5, dim=-1)[:, :dh]
+    kept = pd > 0
+    assert abs(kept.double().mean().item() - 0.75) < 0.05
+    assert ((pd - p / 0.75).abs() * kept).max().item() < (1e-5 if dt == L.DT_F32 else 2e-2)
+    # backward with the same mask: dv[key, d] = sum_q P_drop[q, key] * dout[q, d]
+    dout = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, T, device=DEV)
+    L.check(lib.fh_attention_backward(dt, _p(probe), _p(out_p), _p(dout), _p(lse), _p(delta), _p(dqkv), None, B, T, H, dh,
+                                      dh ** -0.5, drop, _st()), "attn bwd")
+    dv_ref = pd.t() @ dout[0, :, :dh].double()  # keys 0..dh-1
+    assert _rel(dqkv[0, :dh, 2 * D:2 * D + dh], dv_ref) < (1e-4 if dt == L.DT_F32 else 3e-2)
+
+
+# ------------------------------------------------------------------------------------------ KD loss
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("tdt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("loss_type", [0, 1])
+def test_kd_loss(dt, tdt, loss_type):
+    torch.manual_seed(4)
+    Lr, B, Tp, Tt, P = 12, 2, 98, 99, 768
+    lib = L.lib()
+    pred = torch.randn(Lr, B, Tp, P, device=DEV).to(_tdt(dt))
+    teacher = torch.randn(Lr, B, Tt, P, device=DEV).to(_tdt(tdt))
+    perm = [4, 0, 9, 2, 7, 10, 1, 5, 8, 3, 6]
+    w = torch.zeros(Lr, device=DEV)
+    w[perm] = 0.1
+    w[11] = 1.0
+    tl = torch.arange(Lr, device=DEV, dtype=torch.int32)
+    nblk = lib.fh_kd_loss_nblk(dt, B, Tp, P)
+    partials = torch.empty(Lr * nblk, device=DEV)
+    out = torch.empty(Lr + 1, device=DEV, dtype=torch.float64)
+    dpred = torch.empty_like(pred)
+    L.check(lib.fh_kd_loss(dt, tdt, _p(pred), _p(teacher), _p(dpred), _p(w), _p(tl), _p(partials), _p(out), Lr, B, Tp, Tt, P,
+                           B * Tt * P, loss_type, 1.0, _st()), "loss")
+    pr = pred.double().requires_grad_(True)
+    diff = pr - teacher.double()[:, :, :Tp]
+    per = (diff ** 2 if loss_type == 0 else diff.abs()).mean((1, 2, 3))
+    total = (per * w.double()).sum()
+    total.backward()
+    assert (out[:Lr] - per).abs().max().item() < 1e-6 * per.abs().max().item()
+    assert abs(out[Lr].item() - total.item()) < 1e-6 * abs(total.item())
+    assert _rel(dpred, pr.grad) < (1e-6 if dt == L.DT_F32 else 5e-3)
+
+
+# ------------------------------------------------------------------------------------------ cast / permute / AdamW
+def test_cast_permute_adamw():
+    torch.manual_seed(5)
+    lib = L.lib()
+    src = torch.randn(1001, device=DEV)
+    dst = torch.empty(1001, device=DEV, dtype=torch.bfloat16)
+    L.check(lib.fh_cast(L.DT_BF16, _p(src), _p(dst), 1001, _st()), "cast")
+    assert torch.equal(dst, src.to(torch.bfloat16))
+    w = torch.randn(7, 5, 3, device=DEV)
+    for dt in (L.DT_F32, L.DT_BF16):
+        for perm in ((0, 2, 1), (2, 1, 0), (1, 0, 2)):
+            out = torch.empty([w.shape[p] for p in perm], device=DEV, dtype=_tdt(dt))
+            L.check(lib.fh_permute3_cast(dt, _p(w), _p(out), 7, 5, 3, *perm, _st()), "permute")
+            assert torch.equal(out, w.permute(*perm).contiguous().to(_tdt(dt)))
+    n = 10007
+    p = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-2)
+    for step in range(1, 4):
+        pr.grad = g.clone() * step
+        opt.step()
+        L.check(lib.fh_adamw(_p(p), _p(g * step), _p(m), _p(v), n, 5e-4, 0.9, 0.98, 1e-6, 1e-2, 1 - 0.9 ** step,
+                             1 - 0.98 ** step, 1.0, None, _st()), "adamw")
+    assert _rel(p, pr.detach()) < 1e-5
