@@ -68,6 +68,37 @@ def lib() -> C.CDLL:
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
+FH_MAX_CONV = 12
+
+
+class StudentConfigC(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("n_conv", C.c_int), ("conv_dim", C.c_int * FH_MAX_CONV), ("conv_k", C.c_int * FH_MAX_CONV),
+        ("conv_stride", C.c_int * FH_MAX_CONV), ("embed_dim", C.c_int), ("ffn_dim", C.c_int), ("heads", C.c_int),
+        ("layers", C.c_int), ("conv_pos", C.c_int), ("conv_pos_groups", C.c_int), ("tr_factor", C.c_int),
+        ("pred_dim", C.c_int), ("dropout", C.c_float), ("attention_dropout", C.c_float),
+        ("activation_dropout", C.c_float), ("dropout_input", C.c_float), ("feature_grad_mult", C.c_float),
+    ]
+
+
+class StudentCallC(C.Structure):
+    _fields_ = [("B", C.c_int), ("S", C.c_int), ("training", C.c_int), ("heads_on", C.c_int), ("seed", C.c_uint32)]
+
+
+_ENGINE_SIGS = {
+    "fh_student_param_count": (_L, [C.POINTER(StudentConfigC)]),
+    "fh_student_param_info": (_I, [C.POINTER(StudentConfigC), _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_I), C.POINTER(_L)]),
+    "fh_student_wc_bytes": (_L, [C.POINTER(StudentConfigC)]),
+    "fh_student_ws_bytes": (_L, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC)]),
+    "fh_student_ws_info": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), C.c_char_p, C.POINTER(_L), C.POINTER(_I),
+                                C.POINTER(_L), C.POINTER(_I)]),
+    "fh_student_frames": (_I, [C.POINTER(StudentConfigC), _I, C.POINTER(_I), C.POINTER(_I)]),
+    "fh_student_prepare": (_I, [C.POINTER(StudentConfigC), _P, _P, _P]),
+    "fh_student_forward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P]),
+    "fh_student_backward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+
 # name -> (restype, argtypes) ; mirrors include/fithubert_hip.h one to one
 SIGNATURES = {
     "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
@@ -90,6 +121,9 @@ SIGNATURES = {
     "fh_permute3_cast": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fh_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
 }
+
+
+SIGNATURES.update(_ENGINE_SIGS)
 
 
 def _declare(l: C.CDLL) -> None:

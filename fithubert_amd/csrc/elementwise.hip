@@ -68,7 +68,80 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// dst = src * gelu'(aux) * scale
+template <typename T>
+__global__ void mul_gelu_grad_kernel(const T* __restrict__ src, const T* __restrict__ aux, T* __restrict__ dst, long nvec,
+                                     float scale) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float a[VEC], z[VEC];
+    unpack16<T>(ld16(src + i * VEC), a);
+    unpack16<T>(ld16(aux + i * VEC), z);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] *= gelu_grad_f(z[e]) * scale;
+    st16(dst + i * VEC, pack16<T>(a));
+  }
+}
+
+// dst[row][c] = src[row][c] * dropmask(row*C + c) * (t(row) < row_len[b(row)])
+template <typename T>
+__global__ void mask_drop_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int C, int rpb,
+                                 const int* __restrict__ row_len, DropCfg drop) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  const long nvec = rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / cpr;
+    const int c0 = (int)(i - row * cpr) * VEC;
+    float a[VEC];
+    unpack16<T>(ld16(src + i * VEC), a);
+    bool zero = false;
+    if (row_len) {
+      const long b = row / rpb;
+      zero = (int)(row - b * rpb) >= row_len[b];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if (zero) a[e] = 0.f;
+      else if (drop.p > 0.f) a[e] *= drop_scale(drop, (unsigned long long)row * C + c0 + e);
+    }
+    st16(dst + i * VEC, pack16<T>(a));
+  }
+}
+
 }  // namespace
+
+int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* dst, long n, float scale, hipStream_t st) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if (n <= 0) return 0;
+  if (n % vec) return -701;
+  const long nvec = n / vec;
+  dim3 grid((unsigned)min((long)4096, (nvec + 255) / 256)), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(mul_gelu_grad_kernel<float>, grid, block, 0, st, (const float*)src, (const float*)aux, (float*)dst,
+                       nvec, scale);
+  else
+    hipLaunchKernelGGL(mul_gelu_grad_kernel<bf16>, grid, block, 0, st, (const bf16*)src, (const bf16*)aux, (bf16*)dst, nvec,
+                       scale);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_mask_drop_launch(int dtype, const void* src, void* dst, long rows, int C, int rpb, const int* row_len, fh_drop drop,
+                        hipStream_t st) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if (rows <= 0) return 0;
+  if (C % vec || (row_len && rpb <= 0)) return -702;
+  const long nvec = rows * (C / vec);
+  dim3 grid((unsigned)min((long)4096, (nvec + 255) / 256)), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(mask_drop_kernel<float>, grid, block, 0, st, (const float*)src, (float*)dst, rows, C, rpb, row_len,
+                       drop);
+  else
+    hipLaunchKernelGGL(mask_drop_kernel<bf16>, grid, block, 0, st, (const bf16*)src, (bf16*)dst, rows, C, rpb, row_len, drop);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
 
 int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t st) {
   if (n <= 0) return 0;

@@ -1,0 +1,940 @@
+// Student engine: CustomStudentModel.forward (reference modules/model.py:420-552) and its backward as one native plan.
+//
+// Data layout in HBM: every activation is channels-last [B][T][C] (so a conv window is a contiguous k*Cin run and
+// conv1d == GEMM with overlapping rows), all in one caller-provided workspace; the 12 transformer layers and the
+// 12 projection heads keep their activations in [L][...] arrays with a uniform stride so that the weight-gradient
+// GEMMs of all layers run as ONE grouped launch (fills 256 CUs without split-K).  Parameters live in one flat fp32
+// buffer (q|k|v adjacent => fused QKV GEMM); gradients in a flat fp32 buffer of the same layout (one all-reduce).
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gemm.h"
+#include "kernels.h"
+
+namespace {
+
+#define RC(x)                 \
+  do {                        \
+    int rc__ = (x);           \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+inline long rup(long x, long a) { return (x + a - 1) / a * a; }
+
+struct PEntry {
+  std::string name;
+  long off;
+  int ndim;
+  long dims[4];
+  long numel() const {
+    long n = 1;
+    for (int i = 0; i < ndim; ++i) n *= dims[i];
+    return n;
+  }
+};
+
+struct ParamLayout {
+  std::vector<PEntry> list;
+  long total = 0;
+  long conv_w[FH_MAX_CONV];
+  long gn_w, gn_b, ln_w, ln_b, post_w, post_b, pos_b, pos_g, pos_v, tr_w, tr_b;
+  long layer0, layer_stride;
+  long l_qkv_w, l_qkv_b, l_o_w, l_o_b, l_ln1_w, l_ln1_b, l_fc1_w, l_fc1_b, l_fc2_w, l_fc2_b, l_ln2_w, l_ln2_b;
+  long enc_ln_w, enc_ln_b, ups_w, ups_b;
+  long head0, head_stride, h_up_w, h_up_b, h_lin_w, h_lin_b;
+
+  long add(const std::string& name, std::initializer_list<long> dims) {
+    PEntry e;
+    e.name = name;
+    e.off = total;
+    e.ndim = (int)dims.size();
+    int i = 0;
+    for (long d : dims) e.dims[i++] = d;
+    for (; i < 4; ++i) e.dims[i] = 1;
+    list.push_back(e);
+    total += rup(e.numel(), 8);
+    return e.off;
+  }
+
+  explicit ParamLayout(const fh_student_config& c) {
+    const long D = c.embed_dim, Fd = c.ffn_dim, P = c.pred_dim;
+    long cin = 1;
+    for (int i = 0; i < c.n_conv; ++i) {
+      conv_w[i] = add("feature_extractor.conv_layers." + std::to_string(i) + ".0.weight", {c.conv_dim[i], cin, c.conv_k[i]});
+      cin = c.conv_dim[i];
+    }
+    gn_w = add("feature_extractor.conv_layers.0.2.weight", {c.conv_dim[0]});
+    gn_b = add("feature_extractor.conv_layers.0.2.bias", {c.conv_dim[0]});
+    ln_w = add("layer_norm.weight", {cin});
+    ln_b = add("layer_norm.bias", {cin});
+    post_w = add("post_extract_proj.weight", {D, cin});
+    post_b = add("post_extract_proj.bias", {D});
+    pos_b = add("encoder.pos_conv.0.bias", {D});
+    pos_g = add("encoder.pos_conv.0.weight_g", {1, 1, c.conv_pos});
+    pos_v = add("encoder.pos_conv.0.weight_v", {D, D / c.conv_pos_groups, c.conv_pos});
+    tr_w = tr_b = -1;
+    if (c.tr_factor > 0) {
+      tr_w = add("encoder.layers.0.weight", {D, D, c.tr_factor});
+      tr_b = add("encoder.layers.0.bias", {D});
+    }
+    layer0 = total;
+    for (int l = 0; l < c.layers; ++l) {
+      const std::string p = "encoder.layers." + std::to_string(l + (c.tr_factor > 0 ? 1 : 0)) + ".";
+      const long base = total;
+      long o;
+      o = add(p + "self_attn.q_proj.weight", {D, D}); if (!l) l_qkv_w = o - base;
+      add(p + "self_attn.k_proj.weight", {D, D});
+      add(p + "self_attn.v_proj.weight", {D, D});
+      o = add(p + "self_attn.q_proj.bias", {D}); if (!l) l_qkv_b = o - base;
+      add(p + "self_attn.k_proj.bias", {D});
+      add(p + "self_attn.v_proj.bias", {D});
+      o = add(p + "self_attn.out_proj.weight", {D, D}); if (!l) l_o_w = o - base;
+      o = add(p + "self_attn.out_proj.bias", {D}); if (!l) l_o_b = o - base;
+      o = add(p + "self_attn_layer_norm.weight", {D}); if (!l) l_ln1_w = o - base;
+      o = add(p + "self_attn_layer_norm.bias", {D}); if (!l) l_ln1_b = o - base;
+      o = add(p + "fc1.weight", {Fd, D}); if (!l) l_fc1_w = o - base;
+      o = add(p + "fc1.bias", {Fd}); if (!l) l_fc1_b = o - base;
+      o = add(p + "fc2.weight", {D, Fd}); if (!l) l_fc2_w = o - base;
+      o = add(p + "fc2.bias", {D}); if (!l) l_fc2_b = o - base;
+      o = add(p + "final_layer_norm.weight", {D}); if (!l) l_ln2_w = o - base;
+      o = add(p + "final_layer_norm.bias", {D}); if (!l) l_ln2_b = o - base;
+      if (!l) layer_stride = total - base;
+    }
+    enc_ln_w = add("encoder.layer_norm.weight", {D});
+    enc_ln_b = add("encoder.layer_norm.bias", {D});
+    ups_w = ups_b = -1;
+    const long f = c.tr_factor > 0 ? c.tr_factor : 1;
+    if (c.tr_factor > 0) {
+      ups_w = add("upsampler.weight", {D, D, f});  // present in the reference state dict, never used (model.py:342-348)
+      ups_b = add("upsampler.bias", {D});
+    }
+    head0 = total;
+    for (int l = 0; l < c.layers; ++l) {
+      const std::string p = "proj_head." + std::to_string(l) + ".";
+      const long base = total;
+      long o;
+      if (c.tr_factor > 0) {
+        o = add(p + "upsampler.weight", {D, D, f}); if (!l) h_up_w = o - base;
+        o = add(p + "upsampler.bias", {D}); if (!l) h_up_b = o - base;
+      } else if (!l) {
+        h_up_w = h_up_b = -1;
+      }
+      o = add(p + "lin_proj.weight", {P, D}); if (!l) h_lin_w = o - base;
+      o = add(p + "lin_proj.bias", {P}); if (!l) h_lin_b = o - base;
+      if (!l) head_stride = total - base;
+    }
+  }
+};
+
+struct WBuf {
+  std::string name;
+  long off;  // bytes
+  int ndim;
+  long dims[4];
+  int esize;
+};
+
+struct Shapes {
+  int B, S, n;
+  int T[FH_MAX_CONV];  // frames after conv layer i
+  int Tp, T2, f;       // frames after the frontend, after time reduction, reduction factor (1 if none)
+  long Mp, M2;
+};
+
+inline int make_shapes(const fh_student_config& c, int B, int S, Shapes& s) {
+  s.B = B; s.S = S; s.n = c.n_conv;
+  long t = S;
+  for (int i = 0; i < c.n_conv; ++i) {
+    if (t < c.conv_k[i]) return -801;
+    t = (t - c.conv_k[i]) / c.conv_stride[i] + 1;
+    s.T[i] = (int)t;
+  }
+  s.Tp = (int)t;
+  s.f = c.tr_factor > 0 ? c.tr_factor : 1;
+  s.T2 = c.tr_factor > 0 ? (s.Tp - c.tr_factor) / c.tr_factor + 1 : s.Tp;
+  if (s.T2 < 1) return -801;
+  s.Mp = (long)B * s.Tp;
+  s.M2 = (long)B * s.T2;
+  return 0;
+}
+
+// compute-dtype weight buffer
+struct WcLayout {
+  long cast_off = 0;      // bf16 copy of the whole flat parameter buffer (bf16 mode only)
+  long conv_wf[FH_MAX_CONV];
+  long tr_wf = -1, head_wup = -1, head_wup_stride = 0, pos_wf, pos_wb, pos_norm;
+  long total = 0;
+  WcLayout(const fh_student_config& c, const ParamLayout& pl) {
+    const int es = c.dtype == 0 ? 4 : 2;
+    long o = 0;
+    if (c.dtype != 0) { cast_off = 0; o = rup(pl.total * 2, 256); }
+    long cin = 1;
+    for (int i = 0; i < c.n_conv; ++i) {
+      conv_wf[i] = o;
+      if (i > 0) o += rup((long)c.conv_dim[i] * cin * c.conv_k[i] * es, 256);
+      cin = c.conv_dim[i];
+    }
+    const long D = c.embed_dim;
+    if (c.tr_factor > 0) {
+      tr_wf = o; o += rup(D * D * c.tr_factor * es, 256);
+      head_wup = o; head_wup_stride = D * D * c.tr_factor;  // elements
+      o += rup(head_wup_stride * c.layers * es, 256);
+    }
+    const long pw = (long)c.conv_pos_groups * c.conv_pos * 32 * 32;
+    pos_wf = o; o += rup(pw * es, 256);
+    pos_wb = o; o += rup(pw * es, 256);
+    pos_norm = o; o += rup(3L * c.conv_pos * 4, 256);
+    total = o;
+  }
+};
+
+struct WsLayout {
+  std::vector<WBuf> bufs;
+  long total = 0;
+  long add(const std::string& name, std::initializer_list<long> dims, int esize) {
+    WBuf b;
+    b.name = name; b.off = total; b.ndim = (int)dims.size(); b.esize = esize;
+    int i = 0; long n = 1;
+    for (long d : dims) { b.dims[i++] = d; n *= d; }
+    for (; i < 4; ++i) b.dims[i] = 1;
+    bufs.push_back(b);
+    total += rup(n * esize, 256);
+    return b.off;
+  }
+  long find(const char* name) const {
+    for (auto& b : bufs) if (b.name == name) return b.off;
+    return -1;
+  }
+};
+
+struct Plan {
+  fh_student_config c;
+  fh_student_call k;
+  ParamLayout pl;
+  WcLayout wl;
+  Shapes sh;
+  WsLayout ws;
+  int es;
+  int ok;
+  // workspace offsets
+  long y[FH_MAX_CONV], z[FH_MAX_CONV], dz[FH_MAX_CONV];
+  long c0_mean, c0_rstd, c0_scratch;
+  long ln0, ln0_mean, ln0_rstd, features, x0, zc, psum, ln1_mean, ln1_rstd, x1;
+  long xo, qkv, attn, lse, s1, st1_mean, st1_rstd, xa, z1, hbuf, f2, s2, st2_mean, st2_rstd;
+  long u, pred;
+  // backward
+  long du, ghead, dxin, ds2, df2, dz1, dx1b, ds1, dao, da, dqkv, delta;
+  long dx1tr, dpsum, dzc, dx0, dfeat, dln0, dylast, pos_dws;
+
+  Plan(const fh_student_config& cfg, const fh_student_call& call) : c(cfg), k(call), pl(cfg), wl(cfg, pl) {
+    es = c.dtype == 0 ? 4 : 2;
+    ok = make_shapes(c, k.B, k.S, sh);
+    if (ok != 0) return;
+    const long B = k.B, D = c.embed_dim, Fd = c.ffn_dim, P = c.pred_dim, L = c.layers, H = c.heads;
+    const long Mp = sh.Mp, M2 = sh.M2;
+    const bool tr = k.training != 0;
+    for (int i = 0; i < c.n_conv; ++i) {
+      y[i] = ws.add("y" + std::to_string(i), {B, sh.T[i], c.conv_dim[i]}, es);
+      z[i] = dz[i] = -1;
+      if (tr && i > 0) z[i] = ws.add("z" + std::to_string(i), {B, sh.T[i], c.conv_dim[i]}, es);
+    }
+    c0_mean = ws.add("c0_mean", {B, c.conv_dim[0]}, 4);
+    c0_rstd = ws.add("c0_rstd", {B, c.conv_dim[0]}, 4);
+    {
+      const long nchunk = fh_conv0_nchunk(sh.T[0]);
+      c0_scratch = ws.add("c0_scratch", {2 * B * nchunk * c.conv_dim[0] + 2 * B * c.conv_dim[0]}, 4);
+    }
+    const long E = c.conv_dim[c.n_conv - 1];
+    ln0 = ws.add("ln0", {Mp, E}, es);
+    ln0_mean = ws.add("ln0_mean", {Mp}, 4);
+    ln0_rstd = ws.add("ln0_rstd", {Mp}, 4);
+    features = ws.add("features", {B, sh.Tp, D}, es);
+    x0 = ws.add("x0", {B, sh.Tp, D}, es);
+    zc = ws.add("zc", {B, sh.Tp, D}, es);
+    psum = ws.add("psum", {B, sh.Tp, D}, es);
+    ln1_mean = ws.add("ln1_mean", {Mp}, 4);
+    ln1_rstd = ws.add("ln1_rstd", {Mp}, 4);
+    x1 = ws.add("x1", {B, sh.Tp, D}, es);
+    // slot 0 = input of layer 0 (time-reduced), slot l+1 = output of layer l
+    xo = ws.add("xo", {L + 1, B, sh.T2, D}, es);
+    qkv = ws.add("qkv", {L, M2, 3 * D}, es);
+    attn = ws.add("attn", {L, M2, D}, es);
+    lse = ws.add("lse", {L, B * H, sh.T2}, 4);
+    s1 = ws.add("s1", {L, M2, D}, es);
+    st1_mean = ws.add("st1_mean", {L, M2}, 4);
+    st1_rstd = ws.add("st1_rstd", {L, M2}, 4);
+    xa = ws.add("xa", {L, M2, D}, es);
+    z1 = ws.add("z1", {L, M2, Fd}, es);
+    hbuf = ws.add("h", {L, M2, Fd}, es);
+    f2 = ws.add("f2", {L, B, sh.T2, D}, es);
+    s2 = ws.add("s2", {L, M2, D}, es);
+    st2_mean = ws.add("st2_mean", {L, M2}, 4);
+    st2_rstd = ws.add("st2_rstd", {L, M2}, 4);
+    const long Lh = k.heads_on ? L : 1;
+    u = ws.add("u", {Lh, B, sh.T2 * sh.f, D}, es);
+    pred = ws.add("pred", {Lh, B, sh.T2 * sh.f, P}, es);
+    if (tr) {
+      du = ws.add("du", {Lh, B, sh.T2 * sh.f, D}, es);
+      ghead = ws.add("ghead", {L, M2, D}, es);
+      dxin = ws.add("dxin", {2, M2, D}, es);
+      ds2 = ws.add("ds2", {M2, D}, es);
+      df2 = ws.add("df2", {L, M2, D}, es);
+      dz1 = ws.add("dz1", {L, M2, Fd}, es);
+      dx1b = ws.add("dx1b", {M2, D}, es);
+      ds1 = ws.add("ds1", {M2, D}, es);
+      dao = ws.add("dao", {L, M2, D}, es);
+      da = ws.add("da", {M2, D}, es);
+      dqkv = ws.add("dqkv", {L, M2, 3 * D}, es);
+      delta = ws.add("delta", {B * H, sh.T2}, 4);
+      dx1tr = ws.add("dx1tr", {B, sh.Tp, D}, es);
+      dpsum = ws.add("dpsum", {B, sh.Tp, D}, es);
+      dzc = ws.add("dzc", {B, sh.Tp, D}, es);
+      dx0 = ws.add("dx0", {B, sh.Tp, D}, es);
+      dfeat = ws.add("dfeat", {B, sh.Tp, D}, es);
+      dln0 = ws.add("dln0", {Mp, E}, es);
+      dylast = ws.add("dylast", {Mp, E}, es);
+      pos_dws = ws.add("pos_dws", {(long)c.conv_pos_groups * c.conv_pos * 32 * 32}, 4);
+      for (int i = 0; i < c.n_conv; ++i) dz[i] = ws.add("dz" + std::to_string(i), {B, sh.T[i], c.conv_dim[i]}, es);
+    }
+  }
+};
+
+inline int validate(const fh_student_config& c) {
+  if (c.dtype != 0 && c.dtype != 1) return -810;
+  if (c.n_conv < 1 || c.n_conv > FH_MAX_CONV) return -811;
+  if (c.conv_k[0] > 16) return -812;
+  const int vec = c.dtype == 0 ? 4 : 8;
+  for (int i = 0; i < c.n_conv; ++i)
+    if (c.conv_dim[i] % 64) return -813;
+  if (c.embed_dim % c.heads || c.embed_dim % c.conv_pos_groups || c.embed_dim % vec || c.ffn_dim % vec || c.pred_dim % 8)
+    return -814;
+  if (c.tr_factor != 0 && c.tr_factor != 2) return -815;  // shipped configs: conv1d TR with factor 2 at index 0
+  for (int i = 1; i < c.n_conv; ++i) {
+    const int kk = c.conv_k[i], s = c.conv_stride[i];
+    if (!((kk == s) || (kk == 1 && s == 1) || (kk == 3 && s == 2))) return -816;
+  }
+  return 0;
+}
+
+struct Ctx {
+  const Plan& p;
+  const float* params;
+  const unsigned char* wc;
+  unsigned char* ws;
+  hipStream_t st;
+  int dt;
+  template <typename T = void> T* W(long off) const { return reinterpret_cast<T*>(ws + off); }
+  // natural-layout weight in compute dtype
+  const void* nat(long poff) const {
+    return p.c.dtype == 0 ? (const void*)(params + poff) : (const void*)(wc + p.wl.cast_off + poff * 2);
+  }
+  const void* rel(long boff) const { return wc + boff; }
+  fh_drop drop(float prob, uint32_t site) const {
+    fh_drop d;
+    d.p = p.k.training ? prob : 0.f;
+    d.seed = p.k.seed;
+    d.site = site;
+    return d;
+  }
+  unsigned char* at(long off, long elems) const { return ws + off + elems * p.es; }
+};
+
+enum { SITE_INPUT = 1, SITE_ENC = 2, SITE_LAYER0 = 16 };
+
+inline int splitk_for(long tiles, long red) {
+  long sk = (512 + tiles - 1) / tiles;
+  const long maxsk = red / 512 > 0 ? red / 512 : 1;
+  if (sk > maxsk) sk = maxsk;
+  if (sk < 1) sk = 1;
+  if (sk > 64) sk = 64;
+  return (int)sk;
+}
+
+// weight-gradient GEMM: dW[n][kk] += sum_m dC[m][n] * A(m)[kk]   (atomic accumulate into the fp32 grad buffer)
+inline int wgrad(const Ctx& x, const void* dC, long ld_dc, const GemmOperand& A, float* dW, int N, int Kout, long Mred,
+                 int groups, long dc_g, long dw_g, int jdiv = 0, long sj1 = 0, long sj0 = 0, int idiv = 0, long si1 = 0,
+                 long si0 = 0, long ldc = -1) {
+  GemmParams g = fh_gemm_params();
+  g.X = fh_operand(dC, FH_R_STRIDED, ld_dc);
+  g.X.gstride = dc_g;
+  g.Y = A;
+  g.C = dW;
+  g.M = N; g.N = Kout; g.Kseg = (int)Mred;
+  g.ldc = ldc >= 0 ? ldc : Kout;
+  g.c_gstride = dw_g;
+  g.groups = groups;
+  g.ep.atomic = 1;
+  g.ep.jdiv = jdiv; g.ep.sj1 = sj1; g.ep.sj0 = sj0;
+  g.ep.idiv = idiv; g.ep.si1 = si1; g.ep.si0 = si0;
+  const long tiles = (long)((N + 127) / 128) * ((Kout + 127) / 128) * groups;
+  g.splitk = splitk_for(tiles, Mred);
+  return fh_gemm_launch(g, x.dt, x.st);
+}
+
+int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t st) {
+  const fh_student_config& c = p.c;
+  const int dt = c.dtype;
+  if (dt != 0) RC(fh_cast_launch(dt, params, wc + p.wl.cast_off, p.pl.total, st));
+  long cin = c.conv_dim[0];
+  for (int i = 1; i < c.n_conv; ++i) {
+    // [Cout][Cin][k] -> [Cout][k][Cin]
+    RC(fh_permute3_cast_launch(dt, params + p.pl.conv_w[i], wc + p.wl.conv_wf[i], c.conv_dim[i], (int)cin, c.conv_k[i], 0, 2, 1, st));
+    cin = c.conv_dim[i];
+  }
+  const int D = c.embed_dim;
+  if (c.tr_factor > 0) {
+    RC(fh_permute3_cast_launch(dt, params + p.pl.tr_w, wc + p.wl.tr_wf, D, D, c.tr_factor, 0, 2, 1, st));
+    const int es = dt == 0 ? 4 : 2;
+    for (int l = 0; l < c.layers; ++l)
+      // ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin]
+      RC(fh_permute3_cast_launch(dt, params + p.pl.head0 + l * p.pl.head_stride + p.pl.h_up_w,
+                                 wc + p.wl.head_wup + (long)l * p.wl.head_wup_stride * es, D, D, c.tr_factor, 2, 1, 0, st));
+  }
+  RC(fh_posconv_prep_launch(dt, params + p.pl.pos_g, params + p.pl.pos_v, wc + p.wl.pos_wf, wc + p.wl.pos_wb,
+                            (float*)(wc + p.wl.pos_norm), D, c.conv_pos_groups, c.conv_pos, st));
+  return 0;
+}
+
+int forward(const Ctx& x, const float* wave, const int* lens) {
+  const Plan& p = x.p;
+  const fh_student_config& c = p.c;
+  const Shapes& s = p.sh;
+  const int dt = x.dt, B = s.B, D = c.embed_dim, Fd = c.ffn_dim, P = c.pred_dim, L = c.layers, H = c.heads;
+  const bool tr = p.k.training != 0;
+  const int* len_p = lens;
+  const int* len_2 = lens ? lens + B : nullptr;
+  const float* prm = x.params;
+
+  // ---- conv frontend (modules/module.py:94-102)
+  RC(fh_conv0_fwd_launch(dt, wave, prm + p.pl.conv_w[0], prm + p.pl.gn_w, prm + p.pl.gn_b, x.W(p.y[0]), x.W<float>(p.c0_mean),
+                         x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch), B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0],
+                         1e-5f, x.st));
+  for (int i = 1; i < c.n_conv; ++i) {
+    const int cin = c.conv_dim[i - 1], kk = c.conv_k[i], sd = c.conv_stride[i];
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(x.W(p.y[i - 1]), FH_R_CONTIG, (long)sd * cin);
+    g.X.rpb = s.T[i]; g.X.bstride = (long)s.T[i - 1] * cin;
+    g.Y = fh_operand(x.rel(p.wl.conv_wf[i]), FH_R_CONTIG, (long)kk * cin);
+    g.C = x.W(p.y[i]);
+    g.M = B * s.T[i]; g.N = c.conv_dim[i]; g.Kseg = kk * cin; g.ldc = c.conv_dim[i];
+    g.ep.act = FH_ACT_GELU;
+    if (tr) g.ep.preact = x.W(p.z[i]);
+    RC(fh_gemm_launch(g, dt, x.st));
+  }
+  // ---- LayerNorm + post_extract_proj (+ dropout_input, zero padded frames)   model.py:446-489, module.py:273-274
+  const int E = c.conv_dim[c.n_conv - 1];
+  RC(fh_layernorm_fwd_launch(dt, x.W(p.y[c.n_conv - 1]), prm + p.pl.ln_w, prm + p.pl.ln_b, x.W(p.ln0), x.W<float>(p.ln0_mean),
+                             x.W<float>(p.ln0_rstd), (int)s.Mp, E, 1e-5f, x.drop(0.f, 0), x.st));
+  {
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(x.W(p.ln0), FH_R_CONTIG, E);
+    g.Y = fh_operand(x.nat(p.pl.post_w), FH_R_CONTIG, E);
+    g.M = (int)s.Mp; g.N = D; g.Kseg = E; g.ldc = D;
+    g.c_rpb = s.Tp; g.c_bstride = (long)s.Tp * D;
+    g.ep.bias = prm + p.pl.post_b;
+    g.ep.row_len = len_p;
+    const bool aliased = !tr || c.dropout_input == 0.f;  // reference aliasing of results["features"], see oracle
+    if (aliased) {
+      g.C = x.W(p.features);
+      RC(fh_gemm_launch(g, dt, x.st));
+      RC((int)hipMemcpyAsync(x.W(p.x0), x.W(p.features), s.Mp * D * p.es, hipMemcpyDeviceToDevice, x.st));
+    } else {
+      g.C = x.W(p.x0);
+      g.ep.preact = x.W(p.features);
+      g.ep.drop = x.drop(c.dropout_input, SITE_INPUT);
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+  }
+  // ---- positional conv + residual, LayerNorm, dropout   module.py:276-294
+  RC(fh_posconv_fwd_launch(dt, x.W(p.x0), x.rel(p.wl.pos_wf), prm + p.pl.pos_b, x.W(p.zc), x.W(p.psum), B, s.Tp, D,
+                           c.conv_pos_groups, c.conv_pos, x.st));
+  RC(fh_layernorm_fwd_launch(dt, x.W(p.psum), prm + p.pl.enc_ln_w, prm + p.pl.enc_ln_b, c.tr_factor > 0 ? x.W(p.x1) : x.W(p.xo),
+                             x.W<float>(p.ln1_mean), x.W<float>(p.ln1_rstd), (int)s.Mp, D, 1e-5f, x.drop(c.dropout, SITE_ENC), x.st));
+  // ---- time-reduction conv (k = s = factor)   module.py:317-321
+  if (c.tr_factor > 0) {
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(x.W(p.x1), FH_R_CONTIG, (long)s.f * D);
+    g.X.rpb = s.T2; g.X.bstride = (long)s.Tp * D;
+    g.Y = fh_operand(x.rel(p.wl.tr_wf), FH_R_CONTIG, (long)s.f * D);
+    g.C = x.W(p.xo);
+    g.M = (int)s.M2; g.N = D; g.Kseg = s.f * D; g.ldc = D;
+    g.ep.bias = prm + p.pl.tr_b;
+    RC(fh_gemm_launch(g, dt, x.st));
+  }
+  // ---- transformer layers (post-LN)   module.py:557-582
+  const long M2 = s.M2;
+  const float scale = 1.0f / sqrtf((float)(D / H));
+  for (int l = 0; l < L; ++l) {
+    const float* lp = prm + p.pl.layer0 + (long)l * p.pl.layer_stride;
+    const long lpo = p.pl.layer0 + (long)l * p.pl.layer_stride;
+    unsigned char* xin = x.at(p.xo, (long)l * M2 * D);
+    unsigned char* xout = x.at(p.xo, (long)(l + 1) * M2 * D);
+    const uint32_t site = SITE_LAYER0 + 4 * l;
+    {  // fused q|k|v projection
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(xin, FH_R_CONTIG, D);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_qkv_w), FH_R_CONTIG, D);
+      g.C = x.at(p.qkv, (long)l * M2 * 3 * D);
+      g.M = (int)M2; g.N = 3 * D; g.Kseg = D; g.ldc = 3 * D;
+      g.ep.bias = lp + p.pl.l_qkv_b;
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    RC(fh_attention_fwd_launch(dt, x.at(p.qkv, (long)l * M2 * 3 * D), x.at(p.attn, (long)l * M2 * D),
+                               x.W<float>(p.lse) + (long)l * B * H * s.T2, len_2, B, s.T2, H, D / H, scale,
+                               x.drop(c.attention_dropout, site + 0), x.st));
+    {  // out_proj + dropout1 + residual
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.at(p.attn, (long)l * M2 * D), FH_R_CONTIG, D);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_o_w), FH_R_CONTIG, D);
+      g.C = x.at(p.s1, (long)l * M2 * D);
+      g.M = (int)M2; g.N = D; g.Kseg = D; g.ldc = D;
+      g.ep.bias = lp + p.pl.l_o_b;
+      g.ep.drop = x.drop(c.dropout, site + 1);
+      g.ep.residual = xin;
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    RC(fh_layernorm_fwd_launch(dt, x.at(p.s1, (long)l * M2 * D), lp + p.pl.l_ln1_w, lp + p.pl.l_ln1_b, x.at(p.xa, (long)l * M2 * D),
+                               x.W<float>(p.st1_mean) + l * M2, x.W<float>(p.st1_rstd) + l * M2, (int)M2, D, 1e-5f,
+                               x.drop(0.f, 0), x.st));
+    {  // fc1 + GELU + dropout2
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.at(p.xa, (long)l * M2 * D), FH_R_CONTIG, D);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_fc1_w), FH_R_CONTIG, D);
+      g.C = x.at(p.hbuf, (long)l * M2 * Fd);
+      g.M = (int)M2; g.N = Fd; g.Kseg = D; g.ldc = Fd;
+      g.ep.bias = lp + p.pl.l_fc1_b;
+      g.ep.act = FH_ACT_GELU;
+      if (tr) g.ep.preact = x.at(p.z1, (long)l * M2 * Fd);
+      g.ep.drop = x.drop(c.activation_dropout, site + 2);
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    {  // fc2 (layer_result) + dropout3 + residual
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.at(p.hbuf, (long)l * M2 * Fd), FH_R_CONTIG, Fd);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_fc2_w), FH_R_CONTIG, Fd);
+      g.C = x.at(p.s2, (long)l * M2 * D);
+      g.M = (int)M2; g.N = D; g.Kseg = Fd; g.ldc = D;
+      g.ep.bias = lp + p.pl.l_fc2_b;
+      g.ep.preact = x.at(p.f2, (long)l * M2 * D);
+      g.ep.drop = x.drop(c.dropout, site + 3);
+      g.ep.residual = x.at(p.xa, (long)l * M2 * D);
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    RC(fh_layernorm_fwd_launch(dt, x.at(p.s2, (long)l * M2 * D), lp + p.pl.l_ln2_w, lp + p.pl.l_ln2_b, xout,
+                               x.W<float>(p.st2_mean) + l * M2, x.W<float>(p.st2_rstd) + l * M2, (int)M2, D, 1e-5f,
+                               x.drop(0.f, 0), x.st));
+  }
+  // ---- projection heads (LayerWiseProjHead, module.py:649-661): ConvTranspose1d(k = s = f) then Linear D -> P
+  {
+    const int Lh = p.k.heads_on ? L : 1;
+    const int l0 = p.k.heads_on ? 0 : L - 1;
+    const long hp0 = p.pl.head0 + (long)l0 * p.pl.head_stride;
+    const void* lin_in = x.at(p.xo, (long)(l0 + 1) * M2 * D);
+    long lin_in_g = M2 * D;
+    if (c.tr_factor > 0) {
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(lin_in, FH_R_CONTIG, D);
+      g.X.gstride = M2 * D;
+      g.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wup) + (long)l0 * p.wl.head_wup_stride * p.es, FH_R_CONTIG, D);
+      g.Y.gstride = p.wl.head_wup_stride;
+      g.C = x.W(p.u);
+      g.M = (int)M2; g.N = s.f * D; g.Kseg = D; g.ldc = (long)s.f * D;
+      g.c_gstride = M2 * s.f * D;
+      g.groups = Lh;
+      g.ep.bias = prm + hp0 + p.pl.h_up_b;
+      g.ep.bias_gstride = p.pl.head_stride;
+      g.ep.bias_mod = D;
+      RC(fh_gemm_launch(g, dt, x.st));
+      lin_in = x.W(p.u);
+      lin_in_g = M2 * s.f * D;
+    }
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(lin_in, FH_R_CONTIG, D);
+    g.X.gstride = lin_in_g;
+    g.Y = fh_operand(x.nat(hp0 + p.pl.h_lin_w), FH_R_CONTIG, D);
+    g.Y.gstride = p.pl.head_stride;
+    g.C = x.W(p.pred);
+    g.M = (int)(M2 * s.f); g.N = P; g.Kseg = D; g.ldc = P;
+    g.c_gstride = M2 * s.f * P;
+    g.groups = Lh;
+    g.ep.bias = prm + hp0 + p.pl.h_lin_b;
+    g.ep.bias_gstride = p.pl.head_stride;
+    RC(fh_gemm_launch(g, dt, x.st));
+  }
+  return 0;
+}
+
+int backward(const Ctx& x, float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden) {
+  const Plan& p = x.p;
+  const fh_student_config& c = p.c;
+  const Shapes& s = p.sh;
+  const int dt = x.dt, B = s.B, D = c.embed_dim, Fd = c.ffn_dim, P = c.pred_dim, L = c.layers, H = c.heads;
+  if (!p.k.training) return -820;
+  const int* len_p = lens;
+  const int* len_2 = lens ? lens + B : nullptr;
+  const long M2 = s.M2;
+  const float scale = 1.0f / sqrtf((float)(D / H));
+  const int Lh = p.k.heads_on ? L : 1;
+  const int l0 = p.k.heads_on ? 0 : L - 1;
+  const long hp0 = p.pl.head0 + (long)l0 * p.pl.head_stride;
+
+  // ---------------- heads: d_pred -> du -> ghead (+ d_hidden), and head weight gradients
+  bool have_ghead = false;
+  if (d_pred) {
+    const void* dlin_in;  // gradient w.r.t. the Linear's input
+    if (c.tr_factor > 0) {
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(d_pred, FH_R_CONTIG, P);
+      g.X.gstride = M2 * s.f * P;
+      g.Y = fh_operand(x.nat(hp0 + p.pl.h_lin_w), FH_R_STRIDED, D);
+      g.Y.gstride = p.pl.head_stride;
+      g.C = x.W(p.du);
+      g.M = (int)(M2 * s.f); g.N = D; g.Kseg = P; g.ldc = D;
+      g.c_gstride = M2 * s.f * D;
+      g.groups = Lh;
+      RC(fh_gemm_launch(g, dt, x.st));
+      dlin_in = x.W(p.du);
+      // ghead[l] = du[l] (as [M2][f*D]) . Wup'  (+ d_hidden)
+      GemmParams g2 = fh_gemm_params();
+      g2.X = fh_operand(x.W(p.du), FH_R_CONTIG, (long)s.f * D);
+      g2.X.gstride = M2 * s.f * D;
+      g2.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wup) + (long)l0 * p.wl.head_wup_stride * p.es, FH_R_STRIDED, D);
+      g2.Y.gstride = p.wl.head_wup_stride;
+      g2.C = x.at(p.ghead, (long)l0 * M2 * D);
+      g2.M = (int)M2; g2.N = D; g2.Kseg = s.f * D; g2.ldc = D;
+      g2.c_gstride = M2 * D;
+      g2.groups = Lh;
+      if (d_hidden) {
+        g2.ep.residual = (const unsigned char*)d_hidden + (long)l0 * M2 * D * p.es;
+      }
+      RC(fh_gemm_launch(g2, dt, x.st));
+    } else {
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(d_pred, FH_R_CONTIG, P);
+      g.X.gstride = M2 * P;
+      g.Y = fh_operand(x.nat(hp0 + p.pl.h_lin_w), FH_R_STRIDED, D);
+      g.Y.gstride = p.pl.head_stride;
+      g.C = x.at(p.ghead, (long)l0 * M2 * D);
+      g.M = (int)M2; g.N = D; g.Kseg = P; g.ldc = D;
+      g.c_gstride = M2 * D;
+      g.groups = Lh;
+      if (d_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)l0 * M2 * D * p.es;
+      RC(fh_gemm_launch(g, dt, x.st));
+      dlin_in = nullptr;
+    }
+    (void)dlin_in;
+    have_ghead = true;
+    // weight grads of the heads
+    const void* lin_x = c.tr_factor > 0 ? (const void*)x.W(p.u) : (const void*)x.at(p.xo, (long)(l0 + 1) * M2 * D);
+    const long lin_x_g = c.tr_factor > 0 ? M2 * s.f * D : M2 * D;
+    {
+      GemmOperand A = fh_operand(lin_x, FH_R_STRIDED, D);
+      A.gstride = lin_x_g;
+      RC(wgrad(x, d_pred, P, A, grads + hp0 + p.pl.h_lin_w, P, D, M2 * s.f, Lh, M2 * s.f * P, p.pl.head_stride));
+      RC(fh_colsum_launch(dt, d_pred, grads + hp0 + p.pl.h_lin_b, (int)(M2 * s.f), P, P, Lh, M2 * s.f * P, p.pl.head_stride, 0, 1.f, x.st));
+    }
+    if (c.tr_factor > 0) {
+      // dWup[ci][co][j] += sum_m du[m][j*D+co] * xo[m][ci] :  i = j*D+co, column = ci
+      GemmOperand A = fh_operand(x.at(p.xo, (long)(l0 + 1) * M2 * D), FH_R_STRIDED, D);
+      A.gstride = M2 * D;
+      RC(wgrad(x, x.W(p.du), (long)s.f * D, A, grads + hp0 + p.pl.h_up_w, s.f * D, D, M2, Lh, M2 * s.f * D, p.pl.head_stride,
+               /*jdiv*/ 1, /*sj1*/ (long)D * s.f, /*sj0*/ 0, /*idiv*/ D, /*si1*/ 1, /*si0*/ s.f));
+      RC(fh_colsum_launch(dt, x.W(p.du), grads + hp0 + p.pl.h_up_b, (int)M2, s.f * D, (long)s.f * D, Lh, M2 * s.f * D,
+                          p.pl.head_stride, D, 1.f, x.st));
+    }
+  }
+
+  // ---------------- transformer layers, last to first
+  const void* dy_next = nullptr;  // gradient w.r.t. xo[l+1] coming from layer l+1
+  for (int l = L - 1; l >= 0; --l) {
+    const long lpo = p.pl.layer0 + (long)l * p.pl.layer_stride;
+    const float* lp = x.params + lpo;
+    float* lg = grads + lpo;
+    const uint32_t site = SITE_LAYER0 + 4 * l;
+    const void* g_head = nullptr;
+    if (have_ghead && (p.k.heads_on || l == L - 1)) g_head = x.at(p.ghead, (long)l * M2 * D);
+    else if (d_hidden) g_head = (const unsigned char*)d_hidden + (long)l * M2 * D * p.es;
+    const void* dy = dy_next ? dy_next : g_head;
+    const void* dy2 = dy_next ? g_head : nullptr;
+    if (!dy) return -821;  // no gradient reaches this layer's output
+    // LN2 backward -> ds2 ; df2 = ds2 * mask3
+    const bool drop3 = c.dropout > 0.f;
+    unsigned char* df2_l = x.at(p.df2, (long)l * M2 * D);
+    RC(fh_layernorm_bwd_launch(dt, dy, dy2, x.at(p.s2, (long)l * M2 * D), x.W<float>(p.st2_mean) + l * M2,
+                               x.W<float>(p.st2_rstd) + l * M2, lp + p.pl.l_ln2_w, x.W(p.ds2), df2_l, lg + p.pl.l_ln2_w,
+                               lg + p.pl.l_ln2_b, (int)M2, D, x.drop(0.f, 0), x.drop(drop3 ? c.dropout : 0.f, site + 3), x.st));
+    {  // dz1 = (df2 . W2) * mask2 * gelu'(z1)
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(df2_l, FH_R_CONTIG, D);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_fc2_w), FH_R_STRIDED, Fd);
+      g.C = x.at(p.dz1, (long)l * M2 * Fd);
+      g.M = (int)M2; g.N = Fd; g.Kseg = D; g.ldc = Fd;
+      g.ep.drop = x.drop(c.activation_dropout, site + 2);
+      g.ep.gelu_aux = x.at(p.z1, (long)l * M2 * Fd);
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    {  // dx1 = dz1 . W1 + ds2
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.at(p.dz1, (long)l * M2 * Fd), FH_R_CONTIG, Fd);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_fc1_w), FH_R_STRIDED, D);
+      g.C = x.W(p.dx1b);
+      g.M = (int)M2; g.N = D; g.Kseg = Fd; g.ldc = D;
+      g.ep.residual = x.W(p.ds2);
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    unsigned char* dao_l = x.at(p.dao, (long)l * M2 * D);
+    RC(fh_layernorm_bwd_launch(dt, x.W(p.dx1b), nullptr, x.at(p.s1, (long)l * M2 * D), x.W<float>(p.st1_mean) + l * M2,
+                               x.W<float>(p.st1_rstd) + l * M2, lp + p.pl.l_ln1_w, x.W(p.ds1), dao_l, lg + p.pl.l_ln1_w,
+                               lg + p.pl.l_ln1_b, (int)M2, D, x.drop(0.f, 0), x.drop(c.dropout, site + 1), x.st));
+    {  // da = dao . Wo
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(dao_l, FH_R_CONTIG, D);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_o_w), FH_R_STRIDED, D);
+      g.C = x.W(p.da);
+      g.M = (int)M2; g.N = D; g.Kseg = D; g.ldc = D;
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    RC(fh_attention_bwd_launch(dt, x.at(p.qkv, (long)l * M2 * 3 * D), x.at(p.attn, (long)l * M2 * D), x.W(p.da),
+                               x.W<float>(p.lse) + (long)l * B * H * s.T2, x.W<float>(p.delta),
+                               x.at(p.dqkv, (long)l * M2 * 3 * D), len_2, B, s.T2, H, D / H, scale,
+                               x.drop(c.attention_dropout, site + 0), x.st));
+    {  // dxin = dqkv . Wqkv + ds1
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.at(p.dqkv, (long)l * M2 * 3 * D), FH_R_CONTIG, 3 * D);
+      g.Y = fh_operand(x.nat(lpo + p.pl.l_qkv_w), FH_R_STRIDED, D);
+      g.C = x.at(p.dxin, (long)(l & 1) * M2 * D);
+      g.M = (int)M2; g.N = D; g.Kseg = 3 * D; g.ldc = D;
+      g.ep.residual = x.W(p.ds1);
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    dy_next = x.at(p.dxin, (long)(l & 1) * M2 * D);
+  }
+  // ---------------- grouped weight gradients of all layers (one launch per linear)
+  {
+    const long lo = p.pl.layer0, ls = p.pl.layer_stride;
+    GemmOperand A = fh_operand(x.W(p.hbuf), FH_R_STRIDED, Fd);
+    A.gstride = M2 * Fd;
+    RC(wgrad(x, x.W(p.df2), D, A, grads + lo + p.pl.l_fc2_w, D, Fd, M2, L, M2 * D, ls));
+    RC(fh_colsum_launch(dt, x.W(p.df2), grads + lo + p.pl.l_fc2_b, (int)M2, D, D, L, M2 * D, ls, 0, 1.f, x.st));
+    A = fh_operand(x.W(p.xa), FH_R_STRIDED, D);
+    A.gstride = M2 * D;
+    RC(wgrad(x, x.W(p.dz1), Fd, A, grads + lo + p.pl.l_fc1_w, Fd, D, M2, L, M2 * Fd, ls));
+    RC(fh_colsum_launch(dt, x.W(p.dz1), grads + lo + p.pl.l_fc1_b, (int)M2, Fd, Fd, L, M2 * Fd, ls, 0, 1.f, x.st));
+    A = fh_operand(x.W(p.attn), FH_R_STRIDED, D);
+    A.gstride = M2 * D;
+    RC(wgrad(x, x.W(p.dao), D, A, grads + lo + p.pl.l_o_w, D, D, M2, L, M2 * D, ls));
+    RC(fh_colsum_launch(dt, x.W(p.dao), grads + lo + p.pl.l_o_b, (int)M2, D, D, L, M2 * D, ls, 0, 1.f, x.st));
+    A = fh_operand(x.W(p.xo), FH_R_STRIDED, D);  // layer inputs = slots 0..L-1
+    A.gstride = M2 * D;
+    RC(wgrad(x, x.W(p.dqkv), 3 * D, A, grads + lo + p.pl.l_qkv_w, 3 * D, D, M2, L, M2 * 3 * D, ls));
+    RC(fh_colsum_launch(dt, x.W(p.dqkv), grads + lo + p.pl.l_qkv_b, (int)M2, 3 * D, 3 * D, L, M2 * 3 * D, ls, 0, 1.f, x.st));
+  }
+  // ---------------- time-reduction conv backward
+  const void* d_x1;  // gradient w.r.t. the encoder LayerNorm(+dropout) output
+  if (c.tr_factor > 0) {
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(dy_next, FH_R_CONTIG, D);
+    g.Y = fh_operand(x.rel(p.wl.tr_wf), FH_R_STRIDED, (long)s.f * D);
+    g.C = x.W(p.dx1tr);
+    g.M = (int)M2; g.N = s.f * D; g.Kseg = D;
+    g.ldc = (long)s.f * D; g.c_rpb = s.T2; g.c_bstride = (long)s.Tp * D;
+    RC(fh_gemm_launch(g, dt, x.st));
+    RC(fh_zero_rows_launch(dt, x.W(p.dx1tr), B, s.Tp, D, s.f * s.T2, x.st));
+    GemmOperand A = fh_operand(x.W(p.x1), FH_R_STRIDED, (long)s.f * D);
+    A.rpb = s.T2; A.bstride = (long)s.Tp * D;
+    RC(wgrad(x, dy_next, D, A, grads + p.pl.tr_w, D, s.f * D, M2, 1, 0, 0, /*jdiv*/ D, /*sj1*/ 1, /*sj0*/ s.f, 0, 0, 0,
+             /*ldc*/ (long)D * s.f));
+    RC(fh_colsum_launch(dt, dy_next, grads + p.pl.tr_b, (int)M2, D, D, 1, 0, 0, 0, 1.f, x.st));
+    d_x1 = x.W(p.dx1tr);
+  } else {
+    d_x1 = dy_next;
+  }
+  // ---------------- encoder LayerNorm (+dropout) backward, positional conv backward
+  RC(fh_layernorm_bwd_launch(dt, d_x1, nullptr, x.W(p.psum), x.W<float>(p.ln1_mean), x.W<float>(p.ln1_rstd),
+                             x.params + p.pl.enc_ln_w, x.W(p.dpsum), nullptr, grads + p.pl.enc_ln_w, grads + p.pl.enc_ln_b,
+                             (int)s.Mp, D, x.drop(c.dropout, SITE_ENC), x.drop(0.f, 0), x.st));
+  RC(fh_posconv_bwd_data_launch(dt, x.W(p.dpsum), x.W(p.zc), x.rel(p.wl.pos_wb), x.W(p.dzc), x.W(p.dx0), B, s.Tp, D,
+                                c.conv_pos_groups, c.conv_pos, x.st));
+  RC((int)hipMemsetAsync(x.W(p.pos_dws), 0, (long)c.conv_pos_groups * c.conv_pos * 32 * 32 * 4, x.st));
+  RC(fh_posconv_bwd_weight_launch(dt, x.W(p.dzc), x.W(p.x0), x.W<float>(p.pos_dws), grads + p.pl.pos_b, B, s.Tp, D,
+                                  c.conv_pos_groups, c.conv_pos, x.st));
+  RC(fh_posconv_wn_bwd_launch(x.params + p.pl.pos_g, x.params + p.pl.pos_v, (const float*)x.rel(p.wl.pos_norm),
+                              x.W<float>(p.pos_dws), grads + p.pl.pos_g, grads + p.pl.pos_v, D, c.conv_pos_groups, c.conv_pos, x.st));
+  // ---------------- post_extract_proj backward
+  const int E = c.conv_dim[c.n_conv - 1];
+  RC(fh_mask_drop_launch(dt, x.W(p.dx0), x.W(p.dfeat), s.Mp, D, s.Tp, len_p, x.drop(c.dropout_input, SITE_INPUT), x.st));
+  {
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(x.W(p.dfeat), FH_R_CONTIG, D);
+    g.Y = fh_operand(x.nat(p.pl.post_w), FH_R_STRIDED, E);
+    g.C = x.W(p.dln0);
+    g.M = (int)s.Mp; g.N = E; g.Kseg = D; g.ldc = E;
+    RC(fh_gemm_launch(g, dt, x.st));
+    GemmOperand A = fh_operand(x.W(p.ln0), FH_R_STRIDED, E);
+    RC(wgrad(x, x.W(p.dfeat), D, A, grads + p.pl.post_w, D, E, s.Mp, 1, 0, 0));
+    RC(fh_colsum_launch(dt, x.W(p.dfeat), grads + p.pl.post_b, (int)s.Mp, D, D, 1, 0, 0, 0, 1.f, x.st));
+  }
+  if (c.feature_grad_mult <= 0.f) return 0;  // model.py:432-434: extractor under no_grad
+  const int nl = c.n_conv - 1;
+  RC(fh_layernorm_bwd_launch(dt, x.W(p.dln0), nullptr, x.W(p.y[nl]), x.W<float>(p.ln0_mean), x.W<float>(p.ln0_rstd),
+                             x.params + p.pl.ln_w, x.W(p.dylast), nullptr, grads + p.pl.ln_w, grads + p.pl.ln_b, (int)s.Mp, E,
+                             x.drop(0.f, 0), x.drop(0.f, 0), x.st));
+  // ---------------- conv frontend backward (GradMultiply: model.py:430-431 scales the gradient entering it)
+  const void* dy0 = nullptr;
+  if (nl == 0) {
+    if (c.feature_grad_mult != 1.f) return -822;
+    dy0 = x.W(p.dylast);
+  } else {
+    RC(fh_mul_gelu_grad_launch(dt, x.W(p.dylast), x.W(p.z[nl]), x.W(p.dz[nl]), s.Mp * E, c.feature_grad_mult, x.st));
+  }
+  for (int i = nl; i >= 1; --i) {
+    const int cin = c.conv_dim[i - 1], cout = c.conv_dim[i], kk = c.conv_k[i], sd = c.conv_stride[i];
+    const int Ti = s.T[i], Tin = s.T[i - 1];
+    const long Mi = (long)B * Ti;
+    // weight gradient: dW[co][ci][j] += sum_m dz[m][co] * window(m)[j*Cin + ci]
+    GemmOperand A = fh_operand(x.W(p.y[i - 1]), FH_R_STRIDED, (long)sd * cin);
+    A.rpb = Ti; A.bstride = (long)Tin * cin;
+    RC(wgrad(x, x.W(p.dz[i]), cout, A, grads + p.pl.conv_w[i], cout, kk * cin, Mi, 1, 0, 0, /*jdiv*/ cin, /*sj1*/ 1, /*sj0*/ kk,
+             0, 0, 0, /*ldc*/ (long)cin * kk));
+    // data gradient -> dz[i-1] = d(y[i-1]) * gelu'(z[i-1])   (for layer 0 the GELU' lives inside the conv0 backward)
+    unsigned char* dst = x.W<unsigned char>(i - 1 >= 1 ? p.dz[i - 1] : p.dz[0]);
+    const unsigned char* aux = i - 1 >= 1 ? x.W<unsigned char>(p.z[i - 1]) : nullptr;
+    const void* wf = x.rel(p.wl.conv_wf[i]);
+    if (kk == sd || (kk == 1 && sd == 1)) {
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
+      g.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
+      g.C = dst;
+      g.M = (int)Mi; g.N = kk * cin; g.Kseg = cout;
+      g.ldc = (long)sd * cin; g.c_rpb = Ti; g.c_bstride = (long)Tin * cin;
+      g.ep.gelu_aux = aux;
+      RC(fh_gemm_launch(g, dt, x.st));
+      RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, sd * (Ti - 1) + kk, x.st));
+    } else {  // k = 3, s = 2
+      const int n_even = (2 * Ti <= Tin - 1) ? Ti + 1 : Ti;
+      GemmParams g = fh_gemm_params();  // odd rows: dx[2u+1] = dz[u] . W_1
+      g.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
+      g.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
+      g.Y.segoff[0] = cin;
+      g.C = dst + (long)cin * p.es;
+      g.M = (int)Mi; g.N = cin; g.Kseg = cout;
+      g.ldc = 2L * cin; g.c_rpb = Ti; g.c_bstride = (long)Tin * cin;
+      g.ep.gelu_aux = aux ? aux + (long)cin * p.es : nullptr;
+      RC(fh_gemm_launch(g, dt, x.st));
+      GemmParams e = fh_gemm_params();  // even rows: dx[2u] = dz[u] . W_0 + dz[u-1] . W_2
+      e.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
+      e.X.rpb = n_even; e.X.bstride = (long)Ti * cout; e.X.nseg = 2; e.X.tshift[0] = 0; e.X.tshift[1] = -1; e.X.tvalid = Ti;
+      e.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
+      e.Y.nseg = 2; e.Y.segoff[0] = 0; e.Y.segoff[1] = 2L * cin;
+      e.C = dst;
+      e.M = B * n_even; e.N = cin; e.Kseg = cout;
+      e.ldc = 2L * cin; e.c_rpb = n_even; e.c_bstride = (long)Tin * cin;
+      e.ep.gelu_aux = aux;
+      RC(fh_gemm_launch(e, dt, x.st));
+      RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, n_even == Ti + 1 ? 2 * Ti + 1 : 2 * Ti, x.st));
+    }
+    if (i - 1 == 0) dy0 = dst;
+  }
+  RC(fh_conv0_bwd_launch(dt, wave, x.params + p.pl.conv_w[0], x.params + p.pl.gn_w, x.params + p.pl.gn_b, dy0,
+                         x.W<float>(p.c0_mean), x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch),
+                         x.W<float2>(p.c0_scratch) + (long)B * fh_conv0_nchunk(s.T[0]) * c.conv_dim[0], grads + p.pl.conv_w[0],
+                         grads + p.pl.gn_w, grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+long fh_student_param_count(const fh_student_config* c) {
+  if (!c || validate(*c)) return -1;
+  return ParamLayout(*c).total;
+}
+
+int fh_student_param_info(const fh_student_config* c, int idx, char* name, int name_cap, long* offset, int* ndim, long* dims) {
+  if (!c || validate(*c)) return -1;
+  ParamLayout pl(*c);
+  if (idx < 0 || idx >= (int)pl.list.size()) return 1;
+  const PEntry& e = pl.list[idx];
+  if (name && name_cap > 0) {
+    std::strncpy(name, e.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (offset) *offset = e.off;
+  if (ndim) *ndim = e.ndim;
+  if (dims) for (int i = 0; i < 4; ++i) dims[i] = e.dims[i];
+  return 0;
+}
+
+long fh_student_wc_bytes(const fh_student_config* c) {
+  if (!c || validate(*c)) return -1;
+  ParamLayout pl(*c);
+  return WcLayout(*c, pl).total;
+}
+
+long fh_student_ws_bytes(const fh_student_config* c, const fh_student_call* k) {
+  if (!c || !k || validate(*c)) return -1;
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  return p.ws.total;
+}
+
+int fh_student_ws_info(const fh_student_config* c, const fh_student_call* k, const char* name, long* byte_offset, int* ndim,
+                       long* dims, int* elem_bytes) {
+  if (!c || !k || validate(*c)) return -1;
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  for (auto& b : p.ws.bufs)
+    if (b.name == name) {
+      if (byte_offset) *byte_offset = b.off;
+      if (ndim) *ndim = b.ndim;
+      if (dims) for (int i = 0; i < 4; ++i) dims[i] = b.dims[i];
+      if (elem_bytes) *elem_bytes = b.esize;
+      return 0;
+    }
+  return 1;
+}
+
+int fh_student_frames(const fh_student_config* c, int S, int* T_conv, int* T_enc) {
+  if (!c || validate(*c)) return -1;
+  Shapes s;
+  int rc = make_shapes(*c, 1, S, s);
+  if (rc) return rc;
+  if (T_conv) *T_conv = s.Tp;
+  if (T_enc) *T_enc = s.T2;
+  return 0;
+}
+
+int fh_student_prepare(const fh_student_config* c, const float* params, void* wc, fh_stream_t stream) {
+  if (!c) return -1;
+  RC(validate(*c));
+  fh_student_call k;
+  k.B = 1; k.S = 400000; k.training = 0; k.heads_on = 1; k.seed = 0;
+  Plan p(*c, k);
+  return prepare(p, params, (unsigned char*)wc, (hipStream_t)stream);
+}
+
+int fh_student_forward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
+                       const float* wave, const int* lens, fh_stream_t stream) {
+  if (!c || !k) return -1;
+  RC(validate(*c));
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
+  return forward(x, wave, lens);
+}
+
+int fh_student_backward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
+                        float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden,
+                        fh_stream_t stream) {
+  if (!c || !k) return -1;
+  RC(validate(*c));
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
+  return backward(x, grads, wave, lens, d_pred, d_hidden);
+}
+
+}  // extern "C"

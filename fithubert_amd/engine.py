@@ -1,0 +1,243 @@
+"""Host-side handle of the native student engine (fithubert_amd/csrc/engine.hip).
+
+Owns nothing numeric: torch is used for device memory and streams only.  Every arithmetic step of
+the student runs in libfithubert_hip.so; if the library or a GPU is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .config import CustomStudentModelConfig, conv_out_length
+
+from ._lib import FH_MAX_CONV, StudentCallC, StudentConfigC
+
+_I, _L = C.c_int, C.c_long
+
+DTYPES = {"float32": L.DT_F32, "fp32": L.DT_F32, "f32": L.DT_F32, "bfloat16": L.DT_BF16, "bf16": L.DT_BF16}
+
+
+def unsupported(cfg: CustomStudentModelConfig) -> Optional[str]:
+    """Why this configuration is outside the native hot path (SURVEY 8a scope), or None."""
+    if cfg.n_mels > 0:
+        return "mel-spectrogram frontend (n_mels > 0) is out of scope (no shipped config uses it)"
+    if cfg.layer_type != "transformer":
+        return "conformer layers are out of scope (no shipped config uses them)"
+    if cfg.extractor_mode != "default":
+        return "extractor_mode='layer_norm' is not built for the student (teacher-only)"
+    if cfg.conv_bias:
+        return "conv_bias=True is not built for the student"
+    if cfg.layer_norm_first:
+        return "layer_norm_first=True (pre-LN) is not built for the student"
+    if cfg.activation_fn != "gelu":
+        return "only activation_fn='gelu' is built"
+    if cfg.pos_conv_depth != 1:
+        return "pos_conv_depth > 1 is not built"
+    if cfg.encoder_layerdrop > 0:
+        return "encoder_layerdrop > 0 is not built"
+    if cfg.required_seq_len_multiple != 1 or cfg.crop_seq_to_multiple != 1:
+        return "required_seq_len_multiple / crop_seq_to_multiple must be 1 (as in the shipped configs)"
+    if cfg.enable_tr_layer and (cfg.tr_layer_type != "conv1d" or cfg.tr_layer_index != 0 or cfg.tr_reduce_factor != 2):
+        return "time reduction is built for tr_layer_type='conv1d', tr_layer_index=0, tr_reduce_factor=2 (fithubert.yaml)"
+    if not cfg.layerwise_proj:
+        return "DistilHuBERT-style SplitLinear heads (layerwise_proj=False, ex.yaml) are the next scope row, not built yet"
+    if cfg.pred_head_final_dim == cfg.encoder_embed_dim:
+        return "pred_head_final_dim == encoder_embed_dim (no lin_proj) is not built"
+    if cfg._cnn_weight > 0:
+        return "cnn_proj_head / cnn_loss_weight > 0 is not built yet"
+    return None
+
+
+def make_config_c(cfg: CustomStudentModelConfig, dtype: str) -> StudentConfigC:
+    why = unsupported(cfg)
+    if why:
+        raise NotImplementedError("fithubert_amd: " + why)
+    c = StudentConfigC()
+    c.dtype = DTYPES[dtype]
+    layers = cfg.conv_layers()
+    if len(layers) > FH_MAX_CONV:
+        raise NotImplementedError("too many conv layers")
+    c.n_conv = len(layers)
+    for i, (d, k, s) in enumerate(layers):
+        c.conv_dim[i], c.conv_k[i], c.conv_stride[i] = d, k, s
+    c.embed_dim = cfg.encoder_embed_dim
+    c.ffn_dim = cfg.encoder_ffn_embed_dim
+    c.heads = cfg.encoder_attention_heads
+    c.layers = cfg.encoder_layers
+    c.conv_pos = cfg.conv_pos
+    c.conv_pos_groups = cfg.conv_pos_groups
+    c.tr_factor = cfg.tr_reduce_factor if cfg.enable_tr_layer else 0
+    c.pred_dim = cfg.pred_head_final_dim
+    c.dropout = cfg.dropout
+    c.attention_dropout = cfg.attention_dropout
+    c.activation_dropout = cfg.activation_dropout
+    c.dropout_input = cfg.dropout_input
+    c.feature_grad_mult = cfg.feature_grad_mult
+    return c
+
+
+def param_table(cfg: CustomStudentModelConfig, dtype: str = "bf16") -> Tuple[List[Tuple[str, int, Tuple[int, ...]]], int]:
+    """[(state-dict name, flat offset, shape)], total floats -- straight from the native layout (host only, no GPU)."""
+    lib = L.lib()
+    c = make_config_c(cfg, dtype)
+    total = lib.fh_student_param_count(C.byref(c))
+    if total <= 0:
+        raise RuntimeError(f"fh_student_param_count failed ({total})")
+    out = []
+    name = C.create_string_buffer(256)
+    off, nd = _L(), _I()
+    dims = (_L * 4)()
+    i = 0
+    while lib.fh_student_param_info(C.byref(c), i, name, 256, C.byref(off), C.byref(nd), dims) == 0:
+        out.append((name.value.decode(), off.value, tuple(dims[j] for j in range(nd.value))))
+        i += 1
+    return out, total
+
+
+class Workspace:
+    """One forward's activation arena + typed views into it."""
+
+    def __init__(self, eng: "StudentEngine", call: StudentCallC, buf: torch.Tensor):
+        self.eng, self.call, self.buf = eng, call, buf
+
+    def view(self, name: str) -> torch.Tensor:
+        lib = L.lib()
+        off, nd, eb = _L(), _I(), _I()
+        dims = (_L * 4)()
+        rc = lib.fh_student_ws_info(C.byref(self.eng.c), C.byref(self.call), name.encode(), C.byref(off), C.byref(nd), dims, C.byref(eb))
+        if rc != 0:
+            raise KeyError(name)
+        shape = tuple(dims[j] for j in range(nd.value))
+        n = 1
+        for s in shape:
+            n *= s
+        dt = torch.float32 if eb.value == 4 else torch.bfloat16
+        if eb.value == 4 and self.eng.c.dtype == L.DT_F32:
+            dt = torch.float32
+        raw = self.buf[off.value: off.value + n * eb.value]
+        return raw.view(dt).view(shape)
+
+
+class StudentEngine:
+    """Flat fp32 parameters (+ gradients) and the native forward / backward over them."""
+
+    def __init__(self, cfg: CustomStudentModelConfig, dtype: str = "bf16", device: str = "cuda"):
+        self.cfg = cfg
+        self.dtype_name = dtype
+        self.c = make_config_c(cfg, dtype)
+        self.table, self.n_params = param_table(cfg, dtype)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("fithubert_amd runs on an AMD GPU only (no CPU path); got device=%s" % device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("fithubert_amd: no GPU visible (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = L.lib()
+        self.params = torch.zeros(self.n_params, device=self.device, dtype=torch.float32)
+        self.grads = torch.zeros_like(self.params)
+        self.wc = torch.empty(self.lib.fh_student_wc_bytes(C.byref(self.c)), device=self.device, dtype=torch.uint8)
+        self.elem = torch.float32 if self.c.dtype == L.DT_F32 else torch.bfloat16
+        self._prepared_version = -1
+        self.version = 0
+        self.layers = cfg.conv_layers()
+
+    # ------------------------------------------------------------------ parameters
+    def param_views(self, flat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        flat = self.params if flat is None else flat
+        out = {}
+        for name, off, shape in self.table:
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = flat[off: off + n].view(shape)
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        views = self.param_views()
+        missing = [k for k in views if k not in sd]
+        unexpected = [k for k in sd if k not in views]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        with torch.no_grad():
+            for k, v in views.items():
+                if k in sd:
+                    if tuple(sd[k].shape) != tuple(v.shape):
+                        raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(v.shape)}")
+                    v.copy_(sd[k].to(device=self.device, dtype=torch.float32))
+        self.version += 1
+
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def prepare(self, force: bool = False) -> None:
+        """fp32 master weights -> compute-dtype / kernel-layout copies (after every parameter update)."""
+        if force or self._prepared_version != self.version:
+            L.check(self.lib.fh_student_prepare(C.byref(self.c), self.params.data_ptr(), self.wc.data_ptr(), self.stream()), "fh_student_prepare")
+            self._prepared_version = self.version
+
+    # ------------------------------------------------------------------ shapes
+    def frames(self, S: int) -> Tuple[int, int]:
+        a, b = _I(), _I()
+        L.check(self.lib.fh_student_frames(C.byref(self.c), S, C.byref(a), C.byref(b)), "fh_student_frames")
+        return a.value, b.value
+
+    def frame_lengths(self, sample_lengths) -> Tuple[List[int], List[int]]:
+        """valid frames after the frontend (model.py:376-391) and after time reduction (module.py:324-328)."""
+        tp = [conv_out_length(int(n), self.layers) for n in sample_lengths]
+        f = self.c.tr_factor if self.c.tr_factor > 0 else 1
+        return tp, [t // f for t in tp]
+
+    # ------------------------------------------------------------------ compute
+    def forward(self, wave: torch.Tensor, sample_lengths=None, training: bool = False, heads_on: bool = True,
+                seed: int = 0) -> Workspace:
+        assert wave.is_cuda and wave.dtype == torch.float32 and wave.dim() == 2 and wave.is_contiguous()
+        B, S = wave.shape
+        call = StudentCallC(B, S, int(training), int(heads_on), seed & 0xFFFFFFFF)
+        nbytes = self.lib.fh_student_ws_bytes(C.byref(self.c), C.byref(call))
+        if nbytes <= 0:
+            raise RuntimeError(f"fh_student_ws_bytes failed ({nbytes}) for B={B}, S={S}")
+        buf = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+        ws = Workspace(self, call, buf)
+        ws.lens = None
+        if sample_lengths is not None:
+            tp, t2 = self.frame_lengths(sample_lengths)
+            ws.lens = torch.tensor([tp, t2], dtype=torch.int32).to(self.device, non_blocking=True)
+        ws.wave = wave
+        self.prepare()
+        L.check(self.lib.fh_student_forward(C.byref(self.c), C.byref(call), self.params.data_ptr(), self.wc.data_ptr(),
+                                            buf.data_ptr(), wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None,
+                                            self.stream()), "fh_student_forward")
+        return ws
+
+    def backward(self, ws: Workspace, d_pred: Optional[torch.Tensor] = None, d_hidden: Optional[torch.Tensor] = None,
+                 grads: Optional[torch.Tensor] = None) -> None:
+        grads = self.grads if grads is None else grads
+        for t in (d_pred, d_hidden):
+            if t is not None:
+                assert t.is_cuda and t.is_contiguous() and t.dtype == self.elem
+        L.check(self.lib.fh_student_backward(
+            C.byref(self.c), C.byref(ws.call), self.params.data_ptr(), self.wc.data_ptr(), ws.buf.data_ptr(), grads.data_ptr(),
+            ws.wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None,
+            d_pred.data_ptr() if d_pred is not None else None, d_hidden.data_ptr() if d_hidden is not None else None,
+            self.stream()), "fh_student_backward")
+
+    def kd_loss(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
+                loss_type: int = 0, grad_scale: float = 1.0, want_grad: bool = True):
+        """Fused layer-wise KD loss (train.py:250-293).  teacher: [Lt][B][Tt][P] fp32 or bf16, contiguous.
+        Returns (out_losses fp64 [L+1] on device, d_pred or None)."""
+        pred = ws.view("pred")
+        Lh, B, Tp, P = pred.shape
+        assert teacher.is_cuda and teacher.is_contiguous() and teacher.dim() == 4 and teacher.shape[1] == B and teacher.shape[3] == P
+        tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16
+        Tt = teacher.shape[2]
+        nblk = self.lib.fh_kd_loss_nblk(self.c.dtype, B, Tp, P)
+        partials = torch.empty(Lh * nblk, device=self.device, dtype=torch.float32)
+        out = torch.empty(Lh + 1, device=self.device, dtype=torch.float64)
+        d_pred = torch.empty_like(pred) if want_grad else None
+        L.check(self.lib.fh_kd_loss(self.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(),
+                                    d_pred.data_ptr() if want_grad else None, layer_w.data_ptr(), teacher_layer.data_ptr(),
+                                    partials.data_ptr(), out.data_ptr(), Lh, B, Tp, Tt, P, B * Tt * P, loss_type, grad_scale,
+                                    self.stream()), "fh_kd_loss")
+        return out, d_pred

@@ -160,6 +160,56 @@ int fh_permute3_cast(int dtype, const float* src, void* dst, int d0, int d1, int
 int fh_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
              float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, fh_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Student engine: the whole CustomStudentModel forward (modules/model.py:420-552) and its backward as ONE
+ * native plan over a flat fp32 parameter buffer and a caller-provided activation workspace.
+ * Parameter names reported by fh_student_param_info are the reference's state-dict keys,
+ * so checkpoints are interchangeable.  Stateless: every call recomputes the (cheap) layout.
+ * ------------------------------------------------------------------------------------------ */
+#define FH_MAX_CONV 12
+typedef struct {
+  int dtype;                       /* 0 = float, 1 = bf16 activations / MFMA */
+  int n_conv;                      /* conv_feature_layers (modules/model.py:267) */
+  int conv_dim[FH_MAX_CONV], conv_k[FH_MAX_CONV], conv_stride[FH_MAX_CONV];
+  int embed_dim, ffn_dim, heads, layers;  /* encoder_embed_dim, encoder_ffn_embed_dim, encoder_attention_heads, encoder_layers */
+  int conv_pos, conv_pos_groups;
+  int tr_factor;                   /* time-reduction conv1d at layer index 0 (0 = no TR layer) */
+  int pred_dim;                    /* pred_head_final_dim */
+  float dropout, attention_dropout, activation_dropout, dropout_input;
+  float feature_grad_mult;
+} fh_student_config;
+
+/* per-call shape info */
+typedef struct {
+  int B, S;        /* batch, samples */
+  int training;    /* dropout on, save activations for backward */
+  int heads_on;    /* 1: all layer-wise projection heads (distillation); 0: final_proj only (deployment) */
+  uint32_t seed;   /* dropout seed of this step */
+} fh_student_call;
+
+long fh_student_param_count(const fh_student_config* c);
+/* enumerate parameters: returns 0 and fills the outputs while idx is valid, 1 past the end */
+int fh_student_param_info(const fh_student_config* c, int idx, char* name, int name_cap, long* offset, int* ndim,
+                          long* dims /*[4]*/);
+long fh_student_wc_bytes(const fh_student_config* c);
+long fh_student_ws_bytes(const fh_student_config* c, const fh_student_call* k);
+/* locate a named activation in the workspace; returns 0 on success */
+int fh_student_ws_info(const fh_student_config* c, const fh_student_call* k, const char* name, long* byte_offset,
+                       int* ndim, long* dims /*[4]*/, int* elem_bytes);
+/* frames after the conv frontend / after time reduction for S samples */
+int fh_student_frames(const fh_student_config* c, int S, int* T_conv, int* T_enc);
+
+/* fp32 master params -> compute-dtype / kernel-layout weights (once per optimizer step) */
+int fh_student_prepare(const fh_student_config* c, const float* params, void* wc, fh_stream_t stream);
+/* lens: device int [2][B] = valid frames after the frontend, valid frames after time reduction; NULL = no padding */
+int fh_student_forward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
+                       void* ws, const float* wave, const int* lens, fh_stream_t stream);
+/* grads += d loss / d params.  d_pred: gradient w.r.t. the workspace tensor "pred" (same shape/dtype) or NULL;
+ * d_hidden: gradient w.r.t. "xo" slots 1..L (layer outputs, [L][B*T_enc][D], dtype) or NULL. */
+int fh_student_backward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
+                        void* ws, float* grads, const float* wave, const int* lens, const void* d_pred,
+                        const void* d_hidden, fh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,196 @@
+"""GPU: the native student engine (forward, fused KD loss, backward) against the CPU oracle and the golden vectors
+captured from the reference.
+
+Tolerances: dtype float (exact-fp32 MFMA): hidden states <= 2e-4 of the tensor scale, KD loss <= 1e-4 absolute
+(the north star's parity figure), gradients <= 2e-3 relative.  dtype bf16: hidden states rel-L2 <= 2e-2, KD loss
+<= 2e-2 relative, gradient norms <= 5e-2 relative (bf16 keeps 8 significant bits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+from fithubert_amd.config import CustomStudentModelConfig  # noqa: E402
+from fithubert_amd.engine import StudentEngine  # noqa: E402
+from oracle import loss_ref as LR  # noqa: E402
+from oracle import student_ref as S  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel_max(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def _rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def _engine(cfg_dict, seed, dtype):
+    cfg = CustomStudentModelConfig(**cfg_dict)
+    eng = StudentEngine(cfg, dtype=dtype, device=DEV)
+    sd = S.random_state_dict(cfg_dict, seed=seed)
+    eng.load_state_dict(sd)
+    return eng, sd
+
+
+def _check_forward(eng, ws, ref, L, tol_max, tol_l2, padded_check=None):
+    f = eng.c.tr_factor or 1
+    xo = ws.view("xo")  # [L+1][B][T2][D]
+    f2 = ws.view("f2")
+    pred = ws.view("pred")
+    worst = 0.0
+    for i in range(L):
+        got = xo[i + 1].transpose(0, 1).float()
+        e1, e2 = _rel_max(got, ref["layer_results"][i][0]), _rel_l2(got, ref["layer_results"][i][0])
+        assert e1 < tol_max and e2 < tol_l2, ("layer", i, e1, e2)
+        e = _rel_l2(f2[i].transpose(0, 1).float(), ref["layer_results"][i][2])
+        assert e < tol_l2 * 2, ("fc2", i, e)
+        e1 = _rel_l2(pred[i].float(), ref["projections"][i])
+        assert e1 < tol_l2, ("proj", i, e1)
+        worst = max(worst, e2)
+    e = _rel_l2(ws.view("features").float(), ref["features"])
+    assert e < tol_l2, ("features", e)
+    e = _rel_l2(xo[0].transpose(0, 1).float(), ref["tr_layer_results"][0])
+    assert e < tol_l2, ("tr", e)
+    return worst
+
+
+@pytest.mark.parametrize("dtype,tol_max,tol_l2", [("float32", 3e-4, 1e-4), ("bf16", 8e-2, 2e-2)])
+def test_small_config_forward_matches_golden_and_oracle(dtype, tol_max, tol_l2, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "student_small.npz"))
+    cfg = yaml.safe_load(str(fx["cfg_yaml"]))
+    eng, sd = _engine(cfg, int(fx["weight_seed"]), dtype)
+    wav = torch.from_numpy(fx["wav"])
+    L = cfg["encoder_layers"]
+    ws = eng.forward(wav.to(DEV), None, training=False)
+    torch.cuda.synchronize()
+    # against the vectors captured from the reference itself
+    xo = ws.view("xo")
+    for i in range(L):
+        assert _rel_l2(xo[i + 1].transpose(0, 1).float(), torch.from_numpy(fx[f"layer{i}"])) < tol_l2, i
+        assert _rel_l2(ws.view("pred")[i].float(), torch.from_numpy(fx[f"proj{i}"])) < tol_l2, i
+    assert _rel_l2(ws.view("features").float(), torch.from_numpy(fx["features"])) < tol_l2
+    # against the oracle (every tensor)
+    with torch.no_grad():
+        ref = S.student_forward(sd, cfg, wav, None)
+    _check_forward(eng, ws, ref, L, tol_max, tol_l2)
+    # padded pair
+    pm = torch.zeros(wav.shape, dtype=torch.bool)
+    wav_p = wav.clone()
+    lens = [int(n) for n in fx["pad_from"]]
+    for b, n in enumerate(lens):
+        pm[b, n:] = True
+        wav_p[b, n:] = 0
+    ws = eng.forward(wav_p.to(DEV), lens, training=False)
+    torch.cuda.synchronize()
+    xo = ws.view("xo")
+    for i in range(L):
+        assert _rel_l2(xo[i + 1].transpose(0, 1).float(), torch.from_numpy(fx[f"layer{i}_padded"])) < tol_l2, i
+        assert _rel_l2(ws.view("pred")[i].float(), torch.from_numpy(fx[f"proj{i}_padded"])) < tol_l2, i
+    assert _rel_l2(ws.view("features").float(), torch.from_numpy(fx["features_padded"])) < tol_l2
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bf16"])
+def test_small_config_loss_and_gradients(dtype, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "student_small.npz"))
+    cfg = yaml.safe_load(str(fx["cfg_yaml"]))
+    cfg = dict(cfg, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)  # training path, dropout off
+    eng, sd = _engine(cfg, int(fx["weight_seed"]), dtype)
+    L = cfg["encoder_layers"]
+    wav = torch.from_numpy(fx["wav"])
+    g = torch.Generator().manual_seed(int(fx["teacher_seed"]))
+    Tt = int(fx["teacher_T"])
+    t_layers = [torch.randn(Tt, 2, 768, generator=g) for _ in range(L)]
+    teacher = torch.stack([t.transpose(0, 1) for t in t_layers]).contiguous()  # [L][B][Tt][P]
+    rand_l = [int(v) for v in fx["rand_l"]]
+    w = torch.zeros(L)
+    w[rand_l] = 0.1
+    w[L - 1] = 1.0
+    ws = eng.forward(wav.to(DEV), None, training=True, seed=1)
+    out, d_pred = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(L, dtype=torch.int32, device=DEV))
+    eng.grads.zero_()
+    eng.backward(ws, d_pred=d_pred)
+    torch.cuda.synchronize()
+    loss = out[L].item()
+    ref_loss = float(fx["loss"])
+    if dtype == "float32":
+        assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)  # KD-loss parity target of the north star
+        per_layer = out[:L].cpu().numpy()  # unweighted means, indexed by student layer
+        want = np.zeros(L)
+        for j, l in enumerate(rand_l):  # the fixture stores the weighted terms in rand_l order, then the last layer
+            want[l] = fx["layer_losses"][j] / 0.1
+        want[L - 1] = fx["layer_losses"][-1]
+        np.testing.assert_allclose(per_layer, want, rtol=2e-4)
+    else:
+        assert abs(loss - ref_loss) < 2e-2 * ref_loss, (loss, ref_loss)
+    grads = eng.param_views(eng.grads)
+    tol = 3e-3 if dtype == "float32" else 6e-2
+    no_grad = set(str(s) for s in fx["no_grad_params"])
+    bad = []
+    for k, gv in grads.items():
+        if k in no_grad:
+            assert gv.abs().max().item() == 0, k
+            continue
+        ref_norm = float(fx["gradnorm/" + k])
+        got = gv.double().norm().item()
+        if abs(got - ref_norm) > tol * max(ref_norm, 1e-3):
+            bad.append((k, got, ref_norm))
+        if "grad/" + k in fx.files and ref_norm > 1e-3:
+            e = _rel_l2(gv.float(), torch.from_numpy(fx["grad/" + k]))
+            if e > tol * 3:
+                bad.append((k + " (full)", e, 0))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,tol_l2", [("float32", 1e-4), ("bf16", 2.5e-2)])
+def test_full_fithubert_config_2s(dtype, tol_l2, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "student_full_2s.npz"))
+    cfg = yaml.safe_load(str(fx["cfg_yaml"]))
+    eng, sd = _engine(cfg, int(fx["weight_seed"]), dtype)
+    g = torch.Generator().manual_seed(int(fx["wav_seed"]))
+    wav = 0.5 * torch.randn(2, 32000, generator=g)
+    ws = eng.forward(wav.to(DEV), None, training=False)
+    torch.cuda.synchronize()
+    xo, pred = ws.view("xo"), ws.view("pred")
+    for i in range(12):
+        assert _rel_l2(xo[i + 1].transpose(0, 1).float()[::3, :, ::8], torch.from_numpy(fx[f"layer{i}_sub"])) < tol_l2, i
+        assert _rel_l2(pred[i].float()[:, ::5, ::16], torch.from_numpy(fx[f"proj{i}_sub"])) < tol_l2, i
+        assert abs(pred[i].double().norm().item() - float(fx[f"proj{i}_l2"])) < tol_l2 * float(fx[f"proj{i}_l2"]), i
+    # the reference's loss on the seeded stand-in teacher
+    tg = torch.Generator().manual_seed(int(fx["teacher_seed"]))
+    teacher = torch.stack([torch.randn(99, 2, 768, generator=tg).transpose(0, 1) for _ in range(12)]).contiguous()
+    w = torch.full((12,), 0.1)
+    w[11] = 1.0
+    out, _ = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(12, dtype=torch.int32, device=DEV), want_grad=False)
+    loss = out[12].item()
+    ref = float(fx["loss"])
+    assert abs(loss - ref) < (1e-4 if dtype == "float32" else 2e-2 * ref), (loss, ref)
+    # padded pair
+    lens = [int(n) for n in fx["pad_from"]]
+    wav_p = wav.clone()
+    wav_p[1, lens[1]:] = 0
+    ws = eng.forward(wav_p.to(DEV), lens, training=False)
+    pred = ws.view("pred")
+    for i in range(12):
+        assert abs(pred[i].double().norm().item() - float(fx[f"proj{i}_padded_l2"])) < 2 * tol_l2 * float(fx[f"proj{i}_padded_l2"]), i
+    assert _rel_l2(pred[11].float()[:, ::3, ::8], torch.from_numpy(fx["x_padded_sub"])) < tol_l2
+
+
+def test_training_mode_dropout_is_reproducible_and_unbiased():
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=2)
+    eng, sd = _engine(cfg, 3, "bf16")
+    wav = 0.5 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(0)).to(DEV)
+    a = eng.forward(wav, None, training=True, seed=5).view("pred").clone()
+    b = eng.forward(wav, None, training=True, seed=5).view("pred").clone()
+    c = eng.forward(wav, None, training=True, seed=6).view("pred").clone()
+    e = eng.forward(wav, None, training=False).view("pred").clone()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c)
+    assert _rel_l2(a.float(), e.float()) < 1.0  # same signal, perturbed

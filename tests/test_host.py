@@ -1,0 +1,81 @@
+"""CPU: host-side logic of the boundary -- config surface, yaml, parameter table vs the reference's state-dict keys."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from fithubert_amd.config import CustomStudentModelConfig, _eval_layer_spec, conv_out_length
+from fithubert_amd.engine import param_table, unsupported
+from oracle import student_ref as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONF = os.path.join(ROOT, "conf")
+
+
+def _fit():
+    with open(os.path.join(CONF, "fithubert.yaml")) as f:
+        return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def test_yaml_surface_parses_unchanged():
+    y = _fit()
+    assert set(y) == {"teacher", "train", "distiller", "optimizer", "data", "specaug"}
+    cfg = CustomStudentModelConfig(**y["distiller"])
+    assert cfg.encoder_layers == 12 and cfg.encoder_embed_dim == 480 and cfg.tr_layer_index == 0
+    assert y["optimizer"]["lr"] == 5e-4
+    # the reference yaml writes floats as '5.e-4'; FullLoader (train.py:462) parses that form as a float
+    assert yaml.load("lr: 5.e-4", Loader=yaml.FullLoader)["lr"] == 5e-4
+    with pytest.raises(TypeError):
+        CustomStudentModelConfig(not_a_field=1)
+
+
+def test_config_field_names_and_defaults_match_reference_dataclass():
+    # the 44 fields of modules/model.py:24-251
+    names = [f for f in CustomStudentModelConfig.__dataclass_fields__]
+    assert len(names) == 44
+    ref_defaults = S.DEFAULTS
+    c = CustomStudentModelConfig()
+    for k, v in ref_defaults.items():
+        assert getattr(c, k) == v, k
+
+
+def test_layer_spec_evaluator_matches_python_eval():
+    for spec in ["[(128, 10, 5)] + [(256, 1, 1)] + [(256, 3, 2)] * 4 + [(512, 1, 1)] + [(512, 2, 2)] * 2",
+                 "[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 2"]:
+        assert _eval_layer_spec(spec) == [tuple(t) for t in eval(spec)]
+    with pytest.raises(Exception):
+        _eval_layer_spec("__import__('os').system('true')")
+
+
+def test_frame_formula():
+    layers = CustomStudentModelConfig(**_fit()["distiller"]).conv_layers()
+    assert conv_out_length(160000, layers) == 499
+    assert conv_out_length(32000, layers) == 99
+    assert conv_out_length(25000, layers) == 77  # golden: valid frames of the padded pair
+
+
+def test_native_param_table_equals_reference_state_dict():
+    y = _fit()
+    cfg = CustomStudentModelConfig(**y["distiller"])
+    table, total = param_table(cfg, "bf16")
+    ours = {n: s for n, _, s in table}
+    ref = S.param_shapes(y["distiller"])
+    assert set(ours) == set(ref)
+    for k in ref:
+        assert tuple(ours[k]) == tuple(ref[k]), k
+    assert sum(int(np.prod(s)) for s in ours.values()) == 31629632
+    # offsets are 8-float aligned and non-overlapping
+    spans = sorted((o, o + int(np.prod(s))) for _, o, s in table)
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0 and b0 % 8 == 0
+    assert spans[-1][1] <= total
+
+
+def test_unsupported_configs_fail_loudly():
+    y = _fit()
+    d = dict(y["distiller"])
+    d["layer_type"] = "conformer"
+    assert unsupported(CustomStudentModelConfig(**d))
+    with pytest.raises(NotImplementedError):
+        param_table(CustomStudentModelConfig(**d))
