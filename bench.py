@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Distillation throughput benchmark (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full distillation training step on one per-GPU batch of synthetic 10 s / 16 kHz utterances that is
+already resident in HBM: frozen HuBERT-Base-shaped teacher forward (PyTorch-ROCm, bf16) + FitHuBERT student forward
+(train mode, dropout on) + fused layer-wise KD loss + student backward + gradient all-reduce + AdamW.
+Workload = BASELINE.json configs[1] (fithubert.yaml student, HuBERT-Base teacher, bf16, batch of 10 s clips);
+weak scaling: the per-GPU batch is fixed as N grows.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import yaml  # noqa: E402
+
+SAMPLES_10S = 160000
+# algorithmic matrix FLOPs per 10 s utterance (SURVEY.md section 8d / BASELINE.md section 2)
+GF_STUDENT_FWD, GF_TEACHER_BASE = 35.23, 148.1
+GF_STEP = 3 * GF_STUDENT_FWD + GF_TEACHER_BASE  # 253.8
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+VARIANTS = {0: "f32,R_CONTIG,R_CONTIG", 1: "f32,R_CONTIG,R_STRIDED", 2: "f32,R_STRIDED,R_CONTIG", 3: "f32,R_STRIDED,R_STRIDED",
+            4: "bf16,R_CONTIG,R_CONTIG", 5: "bf16,R_CONTIG,R_STRIDED", 6: "bf16,R_STRIDED,R_CONTIG", 7: "bf16,R_STRIDED,R_STRIDED"}
+
+
+def cpu_baseline(cfg, seconds_budget: float = 25.0):
+    """The oracle's full CPU training step (fp32 eager torch) on the host cores, bounded sample."""
+    from oracle.train_step_ref import CpuDistilStep
+
+    threads = torch.get_num_threads()
+    step = CpuDistilStep(cfg, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = 0.1 * torch.randn(1, SAMPLES_10S, generator=g)
+    pm = torch.zeros(1, SAMPLES_10S, dtype=torch.bool)
+    step.step(x, pm)  # warm-up (allocator, thread pool)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < seconds_budget:
+        times.append(step.step(x, pm)["total"])
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "utt/s", "cores": threads, "kind": "port",
+            "sample": f"median of {len(times)} fp32 eager CPU training steps, batch 1 x 10 s (teacher fwd + student fwd train-mode + "
+                      f"KD loss + bwd + AdamW), after 1 warm-up; oracle/train_step_ref.py"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FH_BENCH_BATCH", "16")), help="utterances per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "float32"])
+    ap.add_argument("--config", default=os.path.join(ROOT, "conf", "fithubert.yaml"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=3, help="timed steps (the last ones) with per-launch HIP-event GEMM timing")
+    args = ap.parse_args()
+
+    from fithubert_amd import _lib as L
+    from fithubert_amd.dataset import fixed_length_batch
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.dp import init_distributed
+
+    rank, world, local = init_distributed()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the distillation path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    with open(args.config) as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    cfg["train"]["accumulate_grad_batches"] = 1  # one optimizer step (and one all-reduce) per timed step
+    task = W2V2Distil(cfg, dtype=args.dtype, device=dev, seed=0)
+    total_steps = args.steps + args.warmup
+    task.configure_optimizers(num_training_steps=max(total_steps, 100))
+
+    B = args.batch
+    pool = []
+    for i in range(4):
+        b = fixed_length_batch(B, SAMPLES_10S, seed=1000 * rank + i, device=dev)
+        b["_any_pad"] = False
+        pool.append(b)
+
+    def run_step(i):
+        return task.training_step(pool[i % 4], batch_idx=i, next_batch=pool[(i + 1) % 4])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for i in range(args.warmup):
+        out = run_step(i)
+    barrier()
+    lib = L.lib()
+    prof_from = args.steps - min(args.prof_steps, args.steps)
+    t0 = time.perf_counter()
+    for j in range(args.steps):
+        if j == prof_from and args.prof_steps > 0:
+            lib.fh_prof_enable(1)
+        out = run_step(args.warmup + j)
+    lib.fh_prof_enable(0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss = float(out[-1].item())
+
+    # ---- roofline of the dominant kernel: the MFMA GEMM, per-launch HIP events on its own stream
+    ms = (C.c_double * 8)()
+    fl = (C.c_double * 8)()
+    ln = (C.c_long * 8)()
+    lib.fh_prof_collect(ms, fl, ln)
+    roof = None
+    tot_ms = sum(ms)
+    if tot_ms > 0:
+        v = max(range(8), key=lambda i: ms[i])
+        ach = fl[v] / (ms[v] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+                "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
+                "kernel": f"gemm_kernel<{VARIANTS[v]}>", "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
+                "avg_gflop_per_launch": round(fl[v] / ln[v] / 1e9, 3),
+                "all_gemm": {"achieved": round(sum(fl) / (tot_ms * 1e-3) / 1e12, 2), "launches": int(sum(ln)),
+                             "ms_per_step": round(tot_ms / max(1, min(args.prof_steps, args.steps)), 3)},
+                "note": "HIP events around every GEMM launch during the last %d timed steps" % min(args.prof_steps, args.steps)}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        res = {
+            "metric": "distillation utterances/sec (10 s@16 kHz)",
+            "value": round(value, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "fithubert.yaml student (480-dim, 12 layers) + HuBERT-Base-shaped teacher (random init), "
+                                   "full distillation step on fixed 10 s clips (BASELINE.json configs[1])",
+                       "global_batch": world * B, "per_gpu_batch": B, "seq_len": SAMPLES_10S, "parallelism": f"dp{world}",
+                       "teacher": "PyTorch-ROCm bf16", "optimizer": "fused AdamW every step"},
+            "step_tflops": round(value * GF_STEP / 1e3, 1),
+            "step_frac_of_mfma_peak": round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
+            "final_loss": loss,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,9 @@ def lib() -> C.CDLL:
             raise HipLibraryMissing(
                 f"{LIB_PATH} not found: build it with `python -m fithubert_amd.build` "
                 "(fithubert_amd has no CPU / eager fallback)")
+        # torch owns device memory and streams: its HIP runtime (torch/lib/libamdhip64.so, same SONAME as ROCm's)
+        # must be the one this library binds to, so torch is imported before the dlopen.
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib
@@ -102,6 +105,8 @@ _ENGINE_SIGS = {
 # name -> (restype, argtypes) ; mirrors include/fithubert_hip.h one to one
 SIGNATURES = {
     "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
+    "fh_prof_enable": (_I, [_I]),
+    "fh_prof_collect": (_I, [_P, _P, _P]),
     "fh_conv0_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
     "fh_conv0_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fh_conv0_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

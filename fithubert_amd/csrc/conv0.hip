@@ -195,8 +195,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
   float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [256]
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int nt = stage_wave(a, b, chunk, sw);
+  const int b = blockIdx.y;
   const int cpb = min(a.C0, 256), nlan = 256 / cpb;
   const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
   for (int cbase = 0; cbase < a.C0; cbase += cpb) {
@@ -210,19 +209,25 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
     const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
     const float ga = a.gamma[c], be = a.beta[c];
     const float2 abv = ab[b * a.C0 + c];
-    const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
-    for (int t = tl; t < nt; t += nlan) {
-      const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
-      const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
-      const float dv = rs * (g * ga - abv.x - xh * abv.y);
-      const float* x = sw + t * a.stride;
+    // the block walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... keeping its dW partial in registers
+    for (int chunk = blockIdx.x; chunk < a.nchunk; chunk += gridDim.x) {
+      __syncthreads();
+      const int nt = stage_wave(a, b, chunk, sw);
+      const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
+      for (int t = tl; t < nt; t += nlan) {
+        const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
+        const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
+        const float dv = rs * (g * ga - abv.x - xh * abv.y);
+        const float* x = sw + t * a.stride;
 #pragma unroll
-      for (int j = 0; j < MAXK; ++j)
-        if (j < a.K) acc[j] = fmaf(dv, x[j], acc[j]);
+        for (int j = 0; j < MAXK; ++j)
+          if (j < a.K) acc[j] = fmaf(dv, x[j], acc[j]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < MAXK; ++j) {
       if (j < a.K) {
+        __syncthreads();
         red[threadIdx.x] = acc[j];
         __syncthreads();
         if (tl == 0) {
@@ -230,7 +235,6 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
           for (int l = 1; l < nlan; ++l) s += red[l * cpb + cl];
           atomicAdd(dw + c * a.K + j, s * scale);
         }
-        __syncthreads();
       }
     }
   }
@@ -288,11 +292,13 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
   hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3(B), dim3(256), 0, st, part, gamma, ab, dgamma, dbeta, B, a.nchunk, C0,
                      a.T0);
   FH_CHECK_LAUNCH();
+  const int per_b = (1024 + B - 1) / B;  // ~1024 blocks in total; each flushes its dW partial once
+  dim3 wgrid(min(a.nchunk, max(1, per_b)), B);
   if (dtype == 0)
-    hipLaunchKernelGGL(conv0_bwd_weight_kernel<float>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
+    hipLaunchKernelGGL(conv0_bwd_weight_kernel<float>, wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
                        (const float*)dy, grad_scale, dw);
   else
-    hipLaunchKernelGGL(conv0_bwd_weight_kernel<bf16>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
+    hipLaunchKernelGGL(conv0_bwd_weight_kernel<bf16>, wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
                        (const bf16*)dy, grad_scale, dw);
   FH_CHECK_LAUNCH();
   return 0;

@@ -7,6 +7,9 @@
 // MFMA orientation: the Y operand (output column j) is the MFMA "A" matrix and the X operand
 // (output row i) the MFMA "B" matrix, so a lane's 4 accumulator registers are 4 CONSECUTIVE j
 // of one output row -> 8/16-byte vector stores and vector bias/residual loads in the epilogue.
+#include <utility>
+#include <vector>
+
 #include "gemm.h"
 
 namespace {
@@ -342,6 +345,36 @@ template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+// ------------------------------------------------------------------ optional per-launch HIP-event timing (bench.py roofline)
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+std::vector<ProfRec> g_prof;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+bool g_prof_on = false;
+}  // namespace
+
+extern "C" int fh_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+// sums per (dtype*4 + X layout*2 + Y layout) variant; returns the number of launches recorded and clears the log
+extern "C" int fh_prof_collect(double* ms /*[8]*/, double* flops /*[8]*/, long* launches /*[8]*/) {
+  for (int i = 0; i < 8; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms[r.variant] += t;
+    flops[r.variant] += r.flops;
+    launches[r.variant] += 1;
+    g_pool.emplace_back(r.a, r.b);
+    ++n;
+  }
+  g_prof.clear();
+  return n;
+}
+
 int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   const int vec = dtype == 0 ? 4 : 8;
   if (p.M <= 0 || p.N <= 0 || p.Kseg <= 0) return 0;
@@ -356,5 +389,19 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   if (!p.ep.atomic && (p.ldc % 4 || p.c_bstride % 4 || p.c_gstride % 4)) return -108;
   if (p.ep.row_len && p.c_rpb <= 0) return -109;
   if ((p.X.segoff[0] | p.X.segoff[1] | p.Y.segoff[0] | p.Y.segoff[1] | p.X.gstride | p.Y.gstride) % vec) return -110;
-  return dtype == 0 ? launch_t<float>(p, stream) : launch_t<bf16>(p, stream);
+  if (!g_prof_on) return dtype == 0 ? launch_t<float>(p, stream) : launch_t<bf16>(p, stream);
+  ProfRec r;
+  if (!g_pool.empty()) {
+    r.a = g_pool.back().first; r.b = g_pool.back().second;
+    g_pool.pop_back();
+  } else {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -120;
+  }
+  r.flops = 2.0 * p.M * p.N * (double)p.Kseg * p.X.nseg * p.groups;
+  r.variant = (dtype ? 4 : 0) + p.X.layout * 2 + p.Y.layout;
+  hipEventRecord(r.a, stream);
+  const int rc = dtype == 0 ? launch_t<float>(p, stream) : launch_t<bf16>(p, stream);
+  hipEventRecord(r.b, stream);
+  g_prof.push_back(r);
+  return rc;
 }

@@ -142,44 +142,57 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  if (r0 < r1) {
+  // dgamma / dbeta: reduce the 4 waves of the block through LDS, then ONE atomic per column per block
+  extern __shared__ float red[];  // [4 waves][2][C]
+  float* my = red + (threadIdx.x >> 6) * 2 * C;
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-      const int ch = lane + 64 * u;
-      if (ch < nchunk) {
+  for (int u = 0; u < NCH; ++u) {
+    const int ch = lane + 64 * u;
+    if (ch < nchunk) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          atomicAdd(dgamma + ch * VEC + e, dg[u][e]);
-          atomicAdd(dbeta + ch * VEC + e, db[u][e]);
-        }
+      for (int e = 0; e < VEC; ++e) {
+        my[ch * VEC + e] = dg[u][e];
+        my[C + ch * VEC + e] = db[u][e];
       }
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const float v = red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i];
+    atomicAdd((i < C ? dgamma : dbeta - C) + i, v);
+  }
 }
 
-// out[n % mod] += sum_m X[m][n]   (fp32 atomics; one 16-byte column chunk per thread, 128-row strips)
+// out[n % mod] += sum_m X[m][n]   (fp32 atomics).  Block = 64 column chunks x 4 row lanes over a 512-row strip;
+// the 4 row lanes are reduced through LDS so every block issues one atomic per column.
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int M, int N,
                                                      long ldx, long x_gstride, long out_gstride, int mod, float scale) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch * VEC >= N) return;
-  const T* xp = X + (long)blockIdx.z * x_gstride + ch * VEC;
-  const int r0 = blockIdx.y * 128, r1 = min(M, r0 + 128);
+  __shared__ float red[4][64 * VEC];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cx;
+  const bool cv = ch * VEC < N;
+  const T* xp = X + (long)blockIdx.z * x_gstride + (long)ch * VEC;
+  const int r0 = blockIdx.y * 512, r1 = min(M, r0 + 512);
   float acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    float v[VEC];
-    unpack16<T>(ld16(xp + (long)r * ldx), v);
+  if (cv) {
+    for (int r = r0 + ry; r < r1; r += 4) {
+      float v[VEC];
+      unpack16<T>(ld16(xp + (long)r * ldx), v);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+      for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+    }
   }
-  float* o = out + (long)blockIdx.z * out_gstride;
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    const int n = ch * VEC + e;
-    atomicAdd(o + (mod > 0 ? n % mod : n), acc[e] * scale);
+  for (int e = 0; e < VEC; ++e) red[ry][cx * VEC + e] = acc[e];
+  __syncthreads();
+  float* o = out + (long)blockIdx.z * out_gstride;
+  for (int i = threadIdx.x; i < 64 * VEC; i += 256) {
+    const int n = blockIdx.x * 64 * VEC + i;
+    if (n < N) atomicAdd(o + (mod > 0 ? n % mod : n), (red[0][i] + red[1][i] + red[2][i] + red[3][i]) * scale);
   }
 }
 
@@ -220,17 +233,18 @@ int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const flo
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return -301;
   const int nch = (C / VEC + 63) / 64;
-  const int rpw = 8;
+  const int rpw = 32;  // 128 rows per block
   const int waves = (M + rpw - 1) / rpw;
   dim3 grid((waves + 3) / 4), block(256);
+  const size_t smem = (size_t)8 * C * sizeof(float);
   if (nch == 1)
-    hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, smem, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
                        rpw, out_drop, in_drop);
   else if (nch == 2)
-    hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, smem, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
                        rpw, out_drop, in_drop);
   else if (nch <= 4)
-    hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, smem, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
                        rpw, out_drop, in_drop);
   else
     return -302;
@@ -262,7 +276,7 @@ int fh_colsum_launch(int dtype, const void* X, float* out, int M, int N, long ld
   if (M <= 0 || N <= 0) return 0;
   const int vec = dtype == 0 ? 4 : 8;
   if (N % vec || ldx % vec || x_gstride % vec) return -303;
-  dim3 grid((N / vec + 255) / 256, (M + 127) / 128, groups), block(256);
+  dim3 grid((N / vec + 63) / 64, (M + 511) / 512, groups), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)X, out, M, N, ldx, x_gstride, out_gstride,
                        mod, scale);

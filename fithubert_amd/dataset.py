@@ -1,0 +1,98 @@
+"""Length-bucketed batches (the reference's LibriDataset contract) and synthetic waveform batches.
+
+reference utils/dataset.py:27-53: concatenate the per-utterance length tables, sort by length DESCENDING, cut into
+consecutive chunks of ``batch_size`` (a trailing chunk is kept only if it has more than one item); the DataLoader
+then shuffles whole buckets (train.py:423-428) and Lightning's DistributedSampler deals them out rank-strided.
+A batch is ``{'x': zero-padded B x S_max fp32, 'padding_mask': B x S_max bool (True = pad)}`` (dataset.py:63-74).
+
+FLAC decoding is out of scope (the metric is on synthetic audio): ``SyntheticLibriDataset`` draws utterance lengths
+(from a length table, or fixed) and fills them with seeded Gaussian noise of speech-like RMS.
+"""
+from __future__ import annotations
+
+import random
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def bucket_by_length(lengths: Sequence[int], batch_size: int) -> List[List[int]]:
+    """Indices of each bucket, per utils/dataset.py:27-53 (stable for ties, like pandas' default quicksort is not
+    -- the reference's order among equal lengths is unspecified; only the multiset of lengths per bucket matters)."""
+    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    buckets, cur = [], []
+    for i in order:
+        cur.append(i)
+        if len(cur) == batch_size:
+            buckets.append(cur)
+            cur = []
+    if len(cur) > 1:
+        buckets.append(cur)
+    return buckets
+
+
+def rank_buckets(n_buckets: int, epoch: int, rank: int, world: int, seed: int = 0, shuffle: bool = True) -> List[int]:
+    """DistributedSampler semantics: one shared permutation per epoch, padded to a multiple of world, strided by rank."""
+    idx = list(range(n_buckets))
+    if shuffle:
+        random.Random(seed + epoch).shuffle(idx)
+    pad = (-len(idx)) % world
+    idx += idx[:pad]
+    return idx[rank::world]
+
+
+def balanced_rank_buckets(bucket_samples: Sequence[int], epoch: int, rank: int, world: int, seed: int = 0) -> List[int]:
+    """Per step every rank takes a bucket from the same length neighbourhood (buckets are length-sorted), so the
+    per-step work is balanced across ranks; the order of the steps is shuffled per epoch."""
+    order = sorted(range(len(bucket_samples)), key=lambda i: -bucket_samples[i])
+    pad = (-len(order)) % world
+    order += order[:pad]
+    groups = [order[i:i + world] for i in range(0, len(order), world)]
+    random.Random(seed + epoch).shuffle(groups)
+    return [g[rank] for g in groups]
+
+
+def collate(waves: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """utils/dataset.py:63-74."""
+    lens = torch.tensor([len(w) for w in waves], dtype=torch.long)
+    S = int(lens.max())
+    x = torch.zeros(len(waves), S, dtype=torch.float32)
+    for i, w in enumerate(waves):
+        x[i, : len(w)] = w
+    mask = ~(torch.arange(S)[None, :] < lens[:, None])
+    return {"x": x, "padding_mask": mask}
+
+
+class SyntheticLibriDataset:
+    """Buckets of synthetic utterances with LibriSpeech-shaped lengths."""
+
+    def __init__(self, lengths: Iterable[int], batch_size: int, seed: int = 0, rms: float = 0.1):
+        self.lengths = [int(v) for v in lengths]
+        self.batch_size = batch_size
+        self.buckets = bucket_by_length(self.lengths, batch_size)
+        self.seed = seed
+        self.rms = rms
+
+    def __len__(self):
+        return len(self.buckets)
+
+    def bucket_samples(self) -> List[int]:
+        return [max(self.lengths[i] for i in b) * len(b) for b in self.buckets]
+
+    def __getitem__(self, index: int) -> Dict[str, torch.Tensor]:
+        g = torch.Generator().manual_seed(self.seed * 1000003 + index)
+        waves = [self.rms * torch.randn(self.lengths[i], generator=g) for i in self.buckets[index]]
+        return collate(waves)
+
+
+def fixed_length_batch(batch_size: int, samples: int, seed: int = 0, rms: float = 0.1, device="cpu") -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    x = rms * torch.randn(batch_size, samples, generator=g)
+    return {"x": x.to(device), "padding_mask": torch.zeros(batch_size, samples, dtype=torch.bool, device=device)}
+
+
+def draw_lengths(table: np.ndarray, n: int, seed: int = 0) -> List[int]:
+    """n utterance lengths drawn (with replacement, seeded) from an empirical length table."""
+    rng = np.random.RandomState(seed)
+    return [int(v) for v in rng.choice(table, size=n, replace=True)]

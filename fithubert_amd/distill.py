@@ -1,0 +1,258 @@
+"""``W2V2Distil``: the reference's distillation task (train.py:26-446) without Lightning.
+
+Same constructor input (the parsed yaml), same ``forward`` / ``training_step`` / ``calculate_loss`` /
+``configure_optimizers`` / ``training_epoch_end`` surface and the same loss bookkeeping names
+(``rand_l{i}``, ``l{L-1}``).  The hot loop is re-designed for MI355X:
+
+  teacher forward (PyTorch-ROCm, bf16, no_grad)  ->  pre-stacked [L][B][T'][P] hiddens
+  student forward (native plan)  ->  fused KD loss + dL/dpred  ->  student backward (native plan)
+  async RCCL all-reduce of the flat gradient buffer  ||  NEXT batch's teacher forward
+  fused AdamW (+ warmup / linear-decay schedule, folded 1/world and 1/accumulation) -> weight re-preparation
+
+Per-layer losses stay on the device as one fp64 vector (the reference's ``self.log(k, v.item())`` per term,
+train.py:166-168, forces a host sync per term per step).
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from .config import CustomStudentModelConfig
+from .dp import GradSync, broadcast_parameters
+from .model import CustomStudentModel
+from .teacher import TeacherConfig, TeacherWrapper, build_teacher, freeze_model
+
+
+class W2V2Distil:
+    def __init__(self, cfg: dict, dtype: str = "bf16", device: str = "cuda", teacher: Optional[TeacherWrapper] = None,
+                 teacher_cfg: Optional[TeacherConfig] = None, seed: int = 0, teacher_dtype=torch.bfloat16):
+        self.yaml_cfg = cfg
+        self.train_cfg = cfg["train"]
+        self.device = torch.device(device)
+        # ---- teacher (train.py:35-37): frozen, eval
+        if teacher is None:
+            name = str(cfg.get("teacher", {}).get("teacher_model", "hubert"))
+            tcfg = teacher_cfg or TeacherConfig.base("wav2vec2" if "wav2vec" in name or "w2v" in name else "hubert")
+            teacher = build_teacher(tcfg, seed=seed + 1, dtype=teacher_dtype, device=device)
+        self.teacher_model = teacher
+        freeze_model(self.teacher_model)
+        self.task_agnostic = True
+        # ---- student (train.py:40-53)
+        self.model_cfg = cfg["distiller"]
+        student_config = CustomStudentModelConfig(**self.model_cfg)
+        student_config._teacher_task_agnostic = True
+        student_config._cnn_weight = self.train_cfg["cnn_loss_weight"]
+        self.student_model = CustomStudentModel(student_config, teacher_model=self.teacher_model, dtype=dtype, device=device,
+                                                init_seed=seed)
+        self.engine = self.student_model.engine
+        # ---- loss settings (train.py:55-62)
+        t = self.train_cfg
+        self.cnn_loss_weight = t["cnn_loss_weight"]
+        self.rec_loss_weight = t["rec_loss_weight"]
+        self.rec_loss_type = t["rec_loss_type"]
+        self.sim_loss_weight = t["sim_loss_weight"]
+        self.attn_loss_weight = t["attn_loss_weight"]
+        self.attn_loss_type = t["attn_loss_type"]
+        self.v_rel_loss_weight = t["v_rel_loss_weight"]
+        self.random_layer_weight = t["random_layer_weight"]
+        for k in ("cnn_loss_weight", "sim_loss_weight", "attn_loss_weight", "v_rel_loss_weight"):
+            if t[k] > 0:
+                raise NotImplementedError(f"train.{k} > 0 is a next-scope loss option (SURVEY 8f rank 2); the fused kernel covers rec_loss (mse / l1)")
+        if t.get("delete_projections"):
+            self.student_model._disable_projection_heads()
+        if t.get("specaug"):
+            raise NotImplementedError("specaug applies to the mel branch only, which is out of scope")
+        self.num_encoders = self.model_cfg["encoder_layers"]
+        self._rng = random.Random(seed)  # the reference samples with the unseeded global RNG per process (train.py:91)
+        if t["distil_random_layer"] > 0:
+            self.all_enc = range(self.num_encoders - 1)
+            self.rand_l = self._rng.sample(self.all_enc, t["distil_random_layer"])
+        else:
+            assert t["random_layer_weight"] == 0  # train.py:92-93
+            self.rand_l = []
+        n_teacher = self.teacher_model.model.cfg.encoder_layers
+        if max(list(self.rand_l) + [0]) >= n_teacher:
+            raise ValueError("distil_random_layer indexes teacher layers out of range (SURVEY 0.1): use a deeper teacher")
+        self.batch_size = t["batch_size"]
+        self.num_gpus = len(t["gpus"]) if isinstance(t["gpus"], list) else t["gpus"]
+        self.accumulate = int(t.get("accumulate_grad_batches", 1))
+        self._set_loss_tables()
+        # ---- optimizer state (configure_optimizers fills the schedule)
+        self.opt_m = torch.zeros_like(self.engine.params)
+        self.opt_v = torch.zeros_like(self.engine.params)
+        self.opt_step = 0
+        self.num_training_steps = None
+        self.sync = GradSync(self.engine.grads)
+        broadcast_parameters(self.engine.params)
+        self.student_model.mark_params_updated()
+        self._micro = 0
+        self._next_teacher = None
+
+    # ------------------------------------------------------------------ loss tables
+    def _set_loss_tables(self):
+        Lr = self.num_encoders
+        n_teacher = self.teacher_model.model.cfg.encoder_layers
+        w = torch.zeros(Lr)
+        tl = torch.arange(Lr, dtype=torch.int32).clamp_(max=n_teacher - 1)
+        if self.train_cfg["distil_random_layer"] > 0:
+            for l in self.rand_l:
+                w[l] = self.random_layer_weight
+            w[Lr - 1] = 1.0
+            tl[Lr - 1] = n_teacher - 1  # teacher_results["layer_results"][-1] (train.py:255-257)
+            self._mean_over_layers = 1.0
+        else:
+            ids = self.student_model.pred_layer_id
+            for i in ids:
+                w[i] = 1.0 / len(ids)  # rec_loss.mean() over the stacked layers (train.py:297)
+                tl[i] = i
+        self.layer_w = w.to(self.device)
+        self.teacher_layer = tl.to(self.device)
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, x, padding_mask=None):
+        """train.py:129-156 -> (student_results, teacher_results)."""
+        self.teacher_model.eval()
+        teacher_results = self.teacher_model.extract_features(source=x, padding_mask=padding_mask)
+        student_results = self.student_model(source=x, padding_mask=padding_mask)
+        return student_results, teacher_results
+
+    __call__ = forward
+
+    def calculate_loss(self, student_results, teacher_results, labels=None):
+        """train.py:236-405 for the built branch (rec_loss mse / l1, random-layer or pred_layer_id selection).
+        Differentiable w.r.t. the student through the fused loss kernel's gradient."""
+        proj = student_results["projections"]
+        pred = torch.stack(proj, dim=0)
+        teacher = torch.stack([lr[0].transpose(0, 1) for lr in teacher_results["layer_results"]], dim=0).contiguous()
+        out = _KDLossFn.apply(pred, teacher, self)
+        total = self.rec_loss_weight * out[-1]
+        return total.float(), self._loss_dict(out)
+
+    def _loss_dict(self, out) -> Dict[str, torch.Tensor]:
+        losses = {}
+        Lr = self.num_encoders
+        if self.train_cfg["distil_random_layer"] > 0:
+            for i, l in enumerate(self.rand_l):
+                losses[f"rand_l{i}"] = out[l] * self.random_layer_weight
+            losses[f"l{Lr - 1}"] = out[Lr - 1]
+        else:
+            for pid in self.student_model.pred_layer_id:
+                losses[f"layer{pid}"] = out[pid]
+        return losses
+
+    def training_epoch_end(self, training_step_outputs=None):
+        """train.py:172-174."""
+        if self.train_cfg["distil_random_layer"] > 0:
+            self.rand_l = self._rng.sample(self.all_enc, self.train_cfg["distil_random_layer"])
+            self._set_loss_tables()
+
+    def configure_optimizers(self, num_training_steps: int):
+        """train.py:407-421 + the yaml ``optimizer`` section (AdamW_with_schedule: linear warmup then linear decay).
+        The s3prl optimizer is third party and unpinned: parity is on loss / activations / gradients."""
+        self.num_training_steps = int(num_training_steps)
+        return self
+
+    def lr_at(self, step: int) -> float:
+        o = self.yaml_cfg["optimizer"]
+        lr = float(o["lr"])
+        if not self.num_training_steps:
+            return lr
+        warm = max(1, int(self.num_training_steps * float(o.get("warmup_proportion", 0.0))))
+        if step < warm:
+            return lr * (step + 1) / warm
+        return lr * max(0.0, (self.num_training_steps - step) / max(1, self.num_training_steps - warm))
+
+    # ------------------------------------------------------------------ hot path
+    @torch.no_grad()
+    def teacher_hiddens(self, batch) -> torch.Tensor:
+        self.teacher_model.eval()  # train.py:131
+        pm = batch.get("padding_mask")
+        if pm is not None and not bool(pm.any()) and self.teacher_model.model.cfg.model_type != "hubert":
+            pm = None
+        return self.teacher_model.hidden_stack(batch["x"], pm)
+
+    @torch.no_grad()
+    def training_step(self, batch, batch_idx: int = 0, next_batch=None, seed: Optional[int] = None):
+        """One micro-batch: teacher fwd, student fwd, fused loss, student bwd; on accumulation boundaries the async
+        gradient all-reduce, (next batch's teacher forward), AdamW.  Returns the fp64 device vector
+        [per-layer means..., total] (no host sync)."""
+        x = batch["x"]
+        pm = batch.get("padding_mask")
+        lengths = None
+        if pm is not None and bool(batch.get("_any_pad", pm.any())):
+            lengths = batch.get("_lengths")
+            if lengths is None:
+                lengths = (~pm).sum(-1).tolist()
+        hid = self._next_teacher if self._next_teacher is not None else self.teacher_hiddens(batch)
+        self._next_teacher = None
+        if self._micro == 0:
+            self.engine.grads.zero_()
+        step_seed = seed if seed is not None else (self.opt_step * 7919 + self._micro * 104729 + batch_idx + 1)
+        ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed)
+        out, d_pred = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer,
+                                          loss_type=0 if self.rec_loss_type == "mse" else 1, grad_scale=float(self.rec_loss_weight))
+        self.engine.backward(ws, d_pred=d_pred)
+        self._micro += 1
+        if self._micro >= self.accumulate:
+            self.sync.launch()                      # async all-reduce of the flat gradients (RCCL / xGMI)
+            if next_batch is not None:              # overlapped with the frozen teacher's next forward
+                self._next_teacher = self.teacher_hiddens(next_batch)
+            self.sync.wait()
+            self.optimizer_step()
+        elif next_batch is not None:
+            self._next_teacher = self.teacher_hiddens(next_batch)
+        return out
+
+    @torch.no_grad()
+    def optimizer_step(self):
+        o = self.yaml_cfg["optimizer"]
+        b1, b2 = [float(v) for v in o.get("betas", (0.9, 0.999))]
+        self.opt_step += 1
+        t = self.opt_step
+        L.check(L.lib().fh_adamw(self.engine.params.data_ptr(), self.engine.grads.data_ptr(), self.opt_m.data_ptr(),
+                                 self.opt_v.data_ptr(), self.engine.n_params, self.lr_at(t - 1), b1, b2, float(o.get("eps", 1e-8)),
+                                 float(o.get("weight_decay", 0.0)), 1.0 - b1 ** t, 1.0 - b2 ** t,
+                                 self.sync.scale / self.accumulate, None, self.engine.stream()), "fh_adamw")
+        self._micro = 0
+        self.student_model.mark_params_updated()
+        self.student_model._flat_version = self.student_model.flat._version
+
+    # ------------------------------------------------------------------ checkpoints (train.py:475-483 key convention)
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        sd = {"student_model." + k: v.detach().clone() for k, v in self.student_model.state_dict().items()}
+        sd.update({"teacher_model.model." + k: v for k, v in self.teacher_model.model.state_dict().items()})
+        return sd
+
+    def save_checkpoint(self, path: str, epoch: int = 0) -> None:
+        torch.save({"state_dict": {k: v.cpu() for k, v in self.state_dict().items()}, "epoch": epoch,
+                    "global_step": self.opt_step, "hyper_parameters": {"cfg": self.yaml_cfg}}, path)
+
+
+class _KDLossFn(torch.autograd.Function):
+    """API-path loss: out = [per-layer means..., weighted total]; grad flows to the stacked projections."""
+
+    @staticmethod
+    def forward(ctx, pred, teacher, task):
+        eng = task.engine
+        pred = pred.contiguous()
+        Lh, B, Tp, P = pred.shape
+        tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16
+        lib = L.lib()
+        nblk = lib.fh_kd_loss_nblk(eng.c.dtype, B, Tp, P)
+        partials = torch.empty(Lh * nblk, device=pred.device, dtype=torch.float32)
+        out = torch.empty(Lh + 1, device=pred.device, dtype=torch.float64)
+        d_pred = torch.empty_like(pred)
+        L.check(lib.fh_kd_loss(eng.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(), d_pred.data_ptr(), task.layer_w.data_ptr(),
+                               task.teacher_layer.data_ptr(), partials.data_ptr(), out.data_ptr(), Lh, B, Tp, teacher.shape[2], P,
+                               B * teacher.shape[2] * P, 0 if task.rec_loss_type == "mse" else 1, 1.0, eng.stream()), "fh_kd_loss")
+        ctx.save_for_backward(d_pred)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_pred,) = ctx.saved_tensors
+        return d_pred * g[-1].to(d_pred.dtype), None, None

@@ -1,0 +1,249 @@
+"""``CustomStudentModel``: the reference's student module surface over the native engine.
+
+Mirrors reference modules/model.py:253-587 -- constructor ``CustomStudentModel(cfg, teacher_model=None, **kwargs)``,
+``forward(source, padding_mask=None, layer=None)`` returning exactly the six keys
+``x, padding_mask, features, layer_results, tr_layer_results, projections`` (model.py:545-552),
+``extract_features``, ``_get_feat_extract_output_lengths``, ``_disable_projection_heads``, the attribute
+``pred_layer_id``, and a ``state_dict`` with the reference's key names so Lightning checkpoints written
+by the reference load here and vice versa.
+
+All arithmetic runs in libfithubert_hip.so (fithubert_amd/csrc).  There is no eager / CPU path: constructing the
+model without a GPU or without the built library raises.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .config import CustomStudentModelConfig
+from .engine import StudentEngine
+
+
+class _StudentFn(torch.autograd.Function):
+    """One autograd node for the whole student: forward = native plan, backward = native plan."""
+
+    @staticmethod
+    def forward(ctx, flat, model, source, lengths, training, heads_on, seed):
+        eng = model.engine
+        eng.version += 1 if model._dirty() else 0
+        ws = eng.forward(source, lengths, training=training, heads_on=heads_on, seed=seed)
+        ctx.ws, ctx.model = ws, model
+        ctx.needs = training
+        pred, xo = ws.view("pred"), ws.view("xo")
+        feats, f2 = ws.view("features"), ws.view("f2")
+        ctx.mark_non_differentiable(feats, f2)
+        return pred, xo, feats, f2
+
+    @staticmethod
+    def backward(ctx, d_pred, d_xo, _df, _df2):
+        if not ctx.needs:
+            raise RuntimeError("backward through CustomStudentModel requires model.train() (activations are not kept in eval mode)")
+        eng = ctx.model.engine
+        g = torch.zeros_like(eng.params)
+        d_hidden = None
+        if d_xo is not None:
+            if d_xo[0].abs().max().item() != 0:
+                raise NotImplementedError("gradient w.r.t. tr_layer_results is not built")
+            d_hidden = d_xo[1:].contiguous()
+        eng.backward(ctx.ws, d_pred=d_pred.contiguous() if d_pred is not None else None, d_hidden=d_hidden, grads=g)
+        return g, None, None, None, None, None, None
+
+
+class _LayerList(list):
+    """Stand-in for ``encoder.layers`` (train.py:70 iterates it only when attention transfer is enabled)."""
+
+
+class _EncoderNS:
+    def __init__(self, n):
+        self.layers = _LayerList(range(n))
+
+
+class CustomStudentModel(nn.Module):
+    def __init__(self, cfg: CustomStudentModelConfig, teacher_model=None, dtype: str = "bf16", device: str = "cuda",
+                 init_seed: int = 0, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        self.engine = StudentEngine(cfg, dtype=dtype, device=device)
+        # ONE flat fp32 parameter: its storage IS the engine's parameter buffer
+        self.flat = nn.Parameter(self.engine.params)
+        self._flat_version = self.flat._version
+        self.pred_layer_id = cfg.pred_layers()          # model.py:337
+        self.n_tasks = len(self.pred_layer_id)
+        self.layerwise_proj = cfg.layerwise_proj
+        self.enable_tr_layer = cfg.enable_tr_layer
+        self.feature_grad_mult = cfg.feature_grad_mult
+        self.encoder = _EncoderNS(cfg.encoder_layers + (1 if cfg.enable_tr_layer else 0))
+        self._heads_on = True
+        self.specaug = None
+        self._step_seed = 0
+        self.reset_parameters(init_seed)
+        if cfg.init_conv_layers:                        # model.py:327-332
+            assert teacher_model is not None
+            self.init_from_teacher_conv(teacher_model)
+        if cfg.init_encoder_layers > 0:
+            assert teacher_model is not None
+            self.init_from_teacher_enc(teacher_model, cfg.init_encoder_layers)
+
+    # ------------------------------------------------------------------ parameters / checkpoints
+    def _dirty(self) -> bool:
+        v = self.flat._version
+        if v != self._flat_version:
+            self._flat_version = v
+            return True
+        return False
+
+    def mark_params_updated(self) -> None:
+        self.engine.version += 1
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: int = 0) -> None:
+        """Same distributions as the reference initialisers (module.py:47 kaiming_normal for convs, :195-197 pos_conv,
+        init_bert_params N(0, 0.02) for Linear / q,k,v, default torch init for the TR conv / ConvTranspose heads)."""
+        g = torch.Generator().manual_seed(seed)
+        for name, p in self.engine.param_views().items():
+            shape = tuple(p.shape)
+            if "feature_extractor" in name and name.endswith("0.weight"):
+                fan_in = shape[1] * shape[2]
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+            elif name.endswith("weight_v"):
+                k, e = self.cfg.conv_pos, self.cfg.encoder_embed_dim
+                t = torch.randn(shape, generator=g) * math.sqrt(4.0 / (k * e))
+            elif name.endswith("weight_g"):
+                t = None  # set from weight_v below (weight_norm initialises g = ||v||)
+            elif "layer_norm.weight" in name or name.endswith(".2.weight"):
+                t = torch.ones(shape)
+            elif name.endswith("bias") and ("upsampler" in name or name == "encoder.layers.0.bias" and self.cfg.enable_tr_layer):
+                fan_in = shape[0] * 1
+                t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(self.cfg.encoder_embed_dim * self.cfg.tr_reduce_factor)
+            elif name.endswith("bias"):
+                t = torch.zeros(shape)
+            elif "upsampler.weight" in name or (name == "encoder.layers.0.weight" and self.cfg.enable_tr_layer):
+                fan_in = shape[1] * shape[2] if "upsampler" in name else shape[1] * shape[2]
+                bound = 1.0 / math.sqrt(fan_in)
+                t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            else:
+                t = torch.randn(shape, generator=g) * 0.02
+            if t is not None:
+                p.copy_(t.to(p.device))
+        views = self.engine.param_views()
+        v = views["encoder.pos_conv.0.weight_v"]
+        views["encoder.pos_conv.0.weight_g"].copy_(v.norm(2, dim=(0, 1), keepdim=True))
+        self.mark_params_updated()
+
+    def _name_map(self) -> "OrderedDict[str, str]":
+        """reference key -> engine key (they differ only after _disable_projection_heads: final_proj.* = last head)."""
+        m = OrderedDict()
+        last = f"proj_head.{self.cfg.encoder_layers - 1}."
+        for name, _, _ in self.engine.table:
+            if self._heads_on:
+                m[name] = name
+            elif name.startswith("proj_head."):
+                if name.startswith(last):
+                    m["final_proj." + name[len(last):]] = name
+            else:
+                m[name] = name
+        return m
+
+    def state_dict(self, destination=None, prefix: str = "", keep_vars: bool = False):
+        out = OrderedDict() if destination is None else destination
+        views = self.engine.param_views(self.flat if keep_vars else self.flat.detach())
+        for ref_name, eng_name in self._name_map().items():
+            out[prefix + ref_name] = views[eng_name]
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        m = self._name_map()
+        sd = {m[k]: v for k, v in state_dict.items() if k in m}
+        missing = [k for k in m if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in m]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for CustomStudentModel: missing {missing}, unexpected {unexpected}")
+        self.engine.load_state_dict(sd, strict=False)
+        self._flat_version = self.flat._version
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def named_reference_parameters(self) -> Dict[str, torch.Tensor]:
+        return self.engine.param_views(self.flat)
+
+    # ------------------------------------------------------------------ reference API
+    def add_specaug(self, specaug):
+        raise NotImplementedError("SpecAugment applies to the mel-spectrogram branch only (model.py:439-441), which is out of scope")
+
+    def _get_feat_extract_output_lengths(self, input_lengths: torch.LongTensor):
+        """modules/model.py:376-391."""
+        x = input_lengths
+        for (_, k, s) in self.engine.layers:
+            x = torch.floor((x - k) / s + 1)
+        return x.to(torch.long)
+
+    def _disable_projection_heads(self):
+        """modules/model.py:393-399: keep only the last head as ``final_proj``."""
+        self._heads_on = False
+
+    def init_from_teacher_conv(self, teacher_model):
+        src = teacher_model.model.state_dict()
+        views = self.engine.param_views()
+        with torch.no_grad():
+            for k, v in views.items():
+                if (k.startswith("feature_extractor.") or k.startswith("post_extract_proj.")) and k in src and src[k].shape == v.shape:
+                    v.copy_(src[k].float())
+        self.mark_params_updated()
+
+    def init_from_teacher_enc(self, teacher_model, n_layers):
+        assert n_layers <= self.cfg.encoder_layers
+        src = teacher_model.model.state_dict()
+        views = self.engine.param_views()
+        off = 1 if self.cfg.enable_tr_layer else 0
+        with torch.no_grad():
+            for k, v in views.items():
+                if k.startswith("encoder.pos_conv.") and k in src and src[k].shape == v.shape:
+                    v.copy_(src[k].float())
+            for i in range(n_layers):
+                for k, v in views.items():
+                    p = f"encoder.layers.{i + off}."
+                    if k.startswith(p):
+                        sk = f"encoder.layers.{i}." + k[len(p):]
+                        if sk in src and src[sk].shape == v.shape:
+                            v.copy_(src[sk].float())
+        self.mark_params_updated()
+
+    def forward(self, source, padding_mask=None, layer=None):
+        if layer is not None:
+            raise NotImplementedError("early exit at `layer` is not built")
+        if not source.is_cuda:
+            raise RuntimeError("CustomStudentModel (fithubert_amd) computes on the GPU only; move `source` to the device")
+        source = source.float().contiguous()
+        B, S = source.shape
+        lengths = None
+        pm_out = None
+        if padding_mask is not None and bool(padding_mask.any()):  # model.py:449
+            lengths = (~padding_mask.bool()).sum(-1).tolist()
+            tp, _ = self.engine.frame_lengths(lengths)
+            Tp = self.engine.frames(S)[0]
+            pm_out = (torch.arange(Tp)[None, :] >= torch.tensor(tp)[:, None]).to(source.device)
+        self._step_seed = (self._step_seed + 1) & 0x7FFFFFFF
+        pred, xo, feats, f2 = _StudentFn.apply(self.flat, self, source, lengths, self.training, self._heads_on, self._step_seed)
+        L = self.cfg.encoder_layers
+        layer_results = [(xo[i + 1].transpose(0, 1), None, f2[i].transpose(0, 1)) for i in range(L)]
+        tr_layer_results = [xo[0].transpose(0, 1)] if self.cfg.enable_tr_layer else []
+        if self._heads_on:
+            projections = [pred[i] for i in range(L)]
+            x = projections[-1]
+        else:
+            projections = None
+            x = pred[0]
+        return {
+            "x": x,
+            "padding_mask": pm_out,
+            "features": feats,
+            "layer_results": layer_results,
+            "tr_layer_results": tr_layer_results,
+            "projections": projections,
+        }
+
+    def extract_features(self, source, padding_mask, layer=None):
+        return self.forward(source, padding_mask, layer=layer)

@@ -1,0 +1,263 @@
+"""Frozen teacher on stock PyTorch-ROCm (north star: "the frozen teacher forward runs on PyTorch-ROCm").
+
+A plain ``nn.Module`` HuBERT / wav2vec 2.0 encoder with fairseq's parameter names, so a fairseq checkpoint's
+``state['model']`` loads into it, plus the contract of the reference's ``TeacherWrapper``
+(utils/utils.py:51-99): ``extract_features(source, padding_mask)`` returns
+``{"layer_results": [(x[T,B,C], (None, fc2_out)), ...], "x": [B,T,C], "features": [post_extract_proj out]}``.
+
+For the training hot path ``hidden_stack`` returns the same layer outputs pre-stacked as one
+``[L][B][T'][C]`` tensor in the teacher dtype -- the layout the fused KD-loss kernel reads in place
+(train.py:251-258 builds that stack with a torch.stack every step).
+
+The teacher is third-party in the reference (fairseq@1b61bbad HubertModel / Wav2Vec2Model, loaded at
+utils/utils.py:102-149); there is no fairseq and no checkpoint in this environment, so it is random-initialised
+for benchmarking and its arithmetic is pinned by tests/test_teacher_gpu.py against the oracle restatement.
+"""
+from __future__ import annotations
+
+import ast
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class TeacherConfig:
+    model_type: str = "hubert"            # 'hubert' | 'wav2vec2' (padding-mask rule differs)
+    extractor_mode: str = "default"       # 'default' (GroupNorm on layer 0) | 'layer_norm' (Large)
+    conv_feature_layers: str = "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"
+    conv_bias: bool = False
+    encoder_layers: int = 12
+    encoder_embed_dim: int = 768
+    encoder_ffn_embed_dim: int = 3072
+    encoder_attention_heads: int = 12
+    layer_norm_first: bool = False
+    conv_pos: int = 128
+    conv_pos_groups: int = 16
+
+    @staticmethod
+    def base(model_type: str = "hubert") -> "TeacherConfig":
+        return TeacherConfig(model_type=model_type)
+
+    @staticmethod
+    def large() -> "TeacherConfig":
+        return TeacherConfig(extractor_mode="layer_norm", conv_bias=True, encoder_layers=24, encoder_embed_dim=1024,
+                             encoder_ffn_embed_dim=4096, encoder_attention_heads=16, layer_norm_first=True)
+
+    def layers(self):
+        from .config import _eval_layer_spec
+        return _eval_layer_spec(self.conv_feature_layers)
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, d, h):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+        self.h = h
+
+    def forward(self, x, key_mask):  # x: B x T x C
+        B, T, C = x.shape
+        h, d = self.h, C // self.h
+        q = self.q_proj(x).view(B, T, h, d).transpose(1, 2)
+        k = self.k_proj(x).view(B, T, h, d).transpose(1, 2)
+        v = self.v_proj(x).view(B, T, h, d).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=key_mask)  # scale = d**-0.5 == fairseq's q scaling
+        return self.out_proj(o.transpose(1, 2).reshape(B, T, C))
+
+
+class _Layer(nn.Module):
+    def __init__(self, d, f, h, pre_ln):
+        super().__init__()
+        self.self_attn = _SelfAttn(d, h)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+        self.pre_ln = pre_ln
+
+    def forward(self, x, key_mask):
+        if self.pre_ln:
+            x = x + self.self_attn(self.self_attn_layer_norm(x), key_mask)
+            lr = self.fc2(F.gelu(self.fc1(self.final_layer_norm(x))))
+            return x + lr, lr
+        x = self.self_attn_layer_norm(x + self.self_attn(x, key_mask))
+        lr = self.fc2(F.gelu(self.fc1(x)))
+        return self.final_layer_norm(x + lr), lr
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg: TeacherConfig):
+        super().__init__()
+        d = cfg.encoder_embed_dim
+        conv = nn.Conv1d(d, d, cfg.conv_pos, padding=cfg.conv_pos // 2, groups=cfg.conv_pos_groups)
+        # old-style weight_norm parameter names (weight_g / weight_v) as in fairseq checkpoints
+        self.pos_conv = nn.Sequential(_WeightNormConv(conv))
+        self.layers = nn.ModuleList([_Layer(d, cfg.encoder_ffn_embed_dim, cfg.encoder_attention_heads, cfg.layer_norm_first)
+                                     for _ in range(cfg.encoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+        self.k = cfg.conv_pos
+
+
+class _WeightNormConv(nn.Module):
+    """Conv1d with weight_norm(dim=2) stored as weight_g [1,1,K] / weight_v [Cout,Cin/g,K] / bias."""
+
+    def __init__(self, conv: nn.Conv1d):
+        super().__init__()
+        self.weight_g = nn.Parameter(conv.weight.detach().norm(2, dim=(0, 1), keepdim=True))
+        self.weight_v = nn.Parameter(conv.weight.detach().clone())
+        self.bias = nn.Parameter(conv.bias.detach().clone())
+        self.padding, self.groups = conv.padding[0], conv.groups
+
+    def weight(self):
+        v = self.weight_v.float()
+        return (self.weight_g.float() * v / v.norm(2, dim=(0, 1), keepdim=True)).to(self.weight_v.dtype)
+
+    def forward(self, x):
+        return F.conv1d(x, self.weight(), self.bias, padding=self.padding, groups=self.groups)
+
+
+class _FeatureExtractor(nn.Module):
+    def __init__(self, cfg: TeacherConfig):
+        super().__init__()
+        self.mode = cfg.extractor_mode
+        self.conv_layers = nn.ModuleList()
+        cin = 1
+        self.spec = cfg.layers()
+        for i, (dim, k, s) in enumerate(self.spec):
+            blk = nn.Sequential()
+            blk.add_module("0", nn.Conv1d(cin, dim, k, stride=s, bias=cfg.conv_bias))
+            if self.mode == "layer_norm":
+                blk.add_module("2", nn.Sequential(nn.Identity(), nn.LayerNorm(dim), nn.Identity()))  # names: 2.1.weight
+            elif i == 0:
+                blk.add_module("2", nn.GroupNorm(dim, dim))
+            self.conv_layers.append(blk)
+            cin = dim
+        self.out_dim = cin
+
+    def forward(self, wav):  # B x S -> B x C x T
+        x = wav.unsqueeze(1)
+        for i, blk in enumerate(self.conv_layers):
+            x = getattr(blk, "0")(x)
+            if self.mode == "layer_norm":
+                x = getattr(blk, "2")[1](x.transpose(1, 2)).transpose(1, 2)
+            elif i == 0:
+                x = F.group_norm(x.float(), x.shape[1], getattr(blk, "2").weight.float(), getattr(blk, "2").bias.float(), 1e-5).to(x.dtype)
+            x = F.gelu(x)
+        return x
+
+
+class TeacherModel(nn.Module):
+    """Parameter names == fairseq HubertModel / Wav2Vec2Model for the parts the distillation uses."""
+
+    def __init__(self, cfg: TeacherConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.feature_extractor = _FeatureExtractor(cfg)
+        self.layer_norm = nn.LayerNorm(self.feature_extractor.out_dim)
+        self.post_extract_proj = nn.Linear(self.feature_extractor.out_dim, cfg.encoder_embed_dim)
+        self.encoder = _Encoder(cfg)
+
+    def _frame_mask(self, padding_mask, T):
+        """True = padded frame.  HuBERT: all samples of the frame are padding (fairseq forward_padding_mask);
+        wav2vec 2.0: conv-length formula, and None when nothing is padded."""
+        if padding_mask is None:
+            return None
+        if self.cfg.model_type == "hubert":
+            extra = padding_mask.size(1) % T
+            pm = padding_mask[:, :-extra] if extra > 0 else padding_mask
+            return pm.view(pm.size(0), T, -1).all(-1)
+        if not padding_mask.any():
+            return None
+        lens = (~padding_mask).sum(-1)
+        for (_, k, s) in self.feature_extractor.spec:
+            lens = torch.div(lens - k, s, rounding_mode="floor") + 1
+        return torch.arange(T, device=padding_mask.device)[None, :] >= lens[:, None]
+
+    @torch.no_grad()
+    def run(self, source, padding_mask=None, want_fc2: bool = False):
+        """-> (hidden [L][B][T][C], post_extract_proj [B][T][C], fc2 list or None)"""
+        dt = self.post_extract_proj.weight.dtype
+        x = self.feature_extractor(source.to(dt)).transpose(1, 2)
+        x = self.layer_norm(x)
+        B, T, _ = x.shape
+        fm = self._frame_mask(padding_mask, T)
+        post = self.post_extract_proj(x)
+        x = post
+        if fm is not None:
+            x = x.masked_fill(fm.unsqueeze(-1), 0.0)
+        xc = self.encoder.pos_conv(x.transpose(1, 2))
+        if self.encoder.k % 2 == 0:
+            xc = xc[:, :, :-1]
+        x = x + F.gelu(xc).transpose(1, 2)
+        if not self.cfg.layer_norm_first:
+            x = self.encoder.layer_norm(x)
+        key_mask = None if fm is None else (~fm)[:, None, None, :]
+        L = len(self.encoder.layers)
+        hidden = torch.empty(L, B, T, x.shape[-1], device=x.device, dtype=dt)
+        fc2 = [] if want_fc2 else None
+        for i, layer in enumerate(self.encoder.layers):
+            x, lr = layer(x, key_mask)
+            hidden[i].copy_(x)
+            if want_fc2:
+                fc2.append(lr)
+        return hidden, post, fc2
+
+
+class TeacherWrapper(nn.Module):
+    """reference utils/utils.py:51-99: ``.model`` is the teacher, ``extract_features`` yields the hook outputs."""
+
+    def __init__(self, model: TeacherModel):
+        super().__init__()
+        self.model = model
+
+    def extract_features(self, source, padding_mask):
+        hidden, post, fc2 = self.model.run(source, padding_mask, want_fc2=True)
+        layer_results = [(hidden[i].transpose(0, 1), (None, fc2[i].transpose(0, 1))) for i in range(hidden.shape[0])]
+        return {"layer_results": layer_results, "x": hidden[-1], "features": [post]}
+
+    def hidden_stack(self, source, padding_mask=None):
+        return self.model.run(source, padding_mask)[0]
+
+
+def freeze_model(model: nn.Module) -> None:
+    """reference utils/utils.py:187-190."""
+    for p in model.parameters():
+        p.requires_grad = False
+
+
+def build_teacher(cfg: TeacherConfig, seed: int = 1, dtype=torch.bfloat16, device="cuda",
+                  state_dict: Optional[Dict[str, torch.Tensor]] = None) -> TeacherWrapper:
+    """Random-init (seeded) teacher of the given architecture, or load fairseq-named weights."""
+    g = torch.Generator().manual_seed(seed)
+    m = TeacherModel(cfg)
+    if state_dict is None:
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if name.endswith("weight_g"):
+                    p.copy_(0.5 + torch.rand(p.shape, generator=g))
+                elif "layer_norm.weight" in name or name.endswith(".2.weight") or name.endswith(".2.1.weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                elif name.endswith("bias"):
+                    p.copy_(0.02 * torch.randn(p.shape, generator=g))
+                else:
+                    fan_in = 1
+                    for s in p.shape[1:]:
+                        fan_in *= s
+                    gain = 2.0 ** 0.5 if "feature_extractor" in name else 1.0
+                    p.copy_(torch.randn(p.shape, generator=g) * (gain / fan_in ** 0.5))
+    else:
+        own = m.state_dict()
+        missing = [k for k in own if k not in state_dict]
+        if missing:
+            raise RuntimeError(f"teacher checkpoint is missing {missing[:5]}...")
+        m.load_state_dict({k: state_dict[k] for k in own})
+    m = m.to(device=device, dtype=dtype).eval()
+    w = TeacherWrapper(m)
+    freeze_model(w)
+    return w

@@ -79,6 +79,10 @@ typedef struct {
 } fh_gemm_desc;
 
 int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
+/* Optional per-launch HIP-event timing of the GEMM kernel on its own stream (used by bench.py's roofline object).
+ * Variants are indexed dtype*4 + X.layout*2 + Y.layout.  collect() waits for the recorded events, sums, and clears. */
+int fh_prof_enable(int on);
+int fh_prof_collect(double* ms /*[8]*/, double* flops /*[8]*/, long* launches /*[8]*/);
 
 /* ------------------------------------------------------------------------------------------
  * Waveform frontend layer 0: Conv1d(1, C0, K, stride, bias=False) + GroupNorm(C0, C0) + GELU.
