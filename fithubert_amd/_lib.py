@@ -105,6 +105,7 @@ _ENGINE_SIGS = {
 # name -> (restype, argtypes) ; mirrors include/fithubert_hip.h one to one
 SIGNATURES = {
     "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
+    "fh_gemm_set_path": (_I, [_I]),
     "fh_prof_enable": (_I, [_I]),
     "fh_prof_collect": (_I, [_P, _P, _P]),
     "fh_conv0_scratch_floats": (_L, [_I, _I, _I, _I, _I]),

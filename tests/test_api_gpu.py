@@ -1,0 +1,135 @@
+"""GPU: the reference-shaped Python surface (CustomStudentModel, W2V2Distil, UpstreamExpert) over the native engine."""
+import os
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+from fithubert_amd.config import CustomStudentModelConfig  # noqa: E402
+from fithubert_amd.model import CustomStudentModel  # noqa: E402
+from oracle import student_ref as S  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+def _cfg(**over):
+    d = yaml.safe_load(open(os.path.join(ROOT, "conf", "fithubert.yaml")))
+    d["distiller"].update(over)
+    return d
+
+
+def _rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def test_module_surface_state_dict_and_forward():
+    y = _cfg(encoder_layers=2)
+    cfg = CustomStudentModelConfig(**y["distiller"])
+    m = CustomStudentModel(cfg, dtype="float32", device=DEV)
+    sd = S.random_state_dict(y["distiller"], seed=5)
+    assert set(m.state_dict().keys()) == set(sd.keys())      # the reference's key names
+    m.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in list(sd.items())[1:]})  # strict, like nn.Module
+    m.eval()
+    wav = 0.5 * torch.randn(2, 8000, generator=torch.Generator().manual_seed(1))
+    pm = torch.zeros(2, 8000, dtype=torch.bool)
+    pm[1, 6000:] = True
+    wav[1, 6000:] = 0
+    with torch.no_grad():
+        out = m(wav.to(DEV), pm.to(DEV))
+        ref = S.student_forward(sd, y["distiller"], wav, pm)
+    assert list(out.keys()) == ["x", "padding_mask", "features", "layer_results", "tr_layer_results", "projections"]
+    assert torch.equal(out["padding_mask"].cpu(), ref["padding_mask"])
+    assert _rel_l2(out["x"], ref["x"]) < 1e-4
+    assert _rel_l2(out["features"], ref["features"]) < 1e-4
+    assert out["layer_results"][1][0].shape == ref["layer_results"][1][0].shape  # T2 x B x D
+    assert _rel_l2(out["layer_results"][1][0], ref["layer_results"][1][0]) < 1e-4
+    assert _rel_l2(out["layer_results"][1][2], ref["layer_results"][1][2]) < 2e-4
+    assert _rel_l2(out["tr_layer_results"][0], ref["tr_layer_results"][0]) < 1e-4
+    assert len(out["projections"]) == 2
+    assert m._get_feat_extract_output_lengths(torch.tensor([8000, 6000])).tolist() == [24, 18]
+    # deployment path (expert.py:47): only the last head, exposed as final_proj.*
+    m._disable_projection_heads()
+    keys = set(m.state_dict().keys())
+    assert "final_proj.lin_proj.weight" in keys and not any(k.startswith("proj_head.") for k in keys)
+    with torch.no_grad():
+        out2 = m(wav.to(DEV), pm.to(DEV))
+    assert out2["projections"] is None
+    assert _rel_l2(out2["x"], ref["x"]) < 1e-4
+
+
+def test_module_autograd_matches_oracle_autograd():
+    y = _cfg(encoder_layers=2, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    cfg = CustomStudentModelConfig(**y["distiller"])
+    m = CustomStudentModel(cfg, dtype="float32", device=DEV)
+    sd = S.random_state_dict(y["distiller"], seed=6)
+    m.load_state_dict(sd)
+    m.train()
+    wav = 0.5 * torch.randn(2, 8000, generator=torch.Generator().manual_seed(2))
+    out = m(wav.to(DEV), None)
+    # a loss that touches the final projection AND a hidden state (the S3PRL weighted-sum case)
+    loss = out["x"].float().pow(2).mean() + out["layer_results"][0][0].float().mean()
+    loss.backward()
+    sd_g = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = S.student_forward(sd_g, y["distiller"], wav, None)
+    ref_loss = ref["x"].pow(2).mean() + ref["layer_results"][0][0].mean()
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    g = m.engine.param_views(m.flat.grad)
+    for k in ("encoder.layers.1.self_attn.q_proj.weight", "encoder.layers.2.fc2.weight", "proj_head.1.lin_proj.weight",
+              "feature_extractor.conv_layers.4.0.weight", "encoder.pos_conv.0.weight_v", "layer_norm.bias"):
+        assert _rel_l2(g[k], sd_g[k].grad) < 3e-3, k
+    assert g["proj_head.0.lin_proj.weight"].abs().max().item() == 0  # head 0 does not feed this loss
+
+
+def test_distill_task_trains_and_checkpoints_roundtrip(tmp_path):
+    from fithubert_amd.dataset import fixed_length_batch
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.expert import UpstreamExpert
+    from fithubert_amd.teacher import TeacherConfig
+
+    y = _cfg(encoder_layers=3)
+    y["train"]["distil_random_layer"] = 2
+    y["train"]["accumulate_grad_batches"] = 1
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 3
+    task = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=tc, seed=0)
+    task.configure_optimizers(num_training_steps=40)
+    assert sorted(task.rand_l) == [0, 1]
+    batch = fixed_length_batch(4, 16000, seed=0, device=DEV)
+    losses = [task.training_step(batch, batch_idx=i, next_batch=batch)[-1].item() for i in range(12)]
+    assert losses[-1] < 0.9 * losses[0], losses        # it learns on a fixed batch
+    assert task.opt_step == 12
+    # API path: forward + calculate_loss produce the same number as the fused hot path in eval mode
+    task.student_model.eval()
+    with torch.no_grad():
+        s_res, t_res = task.forward(batch["x"], batch["padding_mask"])
+        total, d = task.calculate_loss(s_res, t_res)
+    assert set(d.keys()) == {"rand_l0", "rand_l1", "l2"}
+    ws = task.engine.forward(batch["x"], None, training=False)
+    out, _ = task.engine.kd_loss(ws, task.teacher_hiddens(batch), task.layer_w, task.teacher_layer, want_grad=False)
+    assert abs(total.item() - out[-1].item()) < 2e-3 * abs(out[-1].item())
+    # Lightning-style checkpoint -> UpstreamExpert (reference README.md:27-29 flow)
+    ck = tmp_path / "checkpoint-epoch=00.ckpt"
+    task.save_checkpoint(str(ck))
+    yp = tmp_path / "cfg.yaml"
+    yp.write_text(yaml.dump(y))
+    exp = UpstreamExpert(str(ck), str(yp)).eval()
+    assert exp.get_downsample_rates("hidden_states") == 320
+    wavs = [batch["x"][0, :16000], batch["x"][1, :12000]]
+    with torch.no_grad():
+        res = exp(wavs)
+    assert res["last_hidden_state"].shape == (2, 48, 768) and res["last_hidden_state"].dtype == torch.float32
+    assert len(res["hidden_states"]) == 3 and res["hidden_states"][0][0].shape == (24, 2, 480)
+    # same weights => same output as the task's student on the same (padded) input
+    pm = torch.zeros(2, 16000, dtype=torch.bool, device=DEV)
+    pm[1, 12000:] = True
+    src = torch.stack([wavs[0], torch.cat([wavs[1], torch.zeros(4000, device=DEV)])])
+    with torch.no_grad():
+        ref = task.student_model(src, pm)
+    assert _rel_l2(res["last_hidden_state"], ref["projections"][-1].float()) < 1e-6
