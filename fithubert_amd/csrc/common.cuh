@@ -101,11 +101,31 @@ __device__ __forceinline__ void st4(bf16* p, const float* f) {
 }
 
 // ---------------------------------------------------------------- math
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact-erf GELU (torch's default, modules/module.py:63-73) evaluated with the Abramowitz-Stegun 7.1.26 rational form:
+// |erf error| <= 1.5e-7 (below fp32 round-off of the surrounding GEMMs), one v_rcp + one v_exp, no branches.
+// libdevice erff() costs several times more VALU and dominated the epilogues of the short-K conv GEMMs.
+// The same exponential also yields the Gaussian pdf needed by the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float u = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, u, 1.0f));
+  const float e = __expf(-u * u);
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erf_abs = fmaf(-p * t, e, 1.0f);
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
 }
 
 // ---------------------------------------------------------------- counter-based dropout

@@ -348,7 +348,7 @@ inline int splitk_for(long tiles, long red) {
   const long maxsk = red / 512 > 0 ? red / 512 : 1;
   if (sk > maxsk) sk = maxsk;
   if (sk < 1) sk = 1;
-  if (sk > 64) sk = 64;
+  if (sk > 256) sk = 256;
   return (int)sk;
 }
 

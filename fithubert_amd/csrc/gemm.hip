@@ -278,6 +278,97 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
   }
 }
 
+// ------------------------------------------------------------------ LDS-staged epilogue (non-atomic outputs)
+// The MFMA C layout gives a lane 4 consecutive columns of one row, so direct stores touch 16 rows x 32 B per wave
+// instruction: on the HBM-bound conv layers the L2 drowned in partial-line requests.  Instead each wave parks its 64x64
+// fp32 sub-tile in LDS (two passes of 32 rows, 272-B padded rows) and re-reads it row-major, 8 consecutive columns per
+// lane: bias / residual / GELU'-operand loads and every store are 16-byte accesses, 8 rows x 128 contiguous bytes per
+// instruction.  All arithmetic stays fp32 (no extra rounding).
+constexpr int EPI_ROW = 272;             // 64 fp32 columns + 16 B pad
+constexpr int EPI_WAVE = 32 * EPI_ROW;   // 8704 B per wave per pass
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* f);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float* f) { ld4(p, f); ld4(p + 4, f + 4); }
+template <> __device__ __forceinline__ void ld8<bf16>(const bf16* p, float* f) { unpack16<bf16>(ld16(p), f); }
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* f);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float* f) { st4(p, f); st4(p + 4, f + 4); }
+template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float* f) { st16(p, pack16<bf16>(f)); }
+
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const f32x4 (&acc)[4][4], unsigned char* lds, int i0,
+                                                     int j0, int xi0, int yj0, int lane, int wave, int g) {
+  const GemmEpilogue& ep = p.ep;
+  unsigned char* my = lds + wave * EPI_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();  // main-loop LDS reads (h = 0) / previous pass (h = 1) are finished in every wave
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = it * 8 + (lane >> 3);
+      const int i = i0 + xi0 + 32 * h + rl;
+      const int j = j0 + yj0 + 8 * (lane & 7);
+      if (i >= p.M || j >= p.N) continue;
+      float v[8];
+      {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(my + rl * EPI_ROW + (lane & 7) * 32);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(my + rl * EPI_ROW + (lane & 7) * 32 + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = a[e] * ep.alpha;
+          v[4 + e] = b[e] * ep.alpha;
+        }
+      }
+      RowMap rm = map_row(i, p.c_rpb);
+      const long coff = (long)g * p.c_gstride + (long)rm.b * p.c_bstride + (long)rm.t * p.ldc + j;
+      if (ep.bias) {
+        const float* bp = ep.bias + (long)g * ep.bias_gstride + (ep.bias_mod > 0 ? (j % ep.bias_mod) : j);
+        float bv[8];
+        ld4(bp, bv);
+        ld4(bp + 4, bv + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+      }
+      if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + coff, v);
+      if (ep.act == FH_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      }
+      if (ep.drop.p > 0.f) {
+        const unsigned long long didx = ((unsigned long long)g * p.M + i) * (unsigned long long)p.N + j;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= drop_scale(ep.drop, didx + e);
+      }
+      if (ep.gelu_aux) {
+        float a[8];
+        ld8<T>(reinterpret_cast<const T*>(ep.gelu_aux) + coff, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(a[e]);
+      }
+      if (ep.residual) {
+        float rr[8];
+        ld8<T>(reinterpret_cast<const T*>(ep.residual) + coff, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+      }
+      if (ep.row_len && rm.t >= ep.row_len[rm.b]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      if (ep.out_f32)
+        st8<float>(reinterpret_cast<float*>(p.C) + coff, v);
+      else
+        st8<T>(reinterpret_cast<T*>(p.C) + coff, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ the kernel
 template <typename T, int XL, int YL>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
@@ -331,30 +422,46 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
     __syncthreads();
   }
 
-  gemm_epilogue<T>(p, acc, i0, j0, xi0, yj0, lane, g);
+  if (p.ep.atomic)
+    gemm_epilogue<T>(p, acc, i0, j0, xi0, yj0, lane, g);
+  else
+    gemm_epilogue_staged<T>(p, acc, lds, i0, j0, xi0, yj0, lane, wave, g);
 }
 
 // ------------------------------------------------------------------ bf16 main loop with direct-to-LDS loads (LDS-DMA)
 // global_load_lds_dwordx4 moves 16 B per lane straight into LDS (no VGPR staging, no ds_write pass): one wave
 // instruction fills 1 KiB of LINEAR LDS.  Tiles are therefore unpadded; bank conflicts are removed with an XOR swizzle
-// applied to the per-lane SOURCE address and, identically, to the fragment reads (guide rule 21).  Double-buffered:
-// tile t+1 streams in while tile t feeds the MFMAs; one barrier per K-tile.
+// applied to the per-lane SOURCE address and, identically, to the fragment reads (guide rule 21).
+// Pipeline: a ring of NST = 4 stages of BK = 32 (8 KiB per operand per stage, 64 KiB per block -> 2 blocks per CU).
+// Three K-tiles are in flight while one feeds the MFMAs; the only synchronisation per K-tile is a COUNTED
+// s_waitcnt vmcnt(8) (this wave's share of the oldest tile has landed) followed by one raw s_barrier (everyone's has,
+// and everyone is done reading the stage that is about to be refilled).  The student's GEMMs have short reductions
+// (K = 480): with one tile of prefetch every K-step exposed the full HBM/L2 latency.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+constexpr int DMA_BK = 32;
+constexpr int DMA_NST = 4;
+constexpr int DMA_STAGE = 16384;  // X tile 8 KiB + Y tile 8 KiB
+
 __device__ __forceinline__ int strided_key(int kl) { return ((kl & 3) << 1) | (((kl >> 3) & 1) << 3); }
 
+// Loaders keep one running 64-bit source pointer per wave instruction.  Full K-tiles inside a segment take the FAST path
+// (pointer += per-lane step, no bounds logic, no branches: a lane whose row/column is out of range points at the zero
+// chunk with step 0).  The first tile of a segment and a partial last tile take the SLOW path that re-derives pointers.
 template <int LAYOUT> struct DmaLoader;
 
-template <> struct DmaLoader<FH_R_CONTIG> {  // LDS tile [128 rows][128 B]; 16-B chunk c of row R stored at chunk c ^ ((R>>1)&7)
+template <> struct DmaLoader<FH_R_CONTIG> {  // LDS tile [128 rows][64 B]; 16-B chunk c of row R stored at chunk c ^ ((R>>2)&3)
   const bf16* base;
-  long off[4];
+  long off[2];
   long segdelta;
   unsigned vmask;
-  int kch[4];  // logical k-chunk (8 elements) this lane fetches for its i-th wave instruction
+  int kch[2];  // logical k-chunk (8 elements) this lane fetches for its u-th wave instruction
   int wave;
+  const unsigned char* ptr[2];
+  int step[2];
   __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid) {
     base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
     wave = tid >> 6;
@@ -362,9 +469,9 @@ template <> struct DmaLoader<FH_R_CONTIG> {  // LDS tile [128 rows][128 B]; 16-B
     vmask = 0;
     segdelta = (long)(o.tshift[1] - o.tshift[0]) * o.ld + (o.segoff[1] - o.segoff[0]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = wave * 32 + u * 8 + (lane >> 3);
-      kch[u] = (lane & 7) ^ ((row >> 1) & 7);
+    for (int u = 0; u < 2; ++u) {
+      const int row = (wave * 2 + u) * 16 + (lane >> 2);
+      kch[u] = (lane & 3) ^ ((row >> 2) & 3);
       const int idx = idx0 + row;
       const bool rv = idx < idx_limit;
       RowMap rm = map_row(rv ? idx : 0, o.rpb);
@@ -377,59 +484,91 @@ template <> struct DmaLoader<FH_R_CONTIG> {  // LDS tile [128 rows][128 B]; 16-B
       }
     }
   }
-  __device__ __forceinline__ void issue(const GemmOperand& o, int seg, int k0, int Kseg, unsigned char* tile) {
+  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {  // slow path
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int k = k0 + kch[u] * 8;
       const bool v = (k < Kseg) && ((vmask >> (2 * u + seg)) & 1u);
-      const void* src = v ? (const void*)(base + off[u] + (long)seg * segdelta + k) : (const void*)g_zero_chunk;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + (wave * 4 + u) * 1024), 16, 0, 0);
+      ptr[u] = v ? (const unsigned char*)(base + off[u] + (long)seg * segdelta + k) : (const unsigned char*)g_zero_chunk;
+      step[u] = v ? DMA_BK * 2 : 0;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * 2 + u) * 1024), 16, 0, 0);
+      ptr[u] += step[u];
     }
   }
 };
 
-template <> struct DmaLoader<FH_R_STRIDED> {  // LDS tile [64 k][256 B]; chunk c of k-row kl stored at chunk c ^ strided_key(kl)
+template <> struct DmaLoader<FH_R_STRIDED> {  // LDS tile [32 k][256 B]; chunk c of k-row kl stored at chunk c ^ strided_key(kl)
   const bf16* base;
-  int col[4];
-  int kl[4];
+  int col[2];
+  int kl[2];
   unsigned cvalid;
   int wave;
+  const unsigned char* ptr[2];
+  int tcur[2];
+  long step;   // bytes per tile (32 reduction rows)
+  long wrap;   // extra bytes when the mapped row index crosses a batch item
+  int rpb;
   __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid) {
     base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
     wave = tid >> 6;
     const int lane = tid & 63;
     cvalid = 0;
+    rpb = o.rpb;
+    step = (long)DMA_BK * o.ld * 2;
+    wrap = (o.bstride - (long)o.rpb * o.ld) * 2;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      kl[u] = (wave * 4 + u) * 4 + (lane >> 4);
+    for (int u = 0; u < 2; ++u) {
+      kl[u] = (wave * 2 + u) * 4 + (lane >> 4);
       const int c = (lane & 15) ^ strided_key(kl[u]);
       col[u] = idx0 + c * 8;
       cvalid |= (col[u] < idx_limit ? 1u : 0u) << u;
     }
   }
-  __device__ __forceinline__ void issue(const GemmOperand& o, int seg, int k0, int Kseg, unsigned char* tile) {
+  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {  // slow path
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int r = k0 + kl[u];
-      const void* src = (const void*)g_zero_chunk;
+      ptr[u] = (const unsigned char*)g_zero_chunk;
+      tcur[u] = -1;  // < 0: this lane stays on the zero chunk
       if (((cvalid >> u) & 1u) && r < Kseg) {
         RowMap rm = map_row(r, o.rpb);
-        src = base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col[u];
+        ptr[u] = (const unsigned char*)(base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col[u]);
+        tcur[u] = rm.t;
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + (wave * 4 + u) * 1024), 16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * 2 + u) * 1024), 16, 0, 0);
+      if (tcur[u] >= 0) {
+        ptr[u] += step;
+        if (rpb > 0) {
+          tcur[u] += DMA_BK;
+          if (tcur[u] >= rpb) {  // requires rpb >= DMA_BK (checked on the host)
+            tcur[u] -= rpb;
+            ptr[u] += wrap;
+          }
+        }
+      }
     }
   }
 };
 
-template <int LAYOUT> __device__ __forceinline__ bf16x8 frag_dma(const unsigned char* lds, int row0, int ks, int lane);
-template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_CONTIG>(const unsigned char* lds, int row0, int ks, int lane) {
+template <int LAYOUT> __device__ __forceinline__ bf16x8 frag_dma(const unsigned char* lds, int row0, int lane);
+template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_CONTIG>(const unsigned char* lds, int row0, int lane) {
   const int R = row0 + (lane & 15);
-  const int phys = (ks * 4 + (lane >> 4)) ^ ((R >> 1) & 7);
-  return *reinterpret_cast<const bf16x8*>(lds + R * 128 + phys * 16);
+  const int phys = (lane >> 4) ^ ((R >> 2) & 3);
+  return *reinterpret_cast<const bf16x8*>(lds + R * 64 + phys * 16);
 }
-template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_STRIDED>(const unsigned char* lds, int row0, int ks, int lane) {
+template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_STRIDED>(const unsigned char* lds, int row0, int lane) {
   const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
-  const int kl = ks * 32 + 8 * q + qq;
+  const int kl = 8 * q + qq;
   const int phys = ((row0 >> 3) + (pp >> 1)) ^ strided_key(kl);
   const unsigned char* a0 = lds + kl * 256 + phys * 16 + 8 * (pp & 1);
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -444,19 +583,19 @@ template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_STRIDED>(const unsig
 
 template <int XL, int YL>
 __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
-  constexpr int BK = 64;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 buffers x (X tile 16 KiB + Y tile 16 KiB)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // DMA_NST stages x (X 8 KiB | Y 8 KiB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
   const int tiles_j = (p.N + BN - 1) / BN;
   const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
   const int i0 = ti * BM, j0 = tj * BN;
-  const int tiles_per_seg = (p.Kseg + BK - 1) / BK;
+  const int tiles_per_seg = (p.Kseg + DMA_BK - 1) / DMA_BK;
   const int ntiles = tiles_per_seg * p.X.nseg;
   const int per_split = (ntiles + p.splitk - 1) / p.splitk;
   const int t0 = blockIdx.y * per_split;
   const int t1 = min(ntiles, t0 + per_split);
   if (t0 >= t1) return;
+  const int nt = t1 - t0;
 
   DmaLoader<XL> lx;
   DmaLoader<YL> ly;
@@ -470,37 +609,70 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
     for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int xi0 = (wave & 1) * 64, yj0 = (wave >> 1) * 64;
 
-  {
-    const int seg = t0 / tiles_per_seg, k0 = (t0 - seg * tiles_per_seg) * BK;
-    lx.issue(p.X, seg, k0, p.Kseg, lds);
-    ly.issue(p.Y, seg, k0, p.Kseg, lds + 16384);
-  }
-  __syncthreads();
-  for (int t = t0; t < t1; ++t) {
-    const int cur = (t - t0) & 1;
-    unsigned char* bx = lds + cur * 32768;
-    unsigned char* by = bx + 16384;
-    if (t + 1 < t1) {
-      const int seg = (t + 1) / tiles_per_seg, k0 = (t + 1 - seg * tiles_per_seg) * BK;
-      lx.issue(p.X, seg, k0, p.Kseg, lds + (cur ^ 1) * 32768);
-      ly.issue(p.Y, seg, k0, p.Kseg, lds + (cur ^ 1) * 32768 + 16384);
+  // (seg, k0) of the next tile to issue, advanced incrementally (no division in the loop)
+  int is_seg = t0 / tiles_per_seg;
+  int is_k0 = (t0 - is_seg * tiles_per_seg) * DMA_BK;
+  int issued = 0;
+  bool need_slow = true;
+  auto issue_next = [&](int stage) {
+    unsigned char* st = lds + stage * DMA_STAGE;
+    if (issued >= nt) {  // pipeline drain: keep the vmcnt bookkeeping uniform with harmless zero-chunk loads
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        lx.ptr[u] = (const unsigned char*)g_zero_chunk;
+        ly.ptr[u] = (const unsigned char*)g_zero_chunk;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)lx.ptr[0], (lptr_t)(st + (wave * 2) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)lx.ptr[0], (lptr_t)(st + (wave * 2 + 1) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ly.ptr[0], (lptr_t)(st + 8192 + (wave * 2) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ly.ptr[0], (lptr_t)(st + 8192 + (wave * 2 + 1) * 1024), 16, 0, 0);
+      ++issued;
+      return;
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fx[4], fy[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) fx[m] = frag_dma<XL>(bx, xi0 + 16 * m, ks, lane);
-#pragma unroll
-      for (int n = 0; n < 4; ++n) fy[n] = frag_dma<YL>(by, yj0 + 16 * n, ks, lane);
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
+    const bool partial = is_k0 + DMA_BK > p.Kseg;
+    if (need_slow || partial) {
+      lx.set_tile(p.X, is_seg, is_k0, p.Kseg);
+      ly.set_tile(p.Y, is_seg, is_k0, p.Kseg);
     }
-    __syncthreads();
+    lx.issue(st);
+    ly.issue(st + 8192);
+    ++issued;
+    is_k0 += DMA_BK;
+    need_slow = false;
+    if (is_k0 >= p.Kseg) {
+      is_k0 = 0;
+      is_seg = min(is_seg + 1, 1);
+      need_slow = true;
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < DMA_NST - 1; ++s) issue_next(s);
+
+  int stage = 0;
+  for (int it = 0; it < nt; ++it) {
+    // this wave's 4 loads of tile `it` have landed (8 younger loads may still be in flight) ...
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    // ... and after the barrier so have everyone's; the stage read in iteration it-1 is free again: refill it
+    issue_next(stage == 0 ? DMA_NST - 1 : stage - 1);
+    const unsigned char* bx = lds + stage * DMA_STAGE;
+    const unsigned char* by = bx + 8192;
+    bf16x8 fx[4], fy[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fx[m] = frag_dma<XL>(bx, xi0 + 16 * m, lane);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) fy[n] = frag_dma<YL>(by, yj0 + 16 * n, lane);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
+    stage = stage == DMA_NST - 1 ? 0 : stage + 1;
   }
-  gemm_epilogue<bf16>(p, acc, i0, j0, xi0, yj0, lane, g);
+  if (p.ep.atomic) {
+    gemm_epilogue<bf16>(p, acc, i0, j0, xi0, yj0, lane, g);
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero-chunk) tail loads before LDS is reused
+    gemm_epilogue_staged<bf16>(p, acc, lds, i0, j0, xi0, yj0, lane, wave, g);
+  }
 }
 
 template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
@@ -522,7 +694,7 @@ template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
 int launch_dma(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM - 1) / BM, tiles_j = (p.N + BN - 1) / BN;
   dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(256);
-  const size_t smem = 65536;
+  const size_t smem = (size_t)DMA_NST * DMA_STAGE;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_dma_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -546,6 +718,11 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
 
 // FH_GEMM_PATH=dma selects the LDS-DMA main loop for bf16 (A/B comparisons; see tools/gemm_bench.py)
 int g_gemm_path = -1;  // -1: from env FH_GEMM_PATH; 0: register staging (default); 1: LDS-DMA
+bool dma_ok(const GemmParams& p) {
+  if (p.X.layout == FH_R_STRIDED && p.X.rpb > 0 && p.X.rpb < DMA_BK) return false;
+  if (p.Y.layout == FH_R_STRIDED && p.Y.rpb > 0 && p.Y.rpb < DMA_BK) return false;
+  return true;
+}
 bool use_dma() {
   if (g_gemm_path < 0) {
     const char* e = getenv("FH_GEMM_PATH");
@@ -594,17 +771,17 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   const int vec = dtype == 0 ? 4 : 8;
   if (p.M <= 0 || p.N <= 0 || p.Kseg <= 0) return 0;
   // vector-access preconditions (all hold for the student's shapes; fail loudly otherwise)
-  if (p.N % 4 != 0) return -101;
+  if (p.N % 4 != 0 || (!p.ep.atomic && p.N % 8 != 0)) return -101;
   if (p.X.layout == FH_R_CONTIG && (p.Kseg % vec || p.X.ld % vec || p.X.bstride % vec)) return -102;
   if (p.Y.layout == FH_R_CONTIG && (p.Kseg % vec || p.Y.ld % vec || p.Y.bstride % vec)) return -103;
   if (p.X.layout == FH_R_STRIDED && (p.M % vec || p.X.ld % vec || p.X.bstride % vec)) return -104;
   if (p.Y.layout == FH_R_STRIDED && (p.N % vec || p.Y.ld % vec || p.Y.bstride % vec)) return -105;
   if (p.X.nseg != p.Y.nseg || p.X.nseg < 1 || p.X.nseg > 2) return -106;
   if (p.splitk > 1 && !p.ep.atomic) return -107;
-  if (!p.ep.atomic && (p.ldc % 4 || p.c_bstride % 4 || p.c_gstride % 4)) return -108;
+  if (!p.ep.atomic && (p.ldc % 8 || p.c_bstride % 8 || p.c_gstride % 8)) return -108;
   if (p.ep.row_len && p.c_rpb <= 0) return -109;
   if ((p.X.segoff[0] | p.X.segoff[1] | p.Y.segoff[0] | p.Y.segoff[1] | p.X.gstride | p.Y.gstride) % vec) return -110;
-  if (!g_prof_on) return dtype == 0 ? launch_t<float>(p, stream) : (use_dma() ? launch_dma(p, stream) : launch_t<bf16>(p, stream));
+  if (!g_prof_on) return dtype == 0 ? launch_t<float>(p, stream) : (use_dma() && dma_ok(p) ? launch_dma(p, stream) : launch_t<bf16>(p, stream));
   ProfRec r;
   if (!g_pool.empty()) {
     r.a = g_pool.back().first; r.b = g_pool.back().second;
@@ -615,7 +792,7 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   r.flops = 2.0 * p.M * p.N * (double)p.Kseg * p.X.nseg * p.groups;
   r.variant = (dtype ? 4 : 0) + p.X.layout * 2 + p.Y.layout;
   hipEventRecord(r.a, stream);
-  const int rc = dtype == 0 ? launch_t<float>(p, stream) : (use_dma() ? launch_dma(p, stream) : launch_t<bf16>(p, stream));
+  const int rc = dtype == 0 ? launch_t<float>(p, stream) : (use_dma() && dma_ok(p) ? launch_dma(p, stream) : launch_t<bf16>(p, stream));
   hipEventRecord(r.b, stream);
   g_prof.push_back(r);
   return rc;

@@ -25,15 +25,23 @@ template <typename T> struct PC {
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // ---------------------------------------------------------------- weight norm forward + re-layout
-__global__ void wn_norm2_kernel(const float* __restrict__ v, float* __restrict__ norm2, int rows, int K) {
-  const int j = threadIdx.x;
-  if (j >= K) return;
+// ||v||^2 per tap, deterministic: one block per tap, fixed-order tree reduction (no float atomics, so two prepares of
+// the same weights give bit-identical kernel weights)
+__global__ void __launch_bounds__(256) wn_norm2_kernel(const float* __restrict__ v, float* __restrict__ norm2, int rows, int K) {
+  __shared__ float red[256];
+  const int j = blockIdx.x;
   float s = 0.f;
-  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+  for (int r = threadIdx.x; r < rows; r += 256) {
     const float x = v[(long)r * K + j];
     s = fmaf(x, x, s);
   }
-  atomicAdd(norm2 + j, s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) norm2[j] = red[0];
 }
 
 // w_fwd[g][j][co][ci] = w[g*cg+co][ci][j] ; w_bwd[g][j'][ci][co] = w[g*cg+co][ci][K-1-j']  (zero padded to CP)
@@ -350,8 +358,7 @@ int fh_posconv_prep_launch(int dtype, const float* g, const float* v, void* w_fw
   if (cg > CP || cg % 2 || K > 1024 || K % 32) return -501;
   // norm doubles as the ||v||^2 accumulator: [0, K) = norm, [K, 2K) = norm2 scratch
   float* norm2 = norm + K;
-  hipMemsetAsync(norm2, 0, sizeof(float) * K, st);
-  hipLaunchKernelGGL(wn_norm2_kernel, dim3(64), dim3(K), 0, st, v, norm2, D * cg, K);
+  hipLaunchKernelGGL(wn_norm2_kernel, dim3(K), dim3(256), 0, st, v, norm2, D * cg, K);
   FH_CHECK_LAUNCH();
   const long n = (long)groups * K * CP * CP;
   if (dtype == 0)

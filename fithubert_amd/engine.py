@@ -6,6 +6,7 @@ the student runs in libfithubert_hip.so; if the library or a GPU is missing this
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -199,6 +200,8 @@ class StudentEngine:
         if nbytes <= 0:
             raise RuntimeError(f"fh_student_ws_bytes failed ({nbytes}) for B={B}, S={S}")
         buf = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+        if os.environ.get("FH_POISON_WS"):  # debugging aid: any read of never-written workspace shows up as NaN
+            buf.fill_(0xFF)
         ws = Workspace(self, call, buf)
         ws.lens = None
         if sample_lengths is not None:

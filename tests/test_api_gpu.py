@@ -132,4 +132,6 @@ def test_distill_task_trains_and_checkpoints_roundtrip(tmp_path):
     src = torch.stack([wavs[0], torch.cat([wavs[1], torch.zeros(4000, device=DEV)])])
     with torch.no_grad():
         ref = task.student_model(src, pm)
-    assert _rel_l2(res["last_hidden_state"], ref["projections"][-1].float()) < 1e-6
+    err = _rel_l2(res["last_hidden_state"], ref["projections"][-1].float())
+    errs = [_rel_l2(res["hidden_states"][i][0], ref["layer_results"][i][0].float()) for i in range(3)]
+    assert err < 1e-6, (err, errs)

@@ -194,3 +194,22 @@ def test_training_mode_dropout_is_reproducible_and_unbiased():
     assert torch.equal(a, b)
     assert not torch.equal(a, c)
     assert _rel_l2(a.float(), e.float()) < 1.0  # same signal, perturbed
+
+
+def test_forward_is_bitwise_deterministic_across_engines_and_calls():
+    """Inference must not depend on float-atomic arrival order or on stale workspace bytes: two engines prepared from
+    the same weights, repeated calls and both head modes agree bit for bit (the weight-norm preparation once used float
+    atomics and flipped bf16 roundings between instances)."""
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=3)
+    engs = [_engine(cfg, 1, "bf16")[0] for _ in range(2)]
+    wav = 0.1 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(0)).to(DEV)
+    wav[1, 12000:] = 0
+    ref = None
+    for it in range(8):
+        ws = engs[it % 2].forward(wav, [16000, 12000], training=False, heads_on=bool(it % 3))
+        cur = [ws.view(n).clone() for n in ("zc", "xo", "f2")] + [ws.view("pred")[-1].clone()]
+        if ref is None:
+            ref = cur
+        for a, b in zip(cur, ref):
+            assert torch.equal(a, b), it
