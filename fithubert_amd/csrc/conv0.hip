@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256) conv0_stats_kernel(Conv0Args a, float2* p
     for (int j = 0; j < MAXK; ++j) w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
     const float pivot = conv_at(sw, w, 0, a.K, a.stride);
     float s = 0.f, ss = 0.f;
+#pragma unroll 4
     for (int t = tl; t < nt; t += nlan) {
       const float d = conv_at(sw, w, t, a.K, a.stride) - pivot;
       s += d;
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
     const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
     const float sc = rs * a.gamma[c], sh = a.beta[c] - mu * rs * a.gamma[c];
     T* yp = y + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
+#pragma unroll 4
     for (int t = tl; t < nt; t += nlan) {
       const float v = conv_at(sw, w, t, a.K, a.stride);
       yp[(long)t * a.C0] = from_f<T>(gelu_f(fmaf(v, sc, sh)));
@@ -150,6 +152,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_reduce_kernel(Conv0Args a, cons
     const float ga = a.gamma[c], be = a.beta[c];
     const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
     for (int t = tl; t < nt; t += nlan) {
       const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
       const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
@@ -214,7 +217,8 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
       __syncthreads();
       const int nt = stage_wave(a, b, chunk, sw);
       const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
-      for (int t = tl; t < nt; t += nlan) {
+  #pragma unroll 4
+    for (int t = tl; t < nt; t += nlan) {
         const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
         const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
         const float dv = rs * (g * ga - abv.x - xh * abv.y);

@@ -127,8 +127,18 @@ template <typename T> struct Loader<T, FH_R_STRIDED> {
 // bf16: 8 k-values per lane per k32-step, k = ks*32 + 8*(lane>>4) + e
 template <int LAYOUT> __device__ __forceinline__ bf16x8 frag_bf16(const unsigned char* lds, int row0, int ks, int lane);
 template <> __device__ __forceinline__ bf16x8 frag_bf16<FH_R_CONTIG>(const unsigned char* lds, int row0, int ks, int lane) {
-  const unsigned char* a = lds + (row0 + (lane & 15)) * LDS_C_STRIDE + ks * 64 + (lane >> 4) * 16;
-  return *reinterpret_cast<const bf16x8*>(a);
+  // k-order inside a k32 step (shared by both layouts, any order works as long as X and Y agree):
+  //   fragment element e < 4 -> k = 4q + e ; e >= 4 -> k = 16 + 4q + (e - 4).
+  // With this order the transposing reads of an R_STRIDED tile touch rows {4q+qq} and {16+4q+qq}: the two 16-lane
+  // groups of a half-wave read 8 DIFFERENT consecutive rows -> conflict-free (rows 8 apart alias to the same banks).
+  const unsigned char* a = lds + (row0 + (lane & 15)) * LDS_C_STRIDE + ks * 64 + (lane >> 4) * 8;
+  union {
+    struct { uint2 lo, hi; } s;
+    bf16x8 v;
+  } u;
+  u.s.lo = *reinterpret_cast<const uint2*>(a);
+  u.s.hi = *reinterpret_cast<const uint2*>(a + 32);
+  return u.v;
 }
 template <> __device__ __forceinline__ bf16x8 frag_bf16<FH_R_STRIDED>(const unsigned char* lds, int row0, int ks, int lane) {
   // ds_read_b64_tr_b16: within a 16-lane group, lane 4*qq+p supplies the address of row qq, columns 4p..4p+3
@@ -136,8 +146,8 @@ template <> __device__ __forceinline__ bf16x8 frag_bf16<FH_R_STRIDED>(const unsi
   constexpr int STRIDE = StridedCfg<bf16>::STRIDE;
   const int i = lane & 15, q = lane >> 4;
   const int qq = i >> 2, pp = i & 3;
-  const unsigned char* a0 = lds + (ks * 32 + 8 * q + qq) * STRIDE + (row0 + 4 * pp) * 2;
-  const unsigned char* a1 = a0 + 4 * STRIDE;
+  const unsigned char* a0 = lds + (ks * 32 + 4 * q + qq) * STRIDE + (row0 + 4 * pp) * 2;
+  const unsigned char* a1 = a0 + 16 * STRIDE;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);

@@ -12,6 +12,8 @@
 
 namespace {
 
+constexpr int LN_RPW = 4;  // rows per wave, loaded together (4x the bytes in flight of a row-at-a-time loop)
+
 template <typename T, int NCH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -19,51 +21,77 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
                                                      int C, float eps, DropCfg drop) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+  if (row0 >= M) return;
   const int nchunk = C / VEC;
-  const T* xr = x + (long)row * C;
-  float v[NCH][VEC];
-  float s = 0.f;
+  float v[LN_RPW][NCH][VEC];
+#pragma unroll
+  for (int rr = 0; rr < LN_RPW; ++rr) {
+    const int row = min(row0 + rr, M - 1);
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunk) unpack16<T>(ld16(x + (long)row * C + ch * VEC), v[rr][u]);
+    }
+  }
+  float gm[NCH][VEC], bt[NCH][VEC];
 #pragma unroll
   for (int u = 0; u < NCH; ++u) {
     const int ch = lane + 64 * u;
     if (ch < nchunk) {
-      unpack16<T>(ld16(xr + ch * VEC), v[u]);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) s += v[u][e];
-    }
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float ss = 0.f;
-#pragma unroll
-  for (int u = 0; u < NCH; ++u) {
-    if (lane + 64 * u < nchunk) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float d = v[u][e] - mean;
-        ss = fmaf(d, d, ss);
+      for (int e = 0; e < VEC; e += 4) {
+        ld4(gamma + ch * VEC + e, gm[u] + e);
+        ld4(beta + ch * VEC + e, bt[u] + e);
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
-  if (lane == 0) {
-    if (mean_out) mean_out[row] = mean;
-    if (rstd_out) rstd_out[row] = rstd;
-  }
-  T* yr = y + (long)row * C;
+  float mean[LN_RPW], rstd[LN_RPW];
 #pragma unroll
-  for (int u = 0; u < NCH; ++u) {
-    const int ch = lane + 64 * u;
-    if (ch < nchunk) {
-      float o[VEC];
+  for (int rr = 0; rr < LN_RPW; ++rr) {
+    float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const int c = ch * VEC + e;
-        o[e] = fmaf((v[u][e] - mean) * rstd, gamma[c], beta[c]);
-        if (drop.p > 0.f) o[e] *= drop_scale(drop, (unsigned long long)row * C + c);
+    for (int u = 0; u < NCH; ++u)
+      if (lane + 64 * u < nchunk) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[rr][u][e];
       }
-      st16(yr + ch * VEC, pack16<T>(o));
+    mean[rr] = wave_sum(s) / (float)C;
+  }
+#pragma unroll
+  for (int rr = 0; rr < LN_RPW; ++rr) {
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u)
+      if (lane + 64 * u < nchunk) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = v[rr][u][e] - mean[rr];
+          ss = fmaf(d, d, ss);
+        }
+      }
+    rstd[rr] = rsqrtf(wave_sum(ss) / (float)C + eps);
+  }
+#pragma unroll
+  for (int rr = 0; rr < LN_RPW; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean[rr];
+      if (rstd_out) rstd_out[row] = rstd[rr];
+    }
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunk) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          o[e] = fmaf((v[rr][u][e] - mean[rr]) * rstd[rr], gm[u][e], bt[u][e]);
+          if (drop.p > 0.f) o[e] *= drop_scale(drop, (unsigned long long)row * C + ch * VEC + e);
+        }
+        st16(y + (long)row * C + ch * VEC, pack16<T>(o));
+      }
     }
   }
 }
@@ -94,6 +122,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
   }
   const int r0 = wave_global * rows_per_wave;
   const int r1 = min(M, r0 + rows_per_wave);
+#pragma unroll 2
   for (int row = r0; row < r1; ++row) {
     const float mean = mean_in[row], rstd = rstd_in[row];
     float g[NCH][VEC], xh[NCH][VEC];
@@ -214,7 +243,7 @@ int ln_fwd_t(const T* x, const float* g, const float* b, T* y, float* mean, floa
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return -301;
   const int nch = (C / VEC + 63) / 64;
-  dim3 grid((M + 3) / 4), block(256);
+  dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
   if (nch == 1)
     hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop);
   else if (nch == 2)
@@ -233,7 +262,7 @@ int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const flo
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return -301;
   const int nch = (C / VEC + 63) / 64;
-  const int rpw = 32;  // 128 rows per block
+  const int rpw = 8;  // 32 rows per block: enough waves in flight to hide the load -> shuffle-reduce -> store chain
   const int waves = (M + rpw - 1) / rpw;
   dim3 grid((waves + 3) / 4), block(256);
   const size_t smem = (size_t)8 * C * sizeof(float);
