@@ -62,10 +62,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("FH_BENCH_BATCH", "16")), help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FH_BENCH_BATCH", "64")), help="utterances per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "float32"])
     ap.add_argument("--config", default=os.path.join(ROOT, "conf", "fithubert.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--teacher-frontend", default="native", choices=["native", "torch"],
+                    help="frozen teacher's conv frontend + positional conv: the student's HIP kernels (native) or stock "
+                         "PyTorch-ROCm ops (torch); its transformer layers always run on PyTorch-ROCm")
     ap.add_argument("--prof-steps", type=int, default=3, help="timed steps (the last ones) with per-launch HIP-event GEMM timing")
     args = ap.parse_args()
 
@@ -87,7 +90,7 @@ def main():
     with open(args.config) as f:
         cfg = yaml.load(f, Loader=yaml.FullLoader)
     cfg["train"]["accumulate_grad_batches"] = 1  # one optimizer step (and one all-reduce) per timed step
-    task = W2V2Distil(cfg, dtype=args.dtype, device=dev, seed=0)
+    task = W2V2Distil(cfg, dtype=args.dtype, device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native")
     total_steps = args.steps + args.warmup
     task.configure_optimizers(num_training_steps=max(total_steps, 100))
 
@@ -156,7 +159,8 @@ def main():
             "config": {"workload": "fithubert.yaml student (480-dim, 12 layers) + HuBERT-Base-shaped teacher (random init), "
                                    "full distillation step on fixed 10 s clips (BASELINE.json configs[1])",
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": SAMPLES_10S, "parallelism": f"dp{world}",
-                       "teacher": "PyTorch-ROCm bf16", "optimizer": "fused AdamW every step"},
+                       "teacher": "bf16; transformer on PyTorch-ROCm (rocBLAS/hipBLASLt + SDPA); conv frontend + pos-conv: " +
+                                  ("HIP kernels shared with the student" if args.teacher_frontend == "native" else "PyTorch-ROCm (MIOpen)"), "optimizer": "fused AdamW every step"},
             "step_tflops": round(value * GF_STEP / 1e3, 1),
             "step_frac_of_mfma_peak": round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
             "final_loss": loss,

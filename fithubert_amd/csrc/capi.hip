@@ -98,4 +98,20 @@ int fh_adamw(float* p, const float* g, float* m, float* v, long n, float lr, flo
   return fh_adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale, decay_mask, ST(stream));
 }
 
+int fh_conv1d_forward(int dtype, const void* x, const void* wf, const float* bias, void* y, int B, int T, int Cin, int Cout,
+                      int k, int stride, int gelu, fh_stream_t stream) {
+  if (T < k) return -561;
+  const int Tout = (T - k) / stride + 1;
+  GemmParams g = fh_gemm_params();
+  g.X = fh_operand(x, FH_R_CONTIG, (long)stride * Cin);
+  g.X.rpb = Tout;
+  g.X.bstride = (long)T * Cin;
+  g.Y = fh_operand(wf, FH_R_CONTIG, (long)k * Cin);
+  g.C = y;
+  g.M = B * Tout; g.N = Cout; g.Kseg = k * Cin; g.ldc = Cout;
+  g.ep.bias = bias;
+  g.ep.act = gelu ? FH_ACT_GELU : FH_ACT_NONE;
+  return fh_gemm_launch(g, dtype, ST(stream));
+}
+
 }  // extern "C"

@@ -1,0 +1,184 @@
+// Forward-only positional conv for wide groups (up to 64 channels per group): the frozen teacher's
+// Conv1d(768, 768, k=128, pad=64, groups=16) + SamePad + GELU + residual (fairseq HubertModel.encoder.pos_conv, used by
+// the reference through utils/utils.py:84-88).  Same scheme as posconv.hip (window staged once in LDS, one tap = one
+// MFMA K-slab over the group's input channels, weights streamed from L2) with the channel padding at 64.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int CPW = 64;
+constexpr int TTW = 128;
+
+template <typename T> struct PW { static constexpr int RS = CPW * (int)sizeof(T) + 16; };
+
+__global__ void __launch_bounds__(256) wnw_norm2_kernel(const float* __restrict__ v, float* __restrict__ norm2, int rows, int K) {
+  __shared__ float red[256];
+  const int j = blockIdx.x;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float x = v[(long)r * K + j];
+    s = fmaf(x, x, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) norm2[j] = red[0];
+}
+
+template <typename T>
+__global__ void wnw_layout_kernel(const float* __restrict__ gsc, const float* __restrict__ v, const float* __restrict__ norm2,
+                                  T* __restrict__ w_fwd, int G, int cg, int K) {
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)G * K * CPW * CPW;
+  if (o >= n) return;
+  const int ci = (int)(o % CPW), co = (int)((o / CPW) % CPW);
+  const int j = (int)((o / (CPW * CPW)) % K), g = (int)(o / ((long)CPW * CPW * K));
+  float w = 0.f;
+  if (co < cg && ci < cg) w = gsc[j] * v[((long)(g * cg + co) * cg + ci) * K + j] * rsqrtf(norm2[j]);
+  w_fwd[o] = from_f<T>(w);
+}
+
+__device__ __forceinline__ void ld2w(const float* p, float* f) {
+  float2 v = *reinterpret_cast<const float2*>(p);
+  f[0] = v.x; f[1] = v.y;
+}
+__device__ __forceinline__ void ld2w(const bf16* p, float* f) {
+  uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+  f[0] = __uint_as_float(v << 16);
+  f[1] = __uint_as_float(v & 0xffff0000u);
+}
+__device__ __forceinline__ void st2w(float* p, const float* f) { *reinterpret_cast<float2*>(p) = make_float2(f[0], f[1]); }
+__device__ __forceinline__ void st2w(bf16* p, const float* f) {
+  *reinterpret_cast<uint32_t*>(p) = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ y, int B, int Tn,
+                                                           int D, int cg, int K, int pad_left) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RS = PW<T>::RS;
+  constexpr bool IS_BF = sizeof(T) == 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int t0 = blockIdx.x * TTW, g = blockIdx.y, b = blockIdx.z;
+  const int nrows = TTW + K - 1;
+  const int units = CPW / 2;
+  for (int idx = threadIdx.x; idx < nrows * units; idx += blockDim.x) {
+    const int row = idx / units, u = idx - row * units;
+    const int t = t0 - pad_left + row;
+    float f[2] = {0.f, 0.f};
+    if (t >= 0 && t < Tn && 2 * u + 1 < cg) ld2w(x + ((long)b * Tn + t) * D + g * cg + 2 * u, f);
+    st2w(reinterpret_cast<T*>(lds + row * RS) + 2 * u, f);
+  }
+  __syncthreads();
+  const int ncb = (cg + 15) / 16;  // output-channel blocks that hold real channels
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) acc[cb][0] = acc[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const T* wg = w + (long)g * K * CPW * CPW;
+#pragma unroll 2
+  for (int j = 0; j < K; ++j) {
+    const T* wj = wg + (long)j * CPW * CPW;
+    if constexpr (IS_BF) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xf[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          xf[tt] = *reinterpret_cast<const bf16x8*>(lds + (wave * 32 + tt * 16 + r + j) * RS + ks * 64 + q * 16);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          if (cb < ncb) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wj + (long)(cb * 16 + r) * CPW + ks * 32 + q * 8);
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[0], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[1], acc[cb][1], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kr = 0; kr < 4; ++kr) {
+        f32x4 xf[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          xf[tt] = *reinterpret_cast<const f32x4*>(lds + (wave * 32 + tt * 16 + r + j) * RS + kr * 64 + q * 16);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          if (cb < ncb) {
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(wj + (long)(cb * 16 + r) * CPW + kr * 16 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xf[0][e], acc[cb][0], 0, 0, 0);
+              acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xf[1][e], acc[cb][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int tl = wave * 32 + tt * 16 + r;
+    const int t = t0 + tl;
+    if (t >= Tn) continue;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int co = cb * 16 + q * 4 + 2 * h;
+        if (co >= cg) continue;
+        const long off = ((long)b * Tn + t) * D + g * cg + co;
+        float v[2] = {acc[cb][tt][2 * h] + bias[g * cg + co], acc[cb][tt][2 * h + 1] + bias[g * cg + co + 1]};
+        float xv[2];
+        ld2w(reinterpret_cast<const T*>(lds + (tl + pad_left) * RS) + co, xv);
+        v[0] = xv[0] + gelu_f(v[0]);
+        v[1] = xv[1] + gelu_f(v[1]);
+        st2w(y + off, v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int fh_posconv_wide_prepare(int dtype, const float* g, const float* v, void* w_fwd, float* norm2, int D, int groups,
+                                       int K, fh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = D / groups;
+  if (cg > CPW || cg % 2 || K > 1024) return -551;
+  hipLaunchKernelGGL(wnw_norm2_kernel, dim3(K), dim3(256), 0, st, v, norm2, D * cg, K);
+  FH_CHECK_LAUNCH();
+  const long n = (long)groups * K * CPW * CPW;
+  if (dtype == 0)
+    hipLaunchKernelGGL(wnw_layout_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2, (float*)w_fwd,
+                       groups, cg, K);
+  else
+    hipLaunchKernelGGL(wnw_layout_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2, (bf16*)w_fwd,
+                       groups, cg, K);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fh_posconv_wide_forward(int dtype, const void* x, const void* w_fwd, const float* bias, void* y, int B, int T, int D,
+                                       int groups, int K, fh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int cg = D / groups;
+  if (cg > CPW || cg % 2 || K % 2) return -551;
+  dim3 grid((T + TTW - 1) / TTW, groups, B), block(256);
+  if (dtype == 0) {
+    const size_t smem = (size_t)(TTW + K - 1) * PW<float>::RS;
+    hipFuncSetAttribute((const void*)posconv_wide_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(posconv_wide_kernel<float>, grid, block, smem, st, (const float*)x, (const float*)w_fwd, bias, (float*)y, B,
+                       T, D, cg, K, K / 2);
+  } else {
+    const size_t smem = (size_t)(TTW + K - 1) * PW<bf16>::RS;
+    hipLaunchKernelGGL(posconv_wide_kernel<bf16>, grid, block, smem, st, (const bf16*)x, (const bf16*)w_fwd, bias, (bf16*)y, B, T, D,
+                       cg, K, K / 2);
+  }
+  FH_CHECK_LAUNCH();
+  return 0;
+}

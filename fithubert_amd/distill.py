@@ -29,7 +29,8 @@ from .teacher import TeacherConfig, TeacherWrapper, build_teacher, freeze_model
 
 class W2V2Distil:
     def __init__(self, cfg: dict, dtype: str = "bf16", device: str = "cuda", teacher: Optional[TeacherWrapper] = None,
-                 teacher_cfg: Optional[TeacherConfig] = None, seed: int = 0, teacher_dtype=torch.bfloat16):
+                 teacher_cfg: Optional[TeacherConfig] = None, seed: int = 0, teacher_dtype=torch.bfloat16,
+                 teacher_native_frontend: bool = False):
         self.yaml_cfg = cfg
         self.train_cfg = cfg["train"]
         self.device = torch.device(device)
@@ -37,7 +38,7 @@ class W2V2Distil:
         if teacher is None:
             name = str(cfg.get("teacher", {}).get("teacher_model", "hubert"))
             tcfg = teacher_cfg or TeacherConfig.base("wav2vec2" if "wav2vec" in name or "w2v" in name else "hubert")
-            teacher = build_teacher(tcfg, seed=seed + 1, dtype=teacher_dtype, device=device)
+            teacher = build_teacher(tcfg, seed=seed + 1, dtype=teacher_dtype, device=device, native_frontend=teacher_native_frontend)
         self.teacher_model = teacher
         freeze_model(self.teacher_model)
         self.task_agnostic = True

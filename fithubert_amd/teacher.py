@@ -152,6 +152,91 @@ class _FeatureExtractor(nn.Module):
         return x
 
 
+class _NativeFrontend:
+    """The frozen teacher's conv frontend and positional conv on the student's HIP kernels:
+    conv0+GroupNorm+GELU fused (fh_conv0_forward), conv layers as channels-last MFMA GEMMs with a GELU epilogue
+    (fh_conv1d_forward), weight-normed grouped positional conv (fh_posconv_wide_forward).  Weights are prepared ONCE
+    (the teacher is frozen).  The transformer layers stay on PyTorch-ROCm."""
+
+    def __init__(self, model: "TeacherModel"):
+        from . import _lib as L
+        self.L, self.lib = L, L.lib()
+        p0 = model.post_extract_proj.weight
+        self.dev, self.tdt = p0.device, p0.dtype
+        if self.tdt not in (torch.bfloat16, torch.float32):
+            raise NotImplementedError("native teacher frontend: bf16 or fp32 only")
+        self.dt = L.DT_BF16 if self.tdt == torch.bfloat16 else L.DT_F32
+        fe = model.feature_extractor
+        self.spec = fe.spec
+        self.mode = fe.mode
+        self.layers = []
+        for i, (dim, k, s) in enumerate(self.spec):
+            conv = getattr(fe.conv_layers[i], "0")
+            w = conv.weight.detach()
+            b = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+            if i == 0:
+                self.w0 = w.float().reshape(dim, k).contiguous()
+                self.b0 = b
+                if self.mode == "default":
+                    gn = getattr(fe.conv_layers[0], "2")
+                    self.g0, self.be0 = gn.weight.detach().float().contiguous(), gn.bias.detach().float().contiguous()
+            else:
+                self.layers.append((w.permute(0, 2, 1).contiguous().to(self.tdt), b))  # [Cout][k][Cin]
+        pc = model.encoder.pos_conv[0]
+        D = pc.weight_v.shape[0]
+        self.D, self.G, self.K = D, pc.groups, pc.weight_v.shape[2]
+        self.pos_bias = pc.bias.detach().float().contiguous()
+        self.pos_w = torch.empty(self.G * self.K * 64 * 64, device=self.dev, dtype=self.tdt)
+        norm2 = torch.empty(self.K, device=self.dev, dtype=torch.float32)
+        L.check(self.lib.fh_posconv_wide_prepare(self.dt, pc.weight_g.detach().float().contiguous().data_ptr(),
+                                                 pc.weight_v.detach().float().contiguous().data_ptr(), self.pos_w.data_ptr(),
+                                                 norm2.data_ptr(), D, self.G, self.K, self._st()), "fh_posconv_wide_prepare")
+
+    def _st(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def features(self, model: "TeacherModel", wav: torch.Tensor) -> torch.Tensor:
+        """B x S fp32 waveform -> B x T' x C (teacher dtype), channels-last."""
+        L, lib = self.L, self.lib
+        wav = wav.float().contiguous()
+        B, S = wav.shape
+        dim0, k0, s0 = self.spec[0]
+        T = (S - k0) // s0 + 1
+        if self.mode == "default":
+            y = torch.empty(B, T, dim0, device=self.dev, dtype=self.tdt)
+            mean = torch.empty(B, dim0, device=self.dev, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            scratch = torch.empty(lib.fh_conv0_scratch_floats(B, S, dim0, k0, s0), device=self.dev, dtype=torch.float32)
+            L.check(lib.fh_conv0_forward(self.dt, wav.data_ptr(), self.w0.data_ptr(), self.g0.data_ptr(), self.be0.data_ptr(),
+                                         y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(), B, S, dim0, k0, s0,
+                                         1e-5, self._st()), "fh_conv0_forward")
+        else:  # layer_norm mode: conv (Cin = 1) -> LayerNorm over channels -> GELU (HuBERT-Large)
+            y = F.linear(wav.to(self.tdt).unfold(1, k0, s0), self.w0.to(self.tdt), None if self.b0 is None else self.b0.to(self.tdt))
+            ln = getattr(model.feature_extractor.conv_layers[0], "2")[1]
+            y = F.gelu(ln(y))
+        for i, (dim, k, s) in enumerate(self.spec[1:], start=1):
+            wf, b = self.layers[i - 1]
+            Tn = (T - k) // s + 1
+            out = torch.empty(B, Tn, dim, device=self.dev, dtype=self.tdt)
+            L.check(lib.fh_conv1d_forward(self.dt, y.data_ptr(), wf.data_ptr(), b.data_ptr() if b is not None else None,
+                                          out.data_ptr(), B, T, y.shape[2], dim, k, s, 1 if self.mode == "default" else 0,
+                                          self._st()), "fh_conv1d_forward")
+            if self.mode != "default":
+                ln = getattr(model.feature_extractor.conv_layers[i], "2")[1]
+                out = F.gelu(ln(out))
+            y, T = out, Tn
+        return y
+
+    def posconv(self, x: torch.Tensor) -> torch.Tensor:
+        """x + gelu(pos_conv(x)) for B x T x D."""
+        x = x.contiguous()
+        B, T, D = x.shape
+        y = torch.empty_like(x)
+        self.L.check(self.lib.fh_posconv_wide_forward(self.dt, x.data_ptr(), self.pos_w.data_ptr(), self.pos_bias.data_ptr(),
+                                                      y.data_ptr(), B, T, D, self.G, self.K, self._st()), "fh_posconv_wide_forward")
+        return y
+
+
 class TeacherModel(nn.Module):
     """Parameter names == fairseq HubertModel / Wav2Vec2Model for the parts the distillation uses."""
 
@@ -162,6 +247,13 @@ class TeacherModel(nn.Module):
         self.layer_norm = nn.LayerNorm(self.feature_extractor.out_dim)
         self.post_extract_proj = nn.Linear(self.feature_extractor.out_dim, cfg.encoder_embed_dim)
         self.encoder = _Encoder(cfg)
+        self.native_frontend = False   # True: conv frontend + positional conv on the HIP kernels (GPU only)
+        self._native = None
+
+    def enable_native_frontend(self, on: bool = True):
+        self.native_frontend = on
+        self._native = None
+        return self
 
     def _frame_mask(self, padding_mask, T):
         """True = padded frame.  HuBERT: all samples of the frame are padding (fairseq forward_padding_mask);
@@ -183,7 +275,14 @@ class TeacherModel(nn.Module):
     def run(self, source, padding_mask=None, want_fc2: bool = False):
         """-> (hidden [L][B][T][C], post_extract_proj [B][T][C], fc2 list or None)"""
         dt = self.post_extract_proj.weight.dtype
-        x = self.feature_extractor(source.to(dt)).transpose(1, 2)
+        native = None
+        if self.native_frontend:
+            if self._native is None:
+                self._native = _NativeFrontend(self)
+            native = self._native
+            x = native.features(self, source)
+        else:
+            x = self.feature_extractor(source.to(dt)).transpose(1, 2)
         x = self.layer_norm(x)
         B, T, _ = x.shape
         fm = self._frame_mask(padding_mask, T)
@@ -191,10 +290,13 @@ class TeacherModel(nn.Module):
         x = post
         if fm is not None:
             x = x.masked_fill(fm.unsqueeze(-1), 0.0)
-        xc = self.encoder.pos_conv(x.transpose(1, 2))
-        if self.encoder.k % 2 == 0:
-            xc = xc[:, :, :-1]
-        x = x + F.gelu(xc).transpose(1, 2)
+        if native is not None and self.encoder.k % 2 == 0:
+            x = native.posconv(x)
+        else:
+            xc = self.encoder.pos_conv(x.transpose(1, 2))
+            if self.encoder.k % 2 == 0:
+                xc = xc[:, :, :-1]
+            x = x + F.gelu(xc).transpose(1, 2)
         if not self.cfg.layer_norm_first:
             x = self.encoder.layer_norm(x)
         key_mask = None if fm is None else (~fm)[:, None, None, :]
@@ -232,7 +334,7 @@ def freeze_model(model: nn.Module) -> None:
 
 
 def build_teacher(cfg: TeacherConfig, seed: int = 1, dtype=torch.bfloat16, device="cuda",
-                  state_dict: Optional[Dict[str, torch.Tensor]] = None) -> TeacherWrapper:
+                  state_dict: Optional[Dict[str, torch.Tensor]] = None, native_frontend: bool = False) -> TeacherWrapper:
     """Random-init (seeded) teacher of the given architecture, or load fairseq-named weights."""
     g = torch.Generator().manual_seed(seed)
     m = TeacherModel(cfg)
@@ -258,6 +360,7 @@ def build_teacher(cfg: TeacherConfig, seed: int = 1, dtype=torch.bfloat16, devic
             raise RuntimeError(f"teacher checkpoint is missing {missing[:5]}...")
         m.load_state_dict({k: state_dict[k] for k in own})
     m = m.to(device=device, dtype=dtype).eval()
+    m.enable_native_frontend(native_frontend)
     w = TeacherWrapper(m)
     freeze_model(w)
     return w

@@ -215,6 +215,21 @@ int fh_student_backward(const fh_student_config* c, const fh_student_call* k, co
                         void* ws, float* grads, const float* wave, const int* lens, const void* d_pred,
                         const void* d_hidden, fh_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Frozen-teacher conv frontend on the student's kernels.  The teacher (fairseq HubertModel /
+ * Wav2Vec2Model, loaded at utils/utils.py:102-149) is third party; its transformer stays on PyTorch-ROCm.
+ *   fh_conv1d_forward : channels-last Conv1d(Cin, Cout, k, stride) [+ bias] [+ GELU] as ONE MFMA GEMM over
+ *                       overlapping windows.  x [B][T][Cin], wf [Cout][k][Cin] (dtype), y [B][Tout][Cout].
+ *   fh_posconv_wide_* : weight-normed grouped positional conv with up to 64 channels per group (768 / 16 = 48):
+ *                       y = x + gelu(conv1d(x, g*v/||v||, bias, pad = K/2)[..., :-1]).  w_fwd: [G][K][64][64] dtype.
+ * ------------------------------------------------------------------------------------------ */
+int fh_conv1d_forward(int dtype, const void* x, const void* wf, const float* bias, void* y, int B, int T, int Cin, int Cout,
+                      int k, int stride, int gelu, fh_stream_t stream);
+int fh_posconv_wide_prepare(int dtype, const float* g, const float* v, void* w_fwd, float* norm2, int D, int groups, int K,
+                            fh_stream_t stream);
+int fh_posconv_wide_forward(int dtype, const void* x, const void* w_fwd, const float* bias, void* y, int B, int T, int D,
+                            int groups, int K, fh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

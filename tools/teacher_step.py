@@ -1,0 +1,15 @@
+"""Teacher-only forward loop (PyTorch-ROCm) for profiling."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fithubert_amd.teacher import TeacherConfig, build_teacher
+ap = argparse.ArgumentParser()
+ap.add_argument("--native", type=int, default=0); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+a = ap.parse_args()
+t = build_teacher(TeacherConfig.base("hubert"), seed=1, dtype=torch.bfloat16, device="cuda", native_frontend=bool(a.native))
+x = 0.1 * torch.randn(a.batch, 160000, device="cuda")
+for _ in range(a.warmup): t.hidden_stack(x, None)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(a.steps): h = t.hidden_stack(x, None)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+print(f"teacher fwd B={a.batch}: {dt*1e3:.2f} ms ({148.1*a.batch/dt/1e3:.0f} TF/s algorithmic)")
