@@ -81,7 +81,7 @@ typedef struct {
 int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 /* Optional per-launch HIP-event timing of the GEMM kernel on its own stream (used by bench.py's roofline object).
  * Variants are indexed dtype*4 + X.layout*2 + Y.layout.  collect() waits for the recorded events, sums, and clears. */
-int fh_gemm_set_path(int path); /* bf16 main loop: 0 = register staging (default), 1 = LDS-DMA, -1 = env FH_GEMM_PATH */
+int fh_gemm_set_path(int path); /* bf16 main loop: 0 = 16x16x32 MFMA register staging, 1 = 16x16x32 LDS-DMA ring, 2 = 32x32x16 MFMA register staging (default), -1 = env FH_GEMM_PATH (reg|dma) */
 int fh_prof_enable(int on);
 int fh_prof_collect(double* ms /*[8]*/, double* flops /*[8]*/, long* launches /*[8]*/);
 

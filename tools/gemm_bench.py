@@ -12,7 +12,7 @@ bf = torch.bfloat16
 
 def run(name, d, flops, bytes_, n=20):
     res = []
-    for path in (0, 1):
+    for path in (0, 2):
         lib.fh_gemm_set_path(path)
         for _ in range(3):
             L.check(lib.fh_gemm(d, 1, st()), name)
@@ -24,7 +24,7 @@ def run(name, d, flops, bytes_, n=20):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         res.append(us)
-    print(f"{name:42s} reg {res[0]:8.1f} us {flops/res[0]/1e6:7.1f} TF/s {bytes_/res[0]/1e3:6.0f} GB/s | dma {res[1]:8.1f} us {flops/res[1]/1e6:7.1f} TF/s {bytes_/res[1]/1e3:6.0f} GB/s", flush=True)
+    print(f"{name:42s} reg {res[0]:8.1f} us {flops/res[0]/1e6:7.1f} TF/s {bytes_/res[0]/1e3:6.0f} GB/s | mfma32 {res[1]:8.1f} us {flops/res[1]/1e6:7.1f} TF/s {bytes_/res[1]/1e3:6.0f} GB/s", flush=True)
 
 def lin(M, N, K, groups=1):
     X = torch.randn(groups, M, K, device=dev).to(bf); W = torch.randn(groups, N, K, device=dev).to(bf)
