@@ -46,64 +46,61 @@ __device__ __forceinline__ float conv_at(const float* sw, const float* w, int t,
   return v;
 }
 
-// ---------------------------------------------------------------- forward pass 1: chunk statistics
-__global__ void __launch_bounds__(256) conv0_stats_kernel(Conv0Args a, float2* part /*[B][nchunk][C0] (mean, M2)*/) {
+// ---------------------------------------------------------------- forward pass 1: statistics WITHOUT evaluating the conv
+// The conv output of channel c at frame t is v = w_c . x_t with x_t = wave[stride*t .. stride*t + K).  Its mean and variance
+// over time are therefore  mean_c = w_c . m  and  var_c = w_c^T Cov w_c  with m = mean_t x_t (K numbers) and
+// Cov = mean_t x_t x_t^T - m m^T (K x K) -- statistics of the WAVEFORM, shared by all C0 channels.  One cheap pass over the
+// waveform (K*(K+1)/2 + K partial sums per 256-frame chunk) replaces a full conv pass over T0 x C0 outputs; the chunk
+// partials are combined and the quadratic forms evaluated in fp64.
+constexpr int NSTAT(int K) { return K + K * K; }  // m_j then R[j][j'] (full matrix, symmetric entries computed twice: simple)
+
+__global__ void __launch_bounds__(128) conv0_stats_kernel(Conv0Args a, float* part /*[B][nchunk][K + K*K]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sw = smem;                                   // waveform chunk
-  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [2][256]
+  float* sw = smem;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int nt = stage_wave(a, b, chunk, sw);
-  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
-  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
-  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
-    const int c = cbase + cl;
-    float w[MAXK];
-#pragma unroll
-    for (int j = 0; j < MAXK; ++j) w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
-    const float pivot = conv_at(sw, w, 0, a.K, a.stride);
-    float s = 0.f, ss = 0.f;
-#pragma unroll 4
-    for (int t = tl; t < nt; t += nlan) {
-      const float d = conv_at(sw, w, t, a.K, a.stride) - pivot;
-      s += d;
-      ss = fmaf(d, d, ss);
+  const int ns = a.K + a.K * a.K;
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+    float acc = 0.f;
+    if (s < a.K) {
+      for (int t = 0; t < nt; ++t) acc += sw[t * a.stride + s];
+    } else {
+      const int j = (s - a.K) / a.K, jj = (s - a.K) - j * a.K;
+      // pivot-free products are fine here: the combine is fp64 and Cov is formed from fp64 sums
+      for (int t = 0; t < nt; ++t) acc = fmaf(sw[t * a.stride + j], sw[t * a.stride + jj], acc);
     }
-    red[threadIdx.x] = s;
-    red[256 + threadIdx.x] = ss;
-    __syncthreads();
-    if (tl == 0) {
-      for (int l = 1; l < nlan; ++l) {
-        s += red[l * cpb + cl];
-        ss += red[256 + l * cpb + cl];
-      }
-      const float n = (float)nt;
-      const float mean_d = s / n;
-      float2 o;
-      o.x = pivot + mean_d;
-      o.y = fmaxf(ss - s * mean_d, 0.f);
-      part[((long)b * a.nchunk + chunk) * a.C0 + c] = o;
-    }
-    __syncthreads();
+    part[((long)b * a.nchunk + chunk) * ns + s] = acc;
   }
 }
 
-// merge chunk statistics (Chan et al.) in fp64 -> mean, rstd per (b, c)
-__global__ void conv0_stats_final_kernel(const float2* part, float* mean, float* rstd, int B, int nchunk, int C0, int T0,
-                                         float eps) {
+// combine chunk partials (fp64), then mean_c = w_c . m, var_c = w_c^T Cov w_c  ->  mean, rstd per (b, c)
+__global__ void conv0_stats_final_kernel(const float* part, const float* w, float* mean, float* rstd, int B, int nchunk, int C0,
+                                         int K, int T0, float eps) {
+  __shared__ double sm[MAXK + MAXK * MAXK];
   const int b = blockIdx.x;
+  const int ns = K + K * K;
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < nchunk; ++k) acc += (double)part[((long)b * nchunk + k) * ns + s];
+    sm[s] = acc / (double)T0;
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < K * K; s += blockDim.x) {
+    const int j = s / K, jj = s - j * K;
+    sm[K + s] -= sm[j] * sm[jj];  // covariance (each entry owned by one thread; means are read-only here)
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C0; c += blockDim.x) {
-    double n = 0.0, mu = 0.0, m2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float2 p = part[((long)b * nchunk + k) * C0 + c];
-      const double nb = (double)min(TCH, T0 - k * TCH);
-      const double delta = (double)p.x - mu;
-      const double nn = n + nb;
-      mu += delta * nb / nn;
-      m2 += (double)p.y + delta * delta * n * nb / nn;
-      n = nn;
+    double mu = 0.0, var = 0.0;
+    for (int j = 0; j < K; ++j) {
+      const double wj = w[c * K + j];
+      mu += wj * sm[j];
+      double row = 0.0;
+      for (int jj = 0; jj < K; ++jj) row += sm[K + j * K + jj] * (double)w[c * K + jj];
+      var += wj * row;
     }
     mean[b * C0 + c] = (float)mu;
-    rstd[b * C0 + c] = (float)(1.0 / sqrt(m2 / n + (double)eps));
+    rstd[b * C0 + c] = (float)(1.0 / sqrt(fmax(var, 0.0) + (double)eps));
   }
 }
 
@@ -263,9 +260,11 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
   a.T0 = (S - K) / stride + 1;
   a.nchunk = fh_conv0_nchunk(a.T0);
   dim3 grid(a.nchunk, B), block(256);
-  hipLaunchKernelGGL(conv0_stats_kernel, grid, block, smem_bytes(stride, K, true), st, a, part);
+  if (K + K * K > 2 * C0) return -202;  // the statistics partials reuse the [B][nchunk][C0] float2 scratch
+  hipLaunchKernelGGL(conv0_stats_kernel, grid, dim3(128), smem_bytes(stride, K, false), st, a, (float*)part);
   FH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv0_stats_final_kernel, dim3(B), dim3(256), 0, st, part, mean, rstd, B, a.nchunk, C0, a.T0, eps);
+  hipLaunchKernelGGL(conv0_stats_final_kernel, dim3(B), dim3(256), 0, st, (const float*)part, w, mean, rstd, B, a.nchunk, C0, K,
+                     a.T0, eps);
   FH_CHECK_LAUNCH();
   if (dtype == 0)
     hipLaunchKernelGGL(conv0_apply_kernel<float>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (float*)y);
