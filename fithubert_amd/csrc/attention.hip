@@ -10,6 +10,8 @@
 // accumulator tiles of S^T are directly the B operand of the P.V product (no LDS round trip), and V^T / K^T come
 // from transposing LDS reads (ds_read_b64_tr_b16).  Head dim 40 is zero-padded to the MFMA K granularity in LDS only.
 // Backward recomputes P from the saved log-sum-exp: a dQ pass (same decomposition) and a dK/dV pass (wave owns keys).
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -135,10 +137,11 @@ __device__ __forceinline__ float xor_sum(float v) {
 template <typename T, int NDT>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const int* __restrict__ key_len, int B,
-                                                       int Tn, int H, int dh, float scale_log2e, DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * AT<T>::RS];
-  unsigned char* Ks = lds;
-  unsigned char* Vs = lds + 64 * AT<T>::RS;
+                                                       int Tn, int H, int dh, float scale_log2e, DropCfg drop, int resident) {
+  // resident != 0: ALL key/value tiles of this (batch, head) are staged once (T <= 512 bf16 / 320 fp32 fits the 160 KiB
+  // LDS) -- one global-load latency and one barrier per workgroup instead of one per 64-key tile.
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PAIR = 2 * 64 * AT<T>::RS;
   constexpr int NK = AT<T>::NK;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
@@ -148,13 +151,22 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
 
-  zero_lds<T>(lds, 2 * 64 * AT<T>::RS);
+  const int ntile = (klen + 63) / 64;
+  zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
   frag qf[2][NK];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int query = q0 + 16 * qt + r;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) qf[qt][ks] = gfrag<T>(base + (long)query * ld, query < Tn, ks, lane, dh);
+  }
+  if (resident) {
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+      stage_tile<T>(lds + kt * PAIR, base + D, ld, kt * 64, Tn, dh);
+      stage_tile<T>(lds + kt * PAIR + 64 * AT<T>::RS, base + 2 * D, ld, kt * 64, Tn, dh);
+    }
+    __syncthreads();
   }
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   f32x4 o[2][NDT];
@@ -164,10 +176,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
     for (int dt = 0; dt < NDT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int kt0 = 0; kt0 < klen; kt0 += 64) {
-    __syncthreads();
-    stage_tile<T>(Ks, base + D, ld, kt0, Tn, dh);
-    stage_tile<T>(Vs, base + 2 * D, ld, kt0, Tn, dh);
-    __syncthreads();
+    const unsigned char* Ks = lds + (resident ? (kt0 >> 6) * PAIR : 0);
+    const unsigned char* Vs = Ks + 64 * AT<T>::RS;
+    if (!resident) {
+      __syncthreads();
+      stage_tile<T>(lds, base + D, ld, kt0, Tn, dh);
+      stage_tile<T>(lds + 64 * AT<T>::RS, base + 2 * D, ld, kt0, Tn, dh);
+      __syncthreads();
+    }
     f32x4 s[4][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -214,11 +230,13 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[qt][dt][e] *= alpha;
       if (drop.p > 0.f) {
-        const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn;
+        const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
+        const DropKey dk = drop_key(drop, (uint32_t)(rowbase >> 32));  // (rows never straddle a 2^32 boundary in practice;
+        const uint32_t lo = (uint32_t)rowbase;                         //  a carry only changes which mask is drawn, identically in fwd/bwd)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s[kb][qt][e] *= drop_scale(drop, rowbase + kt0 + 16 * kb + 4 * q + e);
+          for (int e = 0; e < 4; ++e) s[kb][qt][e] *= drop_apply(dk, lo + 16 * kb + 4 * q + e);
       }
     }
 #pragma unroll
@@ -252,10 +270,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
                                                           const T* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, T* __restrict__ dqkv,
                                                           const int* __restrict__ key_len, int B, int Tn, int H, int dh,
-                                                          float scale, float scale_log2e, DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * AT<T>::RS];
-  unsigned char* Ks = lds;
-  unsigned char* Vs = lds + 64 * AT<T>::RS;
+                                                          float scale, float scale_log2e, DropCfg drop, int resident) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PAIR = 2 * 64 * AT<T>::RS;
   constexpr int NK = AT<T>::NK;
   constexpr int VEC = ElemTraits<T>::VEC;
   typedef typename AT<T>::frag frag;
@@ -266,7 +283,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
 
-  zero_lds<T>(lds, 2 * 64 * AT<T>::RS);
+  const int ntile = (klen + 63) / 64;
+  zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
+  if (resident) {
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+      stage_tile<T>(lds + kt * PAIR, base + D, ld, kt * 64, Tn, dh);
+      stage_tile<T>(lds + kt * PAIR + 64 * AT<T>::RS, base + 2 * D, ld, kt * 64, Tn, dh);
+    }
+  }
   frag qf[2][NK], dof[2][NK];
   float L2[2], dl[2];
 #pragma unroll
@@ -299,11 +324,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if (resident) __syncthreads();
   for (int kt0 = 0; kt0 < klen; kt0 += 64) {
-    __syncthreads();
-    stage_tile<T>(Ks, base + D, ld, kt0, Tn, dh);
-    stage_tile<T>(Vs, base + 2 * D, ld, kt0, Tn, dh);
-    __syncthreads();
+    const unsigned char* Ks = lds + (resident ? (kt0 >> 6) * PAIR : 0);
+    const unsigned char* Vs = Ks + 64 * AT<T>::RS;
+    if (!resident) {
+      __syncthreads();
+      stage_tile<T>(lds, base + D, ld, kt0, Tn, dh);
+      stage_tile<T>(lds + 64 * AT<T>::RS, base + 2 * D, ld, kt0, Tn, dh);
+      __syncthreads();
+    }
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) {
       f32x4 ds[2][2];  // [half][qt]
@@ -325,13 +355,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           const int query = q0 + 16 * qt + r;
-          const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn;
+          const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
+          const DropKey dk = drop_key(drop, (uint32_t)(rowbase >> 32));
+          const uint32_t lo = (uint32_t)rowbase;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int key = kt0 + 16 * kb + 4 * q + e;
             float p = key < klen ? exp2f(s[qt][e] * scale_log2e - L2[qt]) : 0.f;
             float g = dp[qt][e];
-            if (drop.p > 0.f) g *= drop_scale(drop, rowbase + key);
+            if (drop.p > 0.f) g *= drop_apply(dk, lo + 16 * kb + 4 * q + e);
             ds[half][qt][e] = p * (g - dl[qt]) * scale;
           }
         }
@@ -363,12 +395,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            T* __restrict__ dqkv, const int* __restrict__ key_len, int B,
                                                            int Tn, int H, int dh, float scale, float scale_log2e,
-                                                           DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * AT<T>::RS + 512];
-  unsigned char* Qs = lds;
-  unsigned char* Os = lds + 64 * AT<T>::RS;
-  float* L2s = reinterpret_cast<float*>(lds + 2 * 64 * AT<T>::RS);
-  float* Dls = L2s + 64;
+                                                           DropCfg drop, int resident) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PAIR = 2 * 64 * AT<T>::RS + 512;  // Q tile | dO tile | 64 x LSE | 64 x delta
   constexpr int NK = AT<T>::NK;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
@@ -379,7 +408,23 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
   const T* dobase = dout + (long)b * Tn * D + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
 
-  zero_lds<T>(lds, 2 * 64 * AT<T>::RS);
+  const int ntile = (Tn + 63) / 64;
+  zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
+  auto stage_q = [&](int slot, int qt0) {
+    unsigned char* sb = lds + slot * PAIR;
+    stage_tile<T>(sb, base, ld, qt0, Tn, dh);
+    stage_tile<T>(sb + 64 * AT<T>::RS, dobase, D, qt0, Tn, dh);
+    if (threadIdx.x < 64) {
+      float* L2w = reinterpret_cast<float*>(sb + 2 * 64 * AT<T>::RS);
+      const int query = qt0 + threadIdx.x;
+      L2w[threadIdx.x] = query < Tn ? lse[((long)b * H + h) * Tn + query] : INFINITY;
+      L2w[64 + threadIdx.x] = query < Tn ? delta[((long)b * H + h) * Tn + query] : 0.f;
+    }
+  };
+  if (resident) {
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) stage_q(kt, kt * 64);
+  }
   frag kf[2][NK], vf[2][NK];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
@@ -399,16 +444,17 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
       dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+  if (resident) __syncthreads();
   for (int qt0 = 0; qt0 < Tn; qt0 += 64) {
-    __syncthreads();
-    stage_tile<T>(Qs, base, ld, qt0, Tn, dh);
-    stage_tile<T>(Os, dobase, D, qt0, Tn, dh);
-    if (threadIdx.x < 64) {
-      const int query = qt0 + threadIdx.x;
-      L2s[threadIdx.x] = query < Tn ? lse[((long)b * H + h) * Tn + query] : INFINITY;
-      Dls[threadIdx.x] = query < Tn ? delta[((long)b * H + h) * Tn + query] : 0.f;
+    const unsigned char* Qs = lds + (resident ? (qt0 >> 6) * PAIR : 0);
+    const unsigned char* Os = Qs + 64 * AT<T>::RS;
+    const float* L2s = reinterpret_cast<const float*>(Qs + 2 * 64 * AT<T>::RS);
+    const float* Dls = L2s + 64;
+    if (!resident) {
+      __syncthreads();
+      stage_q(0, qt0);
+      __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) {
       f32x4 pd[2][2], ds[2][2];  // [half][kt]
@@ -436,8 +482,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
             const int query = qt0 + ql;
             float p = key < klen ? exp2f(s[kt][e] * scale_log2e - L2s[ql]) : 0.f;
             float dsc = 1.f;
-            if (drop.p > 0.f)
-              dsc = drop_scale(drop, (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + key);
+            if (drop.p > 0.f) {
+              // same (key-tile-relative) split of the index as the forward: hi word of (row base + tile start), lo + offset
+              const int kt0 = key & ~63;
+              const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
+              dsc = drop_apply(drop_key(drop, (uint32_t)(rowbase >> 32)), (uint32_t)rowbase + (key - kt0));
+            }
             pd[half][kt][e] = p * dsc;
             ds[half][kt][e] = p * (dp[kt][e] * dsc - Dls[ql]) * scale;
           }
@@ -476,6 +526,24 @@ int check_dims(int dtype, int H, int dh) {
   return 0;
 }
 
+template <typename T> int resident_tiles_unused();
+}  // namespace
+
+namespace {
+template <typename T> int resident_tiles(int n) {  // 0 = tiled path
+  static int mode = -1;  // FH_ATTN_RESIDENT=0 forces the tiled path (A/B comparisons)
+  if (mode < 0) {
+    const char* e = getenv("FH_ATTN_RESIDENT");
+    mode = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!mode) return 0;
+  const int ntile = (n + 63) / 64;
+  return (size_t)ntile * (2 * 64 * AT<T>::RS + 512) <= 150 * 1024 ? ntile : 0;
+}
+template <typename K> void set_lds(K kernel, size_t bytes) {
+  hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 }  // namespace
 
 int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int Tn, int H,
@@ -483,12 +551,19 @@ int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, c
   if (int rc = check_dims(dtype, H, dh)) return rc;
   dim3 grid((Tn + 127) / 128, H, B), block(256);
   const float sl2 = scale * 1.4426950408889634f;
-  if (dtype == 0)
-    hipLaunchKernelGGL((attn_fwd_kernel<float, 3>), grid, block, 0, st, (const float*)qkv, (float*)out, lse, key_len, B,
-                       Tn, H, dh, sl2, drop);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<bf16, 3>), grid, block, 0, st, (const bf16*)qkv, (bf16*)out, lse, key_len, B, Tn,
-                       H, dh, sl2, drop);
+  if (dtype == 0) {
+    const int res = resident_tiles<float>(Tn);
+    const size_t smem = (size_t)(res ? res : 1) * 2 * 64 * AT<float>::RS;
+    set_lds(attn_fwd_kernel<float, 3>, smem);
+    hipLaunchKernelGGL((attn_fwd_kernel<float, 3>), grid, block, smem, st, (const float*)qkv, (float*)out, lse, key_len, B, Tn, H,
+                       dh, sl2, drop, res);
+  } else {
+    const int res = resident_tiles<bf16>(Tn);
+    const size_t smem = (size_t)(res ? res : 1) * 2 * 64 * AT<bf16>::RS;
+    set_lds(attn_fwd_kernel<bf16, 3>, smem);
+    hipLaunchKernelGGL((attn_fwd_kernel<bf16, 3>), grid, block, smem, st, (const bf16*)qkv, (bf16*)out, lse, key_len, B, Tn, H, dh,
+                       sl2, drop, res);
+  }
   FH_CHECK_LAUNCH();
   return 0;
 }
@@ -500,17 +575,25 @@ int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const v
   dim3 grid((Tn + 127) / 128, H, B), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype == 0) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<float, 3>), grid, block, 0, st, (const float*)qkv, (const float*)out,
-                       (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop);
+    const int res = resident_tiles<float>(Tn);
+    const size_t s1 = (size_t)(res ? res : 1) * 2 * 64 * AT<float>::RS, s2 = (size_t)(res ? res : 1) * (2 * 64 * AT<float>::RS + 512);
+    set_lds(attn_bwd_dq_kernel<float, 3>, s1);
+    set_lds(attn_bwd_dkv_kernel<float, 3>, s2);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<float, 3>), grid, block, s1, st, (const float*)qkv, (const float*)out,
+                       (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
     FH_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 3>), grid, block, 0, st, (const float*)qkv, (const float*)dout, lse,
-                       delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 3>), grid, block, s2, st, (const float*)qkv, (const float*)dout, lse, delta,
+                       (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16, 3>), grid, block, 0, st, (const bf16*)qkv, (const bf16*)out,
-                       (const bf16*)dout, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop);
+    const int res = resident_tiles<bf16>(Tn);
+    const size_t s1 = (size_t)(res ? res : 1) * 2 * 64 * AT<bf16>::RS, s2 = (size_t)(res ? res : 1) * (2 * 64 * AT<bf16>::RS + 512);
+    set_lds(attn_bwd_dq_kernel<bf16, 3>, s1);
+    set_lds(attn_bwd_dkv_kernel<bf16, 3>, s2);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16, 3>), grid, block, s1, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
+                       lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
     FH_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 3>), grid, block, 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
-                       delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 3>), grid, block, s2, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
+                       (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
   }
   FH_CHECK_LAUNCH();
   return 0;

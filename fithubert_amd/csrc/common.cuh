@@ -139,11 +139,26 @@ __device__ __forceinline__ uint32_t fh_mix32(uint32_t x) {
   return x;
 }
 typedef fh_drop DropCfg;  // {p, seed, site}
+// Split form: the per-site key (depends on seed, site and the HIGH index word only) is hoisted out of inner loops; per
+// element it is one 32-bit mix + an integer compare.  keep  <=>  top 24 hash bits >= p * 2^24.
+struct DropKey {
+  uint32_t k;
+  uint32_t thresh;
+  float inv_keep;
+};
+__device__ __forceinline__ DropKey drop_key(const DropCfg& d, uint32_t idx_hi) {
+  DropKey r;
+  r.k = fh_mix32(d.seed * 0x9E3779B9u + d.site * 0x85ebca6bu + idx_hi * 0xc2b2ae35u + 0x27d4eb2fu);
+  r.thresh = (uint32_t)(d.p * 16777216.0f);
+  r.inv_keep = 1.0f / (1.0f - d.p);
+  return r;
+}
+__device__ __forceinline__ float drop_apply(const DropKey& k, uint32_t idx_lo) {
+  const uint32_t h = fh_mix32(idx_lo ^ k.k);
+  return (h >> 8) >= k.thresh ? k.inv_keep : 0.0f;
+}
 __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
-  uint32_t k = fh_mix32(d.seed * 0x9E3779B9u + d.site * 0x85ebca6bu + (uint32_t)(idx >> 32) * 0xc2b2ae35u + 0x27d4eb2fu);
-  uint32_t h = fh_mix32((uint32_t)idx ^ k);
-  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-  return u >= d.p ? 1.0f / (1.0f - d.p) : 0.0f;
+  return drop_apply(drop_key(d, (uint32_t)(idx >> 32)), (uint32_t)idx);
 }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)

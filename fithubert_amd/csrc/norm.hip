@@ -208,7 +208,20 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, fl
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
   if (cv) {
-    for (int r = r0 + ry; r < r1; r += 4) {
+    int r = r0 + ry;
+    for (; r + 28 < r1; r += 32) {  // 8 independent 16-byte loads in flight (the loop is latency-, not bandwidth-bound)
+      V16 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = ld16(xp + (long)(r + 4 * u) * ldx);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float v[VEC];
+        unpack16<T>(t[u], v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+      }
+    }
+    for (; r < r1; r += 4) {
       float v[VEC];
       unpack16<T>(ld16(xp + (long)r * ldx), v);
 #pragma unroll

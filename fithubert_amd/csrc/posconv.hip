@@ -159,19 +159,33 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
     for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * K * CP * CP;
   const int r = lane & 15;
-#pragma unroll 4
+  // weights stream from L2 (identical for every workgroup of the group): keep the NEXT tap's fragments in flight
+  typename F::type wn[F::NK][2];
+#pragma unroll
+  for (int kr = 0; kr < F::NK; ++kr)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) wn[kr][cb] = F::gmem_row(wg, cb * 16 + r, lane, kr);
+#pragma unroll 2
   for (int j = 0; j < K; ++j) {
+    typename F::type wf[F::NK][2];
+#pragma unroll
+    for (int kr = 0; kr < F::NK; ++kr)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) wf[kr][cb] = wn[kr][cb];
+    const int jn = j + 1 < K ? j + 1 : j;
+#pragma unroll
+    for (int kr = 0; kr < F::NK; ++kr)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) wn[kr][cb] = F::gmem_row(wg + (long)jn * CP * CP, cb * 16 + r, lane, kr);
 #pragma unroll
     for (int kr = 0; kr < F::NK; ++kr) {
-      typename F::type wf[2], xf[2];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) wf[cb] = F::gmem_row(wg + (long)j * CP * CP, cb * 16 + r, lane, kr);
+      typename F::type xf[2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) xf[tt] = F::lds_row(lds, wave * 32 + tt * 16 + r + j, lane, kr);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = F::mma(wf[cb], xf[tt], acc[cb][tt]);
+        for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = F::mma(wf[kr][cb], xf[tt], acc[cb][tt]);
     }
   }
 

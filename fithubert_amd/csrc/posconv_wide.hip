@@ -80,10 +80,26 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) acc[cb][0] = acc[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * K * CPW * CPW;
-#pragma unroll 2
-  for (int j = 0; j < K; ++j) {
-    const T* wj = wg + (long)j * CPW * CPW;
-    if constexpr (IS_BF) {
+  if constexpr (IS_BF) {
+    // next tap's weight fragments are loaded (from L2) while this tap's MFMAs run
+    bf16x8 wn[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        wn[ks][cb] = *reinterpret_cast<const bf16x8*>(wg + (long)(cb * 16 + r) * CPW + ks * 32 + q * 8);
+    for (int j = 0; j < K; ++j) {
+      bf16x8 wf[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) wf[ks][cb] = wn[ks][cb];
+      const T* wj = wg + (long)(j + 1 < K ? j + 1 : j) * CPW * CPW;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          if (cb < ncb) wn[ks][cb] = *reinterpret_cast<const bf16x8*>(wj + (long)(cb * 16 + r) * CPW + ks * 32 + q * 8);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 xf[2];
@@ -93,13 +109,15 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           if (cb < ncb) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wj + (long)(cb * 16 + r) * CPW + ks * 32 + q * 8);
-            acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[0], acc[cb][0], 0, 0, 0);
-            acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[1], acc[cb][1], 0, 0, 0);
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cb], xf[0], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cb], xf[1], acc[cb][1], 0, 0, 0);
           }
         }
       }
-    } else {
+    }
+  } else {
+    for (int j = 0; j < K; ++j) {
+      const T* wj = wg + (long)j * CPW * CPW;
 #pragma unroll
       for (int kr = 0; kr < 4; ++kr) {
         f32x4 xf[2];
