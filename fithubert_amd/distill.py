@@ -92,6 +92,9 @@ class W2V2Distil:
         self.student_model.mark_params_updated()
         self._micro = 0
         self._next_teacher = None
+        # the frozen teacher runs on its own HIP stream: its forward for batch i+1 overlaps the student's forward /
+        # backward of batch i (and the gradient all-reduce), filling CUs the student's short kernels leave idle
+        self.teacher_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     # ------------------------------------------------------------------ loss tables
     def _set_loss_tables(self):
@@ -172,9 +175,22 @@ class W2V2Distil:
     def teacher_hiddens(self, batch) -> torch.Tensor:
         self.teacher_model.eval()  # train.py:131
         pm = batch.get("padding_mask")
-        if pm is not None and not bool(pm.any()) and self.teacher_model.model.cfg.model_type != "hubert":
+        if pm is not None and not bool(batch.get("_any_pad", True)) and self.teacher_model.model.cfg.model_type != "hubert":
             pm = None
         return self.teacher_model.hidden_stack(batch["x"], pm)
+
+    def _teacher_async(self, batch):
+        """Enqueue the teacher forward on the side stream; returns (hidden stack, event that marks it ready)."""
+        if self.teacher_stream is None:
+            return self.teacher_hiddens(batch), None
+        main = torch.cuda.current_stream(self.device)
+        self.teacher_stream.wait_stream(main)  # the batch tensors were produced on the main stream
+        with torch.cuda.stream(self.teacher_stream):
+            hid = self.teacher_hiddens(batch)
+            ev = torch.cuda.Event()
+            ev.record(self.teacher_stream)
+        hid.record_stream(main)  # consumed by the loss kernel on the main stream
+        return hid, ev
 
     @torch.no_grad()
     def training_step(self, batch, batch_idx: int = 0, next_batch=None, seed: Optional[int] = None):
@@ -188,24 +204,24 @@ class W2V2Distil:
             lengths = batch.get("_lengths")
             if lengths is None:
                 lengths = (~pm).sum(-1).tolist()
-        hid = self._next_teacher if self._next_teacher is not None else self.teacher_hiddens(batch)
-        self._next_teacher = None
+        hid, ev = self._next_teacher if self._next_teacher is not None else self._teacher_async(batch)
+        # the NEXT batch's teacher forward goes to the side stream now: it runs under this step's student fwd/bwd,
+        # the gradient all-reduce and the optimizer
+        self._next_teacher = self._teacher_async(next_batch) if next_batch is not None else None
         if self._micro == 0:
             self.engine.grads.zero_()
         step_seed = seed if seed is not None else (self.opt_step * 7919 + self._micro * 104729 + batch_idx + 1)
         ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
         out, d_pred = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer,
                                           loss_type=0 if self.rec_loss_type == "mse" else 1, grad_scale=float(self.rec_loss_weight))
         self.engine.backward(ws, d_pred=d_pred)
         self._micro += 1
         if self._micro >= self.accumulate:
             self.sync.launch()                      # async all-reduce of the flat gradients (RCCL / xGMI)
-            if next_batch is not None:              # overlapped with the frozen teacher's next forward
-                self._next_teacher = self.teacher_hiddens(next_batch)
             self.sync.wait()
             self.optimizer_step()
-        elif next_batch is not None:
-            self._next_teacher = self.teacher_hiddens(next_batch)
         return out
 
     @torch.no_grad()
