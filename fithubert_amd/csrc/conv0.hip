@@ -104,6 +104,42 @@ __global__ void conv0_stats_final_kernel(const float* part, const float* w, floa
   }
 }
 
+// ---------------------------------------------------------------- vectorised channel mapping (passes 2, bwd 1, bwd 2)
+// A thread owns CV = 4 consecutive channels (8/16-byte loads and stores, 4x fewer LDS broadcasts per output) and walks time
+// with stride `nlan`; a block's C0/4 channel groups x nlan time lanes = 256 threads.  These passes are latency-bound (one
+// dependent load per output), so wider per-thread I/O is what buys time.
+constexpr int CV = 4;
+
+struct ChanMap {
+  int ngrp, nlan, cg, tl, c0;
+  __device__ __forceinline__ ChanMap(int C0) {
+    ngrp = C0 / CV;           // <= 256 and divides 256 (checked on the host)
+    nlan = 256 / ngrp;
+    cg = threadIdx.x % ngrp;
+    tl = threadIdx.x / ngrp;
+    c0 = cg * CV;
+  }
+};
+
+__device__ __forceinline__ void load_w4(const Conv0Args& a, int c0, float (&w)[CV][MAXK]) {
+#pragma unroll
+  for (int e = 0; e < CV; ++e)
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) w[e][j] = j < a.K ? a.w[(c0 + e) * a.K + j] : 0.f;
+}
+__device__ __forceinline__ void conv4_at(const float* sw, const float (&w)[CV][MAXK], int t, int K, int stride, float* v) {
+  const float* x = sw + t * stride;
+#pragma unroll
+  for (int e = 0; e < CV; ++e) v[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j)
+    if (j < K) {
+      const float xj = x[j];
+#pragma unroll
+      for (int e = 0; e < CV; ++e) v[e] = fmaf(w[e][j], xj, v[e]);
+    }
+}
+
 // ---------------------------------------------------------------- forward pass 2: conv + GN + GELU -> y
 template <typename T>
 __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const float* mean, const float* rstd, T* y) {
@@ -111,21 +147,25 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
   float* sw = smem;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int nt = stage_wave(a, b, chunk, sw);
-  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
-  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
-  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
-    const int c = cbase + cl;
-    float w[MAXK];
+  const ChanMap m(a.C0);
+  float w[CV][MAXK];
+  load_w4(a, m.c0, w);
+  float sc[CV], sh[CV];
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j) w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
-    const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
-    const float sc = rs * a.gamma[c], sh = a.beta[c] - mu * rs * a.gamma[c];
-    T* yp = y + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
-#pragma unroll 4
-    for (int t = tl; t < nt; t += nlan) {
-      const float v = conv_at(sw, w, t, a.K, a.stride);
-      yp[(long)t * a.C0] = from_f<T>(gelu_f(fmaf(v, sc, sh)));
-    }
+  for (int e = 0; e < CV; ++e) {
+    const int c = m.c0 + e;
+    const float rs = rstd[b * a.C0 + c];
+    sc[e] = rs * a.gamma[c];
+    sh[e] = a.beta[c] - mean[b * a.C0 + c] * sc[e];
+  }
+  T* yp = y + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + m.c0;
+#pragma unroll 2
+  for (int t = m.tl; t < nt; t += m.nlan) {
+    float v[CV];
+    conv4_at(sw, w, t, a.K, a.stride, v);
+#pragma unroll
+    for (int e = 0; e < CV; ++e) v[e] = gelu_f(fmaf(v[e], sc[e], sh[e]));
+    st4(yp + (long)t * a.C0, v);
   }
 }
 
@@ -135,38 +175,49 @@ __global__ void __launch_bounds__(256) conv0_bwd_reduce_kernel(Conv0Args a, cons
                                                                const T* dy, float2* part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
-  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;
+  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [2][256][CV]
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int nt = stage_wave(a, b, chunk, sw);
-  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
-  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
-  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
-    const int c = cbase + cl;
-    float w[MAXK];
+  const ChanMap m(a.C0);
+  float w[CV][MAXK];
+  load_w4(a, m.c0, w);
+  float mu[CV], rs[CV], ga[CV], be[CV], s1[CV], s2[CV];
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j) w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
-    const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
-    const float ga = a.gamma[c], be = a.beta[c];
-    const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll 4
-    for (int t = tl; t < nt; t += nlan) {
-      const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
-      const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
-      s1 += g;
-      s2 = fmaf(g, xh, s2);
+  for (int e = 0; e < CV; ++e) {
+    const int c = m.c0 + e;
+    mu[e] = mean[b * a.C0 + c]; rs[e] = rstd[b * a.C0 + c]; ga[e] = a.gamma[c]; be[e] = a.beta[c];
+    s1[e] = 0.f; s2[e] = 0.f;
+  }
+  const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + m.c0;
+#pragma unroll 2
+  for (int t = m.tl; t < nt; t += m.nlan) {
+    float v[CV], d[CV];
+    ld4(dyp + (long)t * a.C0, d);
+    conv4_at(sw, w, t, a.K, a.stride, v);
+#pragma unroll
+    for (int e = 0; e < CV; ++e) {
+      const float xh = (v[e] - mu[e]) * rs[e];
+      const float g = d[e] * gelu_grad_f(fmaf(xh, ga[e], be[e]));
+      s1[e] += g;
+      s2[e] = fmaf(g, xh, s2[e]);
     }
-    red[threadIdx.x] = s1;
-    red[256 + threadIdx.x] = s2;
-    __syncthreads();
-    if (tl == 0) {
-      for (int l = 1; l < nlan; ++l) {
-        s1 += red[l * cpb + cl];
-        s2 += red[256 + l * cpb + cl];
+  }
+#pragma unroll
+  for (int e = 0; e < CV; ++e) {
+    red[threadIdx.x * CV + e] = s1[e];
+    red[256 * CV + threadIdx.x * CV + e] = s2[e];
+  }
+  __syncthreads();
+  if (m.tl == 0) {
+#pragma unroll
+    for (int e = 0; e < CV; ++e) {
+      float a1 = s1[e], a2 = s2[e];
+      for (int l = 1; l < m.nlan; ++l) {
+        a1 += red[(l * m.ngrp + m.cg) * CV + e];
+        a2 += red[256 * CV + (l * m.ngrp + m.cg) * CV + e];
       }
-      part[((long)b * a.nchunk + chunk) * a.C0 + c] = make_float2(s1, s2);
+      part[((long)b * a.nchunk + chunk) * a.C0 + m.c0 + e] = make_float2(a1, a2);
     }
-    __syncthreads();
   }
 }
 
@@ -194,47 +245,60 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
                                                                const float2* ab, const T* dy, float scale, float* dw) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
-  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [256]
+  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [256][CV]
   const int b = blockIdx.y;
-  const int cpb = min(a.C0, 256), nlan = 256 / cpb;
-  const int cl = threadIdx.x % cpb, tl = threadIdx.x / cpb;
-  for (int cbase = 0; cbase < a.C0; cbase += cpb) {
-    const int c = cbase + cl;
-    float w[MAXK], acc[MAXK];
+  const ChanMap m(a.C0);
+  float w[CV][MAXK], acc[CV][MAXK];
+  load_w4(a, m.c0, w);
+  float mu[CV], rs[CV], ga[CV], be[CV], aa[CV], bb[CV];
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j) {
-      w[j] = j < a.K ? a.w[c * a.K + j] : 0.f;
-      acc[j] = 0.f;
-    }
-    const float mu = mean[b * a.C0 + c], rs = rstd[b * a.C0 + c];
-    const float ga = a.gamma[c], be = a.beta[c];
+  for (int e = 0; e < CV; ++e) {
+    const int c = m.c0 + e;
+    mu[e] = mean[b * a.C0 + c]; rs[e] = rstd[b * a.C0 + c]; ga[e] = a.gamma[c]; be[e] = a.beta[c];
     const float2 abv = ab[b * a.C0 + c];
-    // the block walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... keeping its dW partial in registers
-    for (int chunk = blockIdx.x; chunk < a.nchunk; chunk += gridDim.x) {
-      __syncthreads();
-      const int nt = stage_wave(a, b, chunk, sw);
-      const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + c;
-  #pragma unroll 4
-    for (int t = tl; t < nt; t += nlan) {
-        const float xh = (conv_at(sw, w, t, a.K, a.stride) - mu) * rs;
-        const float g = to_f(dyp[(long)t * a.C0]) * gelu_grad_f(fmaf(xh, ga, be));
-        const float dv = rs * (g * ga - abv.x - xh * abv.y);
-        const float* x = sw + t * a.stride;
+    aa[e] = abv.x; bb[e] = abv.y;
 #pragma unroll
-        for (int j = 0; j < MAXK; ++j)
-          if (j < a.K) acc[j] = fmaf(dv, x[j], acc[j]);
+    for (int j = 0; j < MAXK; ++j) acc[e][j] = 0.f;
+  }
+  // the block walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... keeping its dW partial in registers
+  for (int chunk = blockIdx.x; chunk < a.nchunk; chunk += gridDim.x) {
+    __syncthreads();
+    const int nt = stage_wave(a, b, chunk, sw);
+    const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + m.c0;
+#pragma unroll 2
+    for (int t = m.tl; t < nt; t += m.nlan) {
+      float v[CV], d[CV];
+      ld4(dyp + (long)t * a.C0, d);
+      conv4_at(sw, w, t, a.K, a.stride, v);
+      const float* x = sw + t * a.stride;
+#pragma unroll
+      for (int e = 0; e < CV; ++e) {
+        const float xh = (v[e] - mu[e]) * rs[e];
+        const float g = d[e] * gelu_grad_f(fmaf(xh, ga[e], be[e]));
+        v[e] = rs[e] * (g * ga[e] - aa[e] - xh * bb[e]);  // dv
       }
-    }
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j) {
-      if (j < a.K) {
-        __syncthreads();
-        red[threadIdx.x] = acc[j];
-        __syncthreads();
-        if (tl == 0) {
-          float s = acc[j];
-          for (int l = 1; l < nlan; ++l) s += red[l * cpb + cl];
-          atomicAdd(dw + c * a.K + j, s * scale);
+      for (int j = 0; j < MAXK; ++j)
+        if (j < a.K) {
+          const float xj = x[j];
+#pragma unroll
+          for (int e = 0; e < CV; ++e) acc[e][j] = fmaf(v[e], xj, acc[e][j]);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    if (j < a.K) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < CV; ++e) red[threadIdx.x * CV + e] = acc[e][j];
+      __syncthreads();
+      if (m.tl == 0) {
+#pragma unroll
+        for (int e = 0; e < CV; ++e) {
+          float s = acc[e][j];
+          for (int l = 1; l < m.nlan; ++l) s += red[(l * m.ngrp + m.cg) * CV + e];
+          atomicAdd(dw + (m.c0 + e) * a.K + j, s * scale);
         }
       }
     }
@@ -243,7 +307,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
 
 size_t smem_bytes(int stride, int K, bool red2) {
   size_t sw = ((size_t)((TCH - 1) * stride + K) + 3) / 4 * 4;
-  return (sw + (red2 ? 512 : 256)) * sizeof(float);
+  return (sw + (red2 ? 2 : 1) * 256 * CV) * sizeof(float);
 }
 
 }  // namespace
@@ -253,7 +317,7 @@ int fh_conv0_nchunk(int T0) { return (T0 + TCH - 1) / TCH; }
 int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, float2* part, int B, int S, int C0, int K, int stride, float eps,
                         hipStream_t st) {
-  if (K > MAXK || C0 % 64 != 0 || (C0 > 256 && C0 % 256 != 0) || (C0 < 256 && 256 % C0 != 0)) return -201;
+  if (K > MAXK || C0 % 64 != 0 || C0 / CV > 256 || 256 % (C0 / CV) != 0) return -201;
   Conv0Args a;
   a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta;
   a.B = B; a.S = S; a.C0 = C0; a.K = K; a.stride = stride;
@@ -278,7 +342,7 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
                         const void* dy, const float* mean, const float* rstd, float2* part, float2* ab, float* dw,
                         float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
                         hipStream_t st) {
-  if (K > MAXK || C0 % 64 != 0 || (C0 > 256 && C0 % 256 != 0) || (C0 < 256 && 256 % C0 != 0)) return -201;
+  if (K > MAXK || C0 % 64 != 0 || C0 / CV > 256 || 256 % (C0 / CV) != 0) return -201;
   Conv0Args a;
   a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta;
   a.B = B; a.S = S; a.C0 = C0; a.K = K; a.stride = stride;

@@ -135,3 +135,42 @@ def test_distill_task_trains_and_checkpoints_roundtrip(tmp_path):
     err = _rel_l2(res["last_hidden_state"], ref["projections"][-1].float())
     errs = [_rel_l2(res["hidden_states"][i][0], ref["layer_results"][i][0].float()) for i in range(3)]
     assert err < 1e-6, (err, errs)
+
+
+def test_baseline_configs_3_4_5_plumbing():
+    """BASELINE.json configs[2..4] at test size: bucketed variable-length (padded) batches through the fused training
+    step, the wav2vec 2.0 teacher (fitwav2vec2.yaml; conv-length padding rule), and a HuBERT-Large-shaped teacher
+    (layer_norm frontend, pre-LN, 1024-dim: pred_head_final_dim = 1024)."""
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+
+    lengths = [16000, 15000, 12000, 11000, 9000, 8000, 7000, 6000]
+    ds = SyntheticLibriDataset(lengths, batch_size=4, seed=1)
+    for name, tc, pdim in (("fithubert.yaml", TeacherConfig.base("hubert"), 768),
+                           ("fitwav2vec2.yaml", TeacherConfig.base("wav2vec2"), 768),
+                           ("fithubert.yaml", TeacherConfig.large(), 1024)):
+        y = yaml.safe_load(open(os.path.join(ROOT, "conf", name)))
+        y["distiller"].update(encoder_layers=3, pred_head_final_dim=pdim)
+        y["train"].update(distil_random_layer=2, accumulate_grad_batches=2)
+        tc.encoder_layers = 4
+        task = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=tc, seed=0, teacher_native_frontend=True)
+        task.configure_optimizers(num_training_steps=20)
+        assert int(task.teacher_layer[-1]) == 3  # the last student layer is distilled from the teacher's LAST layer
+        vals = []
+        for i in range(4):
+            b = {k: v.to(DEV) for k, v in ds[i % 2].items()}
+            out = task.training_step(b, batch_idx=i, next_batch={k: v.to(DEV) for k, v in ds[(i + 1) % 2].items()})
+            vals.append(out[-1].item())
+        assert all(v == v and v < 1e4 for v in vals), vals      # finite
+        assert task.opt_step == 2                                # accumulate_grad_batches = 2
+        # padded frames are zeroed before the positional conv exactly as the oracle does (eval forward of a padded bucket)
+        task.student_model.eval()
+        b = ds[0]
+        with torch.no_grad():
+            res = task.student_model(b["x"].to(DEV), b["padding_mask"].to(DEV))
+        sd = {k: v.detach().float().cpu() for k, v in task.student_model.state_dict().items()}
+        with torch.no_grad():
+            ref = S.student_forward(sd, y["distiller"], b["x"], b["padding_mask"])
+        assert torch.equal(res["padding_mask"].cpu(), ref["padding_mask"])
+        assert _rel_l2(res["x"].float(), ref["x"]) < 3e-2
