@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("FH_BENCH_BATCH", "64")), help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FH_BENCH_BATCH", "128")), help="utterances per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "float32"])
     ap.add_argument("--config", default=os.path.join(ROOT, "conf", "fithubert.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,11 +142,24 @@ def main():
         ach = fl[v] / (ms[v] * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
                 "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
-                "kernel": f"gemm_kernel<{VARIANTS[v]}>", "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
+                "kernel": f"gemm32_kernel<{VARIANTS[v]}>" if args.dtype == "bf16" else f"gemm_kernel<{VARIANTS[v]}>", "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
                 "avg_gflop_per_launch": round(fl[v] / ln[v] / 1e9, 3),
                 "all_gemm": {"achieved": round(sum(fl) / (tot_ms * 1e-3) / 1e12, 2), "launches": int(sum(ln)),
                              "ms_per_step": round(tot_ms / max(1, min(args.prof_steps, args.steps)), 3)},
                 "note": "HIP events around every GEMM launch during the last %d timed steps" % min(args.prof_steps, args.steps)}
+
+    if roof is not None:
+        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE;
+        # MI355X_MICROARCH.md "HBM"), per launch; collected by tools/pmc_summary.py, not live
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            ent = pmc.get("variants", {}).get(roof["kernel"])
+            if ent and pmc.get("batch") == B:
+                roof["traffic"] = ent["bytes_per_launch"]
+                roof["traffic_note"] = pmc.get("note")
+        except Exception:
+            pass
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
         s[kb][1] = mma(a, qf[1][ks], s[kb][1]);
       }
     }
+    const bool tail = kt0 + 64 > klen;  // wave-uniform: only the last tile needs the key mask
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int query = q0 + 16 * qt + r;
@@ -204,13 +205,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int key = kt0 + 16 * kb + 4 * q + e;
-          float v = s[kb][qt][e] * scale_log2e;
-          if (key >= klen) v = -INFINITY;
+          float v = s[kb][qt][e];
+          if (tail && kt0 + 16 * kb + 4 * q + e >= klen) v = -INFINITY;
           s[kb][qt][e] = v;
           mx = fmaxf(mx, v);
         }
-      mx = xor_max(mx);
+      mx = xor_max(mx) * scale_log2e;  // scale > 0: max commutes with it; the per-element scaling rides in the fma below
       const float mnew = fmaxf(m[qt], mx);
       const float alpha = exp2f(m[qt] - mnew);
       m[qt] = mnew;
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = exp2f(s[kb][qt][e] - mnew);
+          const float p = exp2f(fmaf(s[kb][qt][e], scale_log2e, -mnew));
           rs += p;
           s[kb][qt][e] = p;
         }
@@ -231,12 +231,17 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
         for (int e = 0; e < 4; ++e) o[qt][dt][e] *= alpha;
       if (drop.p > 0.f) {
         const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
-        const DropKey dk = drop_key(drop, (uint32_t)(rowbase >> 32));  // (rows never straddle a 2^32 boundary in practice;
-        const uint32_t lo = (uint32_t)rowbase;                         //  a carry only changes which mask is drawn, identically in fwd/bwd)
+        const DropKey dk = drop_key(drop, (uint32_t)(rowbase >> 32));
+        const uint32_t lo = (uint32_t)rowbase;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s[kb][qt][e] *= drop_apply(dk, lo + 16 * kb + 4 * q + e);
+          for (int e = 0; e < 4; e += 2) {
+            float d0, d1;
+            drop_pair(dk, lo + 16 * kb + 4 * q + e, d0, d1);
+            s[kb][qt][e] *= d0;
+            s[kb][qt][e + 1] *= d1;
+          }
       }
     }
 #pragma unroll
@@ -358,13 +363,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
           const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
           const DropKey dk = drop_key(drop, (uint32_t)(rowbase >> 32));
           const uint32_t lo = (uint32_t)rowbase;
+          float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+          if (drop.p > 0.f) {
+            drop_pair(dk, lo + 16 * kb + 4 * q, dsc[0], dsc[1]);
+            drop_pair(dk, lo + 16 * kb + 4 * q + 2, dsc[2], dsc[3]);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int key = kt0 + 16 * kb + 4 * q + e;
-            float p = key < klen ? exp2f(s[qt][e] * scale_log2e - L2[qt]) : 0.f;
-            float g = dp[qt][e];
-            if (drop.p > 0.f) g *= drop_apply(dk, lo + 16 * kb + 4 * q + e);
-            ds[half][qt][e] = p * (g - dl[qt]) * scale;
+            float p = key < klen ? exp2f(fmaf(s[qt][e], scale_log2e, -L2[qt])) : 0.f;
+            ds[half][qt][e] = p * (dp[qt][e] * dsc[e] - dl[qt]) * scale;
           }
         }
       }
@@ -486,7 +494,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
               // same (key-tile-relative) split of the index as the forward: hi word of (row base + tile start), lo + offset
               const int kt0 = key & ~63;
               const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
-              dsc = drop_apply(drop_key(drop, (uint32_t)(rowbase >> 32)), (uint32_t)rowbase + (key - kt0));
+              dsc = drop_pair_one(drop_key(drop, (uint32_t)(rowbase >> 32)), (uint32_t)rowbase + (key - kt0));
             }
             pd[half][kt][e] = p * dsc;
             ds[half][kt][e] = p * (dp[kt][e] * dsc - Dls[ql]) * scale;

@@ -160,6 +160,19 @@ __device__ __forceinline__ float drop_apply(const DropKey& k, uint32_t idx_lo) {
 __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
   return drop_apply(drop_key(d, (uint32_t)(idx >> 32)), (uint32_t)idx);
 }
+// Pair form (attention probabilities): ONE hash serves the two adjacent even/odd indices, 16 random bits each
+// (keep <=> 16 bits >= p * 2^16).  `idx_lo_even` must be even; s0 / s1 are the scales of idx_lo_even and idx_lo_even + 1.
+__device__ __forceinline__ void drop_pair(const DropKey& k, uint32_t idx_lo_even, float& s0, float& s1) {
+  const uint32_t h = fh_mix32(idx_lo_even ^ k.k);
+  const uint32_t t16 = k.thresh >> 8;
+  s0 = (h & 0xffffu) >= t16 ? k.inv_keep : 0.0f;
+  s1 = (h >> 16) >= t16 ? k.inv_keep : 0.0f;
+}
+__device__ __forceinline__ float drop_pair_one(const DropKey& k, uint32_t idx_lo) {
+  const uint32_t h = fh_mix32((idx_lo & ~1u) ^ k.k);
+  const uint32_t u = (idx_lo & 1u) ? (h >> 16) : (h & 0xffffu);
+  return u >= (k.thresh >> 8) ? k.inv_keep : 0.0f;
+}
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
