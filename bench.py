@@ -148,6 +148,30 @@ def main():
                              "ms_per_step": round(tot_ms / max(1, min(args.prof_steps, args.steps)), 3)},
                 "note": "HIP events around every GEMM launch during the last %d timed steps" % min(args.prof_steps, args.steps)}
 
+    # ---- the same measurement with nothing else on the device: 2 extra steps AFTER the timed region with the teacher on
+    # the main stream (no concurrent kernels), so the per-launch durations are the GEMM's own rather than its share of
+    # a GPU it splits with the teacher's rocBLAS kernels.  Reported beside the live figure, never instead of it.
+    if roof is not None and args.prof_steps > 0:
+        side = task.teacher_stream
+        task.teacher_stream, task._next_teacher = None, None
+        torch.cuda.synchronize()
+        lib.fh_prof_enable(1)
+        for j in range(2):
+            task.training_step(pool[j % 4], batch_idx=total_steps + j, next_batch=None)
+        lib.fh_prof_enable(0)
+        torch.cuda.synchronize()
+        task.teacher_stream = side
+        ms2, fl2, ln2 = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_long * 8)()
+        lib.fh_prof_collect(ms2, fl2, ln2)
+        if ms2[v] > 0:
+            ach2 = fl2[v] / (ms2[v] * 1e-3) / 1e12
+            roof["isolated"] = {"achieved": round(ach2, 2), "frac": round(ach2 / roof["peak"], 4),
+                                "avg_launch_us": round(ms2[v] / ln2[v] * 1e3, 2), "launches": int(ln2[v]),
+                                "all_gemm_achieved": round(sum(fl2) / (sum(ms2) * 1e-3) / 1e12, 2),
+                                "note": "2 untimed steps after the timed region, teacher serialised on the same stream "
+                                        "(no concurrent kernels): the kernel's own rate; 'achieved' above is its rate while "
+                                        "sharing CUs with the overlapped teacher forward"}
+
     if roof is not None:
         # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE;
         # MI355X_MICROARCH.md "HBM"), per launch; collected by tools/pmc_summary.py, not live

@@ -106,12 +106,14 @@ _ENGINE_SIGS = {
 SIGNATURES = {
     "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
     "fh_gemm_set_path": (_I, [_I]),
+    "fh_gemm_tune": (_I, [_I]),
     "fh_prof_enable": (_I, [_I]),
     "fh_prof_collect": (_I, [_P, _P, _P]),
     "fh_conv0_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
     "fh_conv0_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fh_conv0_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fh_layernorm_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _F, Drop, _P]),
+    "fh_add_layernorm_forward": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "fh_layernorm_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, Drop, Drop, _P]),
     "fh_colsum": (_I, [_I, _P, _P, _I, _I, _L, _I, _L, _L, _I, _F, _P]),
     "fh_posconv_prepare": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

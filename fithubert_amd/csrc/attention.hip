@@ -134,8 +134,8 @@ __device__ __forceinline__ float xor_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int NDT>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+template <typename T, int NDT, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const int* __restrict__ key_len, int B,
                                                        int Tn, int H, int dh, float scale_log2e, DropCfg drop, int resident) {
   // resident != 0: ALL key/value tiles of this (batch, head) are staged once (T <= 512 bf16 / 320 fp32 fits the 160 KiB
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
   constexpr int NK = AT<T>::NK;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
   const int D = H * dh;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
@@ -270,8 +270,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <typename T, int NDT>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+template <typename T, int NDT, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                           const T* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, T* __restrict__ dqkv,
                                                           const int* __restrict__ key_len, int B, int Tn, int H, int dh,
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
   constexpr int VEC = ElemTraits<T>::VEC;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
   const int D = H * dh;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
@@ -398,8 +398,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <typename T, int NDT>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+template <typename T, int NDT, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            T* __restrict__ dqkv, const int* __restrict__ key_len, int B,
                                                            int Tn, int H, int dh, float scale, float scale_log2e,
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
   constexpr int NK = AT<T>::NK;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128 + wave * 32;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * (32 * NW) + wave * 32;
   const int D = H * dh;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
@@ -528,9 +528,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
   }
 }
 
-int check_dims(int dtype, int H, int dh) {
+int check_dims(int dtype, int H, int dh, int dh_max = 48) {
   const int vec = dtype == 0 ? 4 : 8;
-  if (dh % vec || dh % 4 || dh > 48 || H <= 0) return -601;  // NDT = 3 build covers dh <= 48 (student dh = 40)
+  if (dh % vec || dh % 4 || dh > dh_max || H <= 0) return -601;  // NDT = 3 builds cover dh <= 48 (student dh = 40)
   return 0;
 }
 
@@ -552,57 +552,95 @@ template <typename K> void set_lds(K kernel, size_t bytes) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Workgroup width.  Resident mode keeps every K/V (or Q/dO) tile of one (batch, head) in LDS, which leaves room for ONE
+// workgroup per CU: with 4 waves that is one wave per SIMD and every LDS / shuffle / exp latency is exposed.  16 waves
+// (512 queries) per workgroup share the same resident tiles -- 4 waves per SIMD at <= 128 VGPRs.
+template <typename T, int NDT, int NW>
+int fwd_launch_t(const T* qkv, T* out, float* lse, const int* key_len, int B, int Tn, int H, int dh, float sl2, fh_drop drop,
+                 int res, hipStream_t st) {
+  dim3 grid((Tn + 32 * NW - 1) / (32 * NW), H, B), block(NW * 64);
+  const size_t smem = (size_t)(res ? res : 1) * 2 * 64 * AT<T>::RS;
+  set_lds(attn_fwd_kernel<T, NDT, NW>, smem);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NDT, NW>), grid, block, smem, st, qkv, out, lse, key_len, B, Tn, H, dh, sl2, drop, res);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+template <typename T, int NDT, int NW>
+int bwd_launch_t(const T* qkv, const T* out, const T* dout, const float* lse, float* delta, T* dqkv, const int* key_len, int B,
+                 int Tn, int H, int dh, float scale, float sl2, fh_drop drop, int res, hipStream_t st) {
+  dim3 grid((Tn + 32 * NW - 1) / (32 * NW), H, B), block(NW * 64);
+  const size_t s1 = (size_t)(res ? res : 1) * 2 * 64 * AT<T>::RS, s2 = (size_t)(res ? res : 1) * (2 * 64 * AT<T>::RS + 512);
+  set_lds(attn_bwd_dq_kernel<T, NDT, NW>, s1);
+  set_lds(attn_bwd_dkv_kernel<T, NDT, NW>, s2);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NDT, NW>), grid, block, s1, st, qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh,
+                     scale, sl2, drop, res);
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NDT, NW>), grid, block, s2, st, qkv, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale,
+                     sl2, drop, res);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+int wide_waves(int res, int Tn, int max_nw = 16) {  // waves per workgroup: FH_ATTN_WAVES = 4 | 8 | 16 overrides
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("FH_ATTN_WAVES");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 4 || forced == 8 || forced == 16) return forced;
+  if (!res) return 4;
+  const int nw = Tn > 256 ? 16 : (Tn > 128 ? 8 : 4);
+  return nw < max_nw ? nw : max_nw;
+}
 }  // namespace
 
 int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int Tn, int H,
                             int dh, float scale, fh_drop drop, hipStream_t st) {
-  if (int rc = check_dims(dtype, H, dh)) return rc;
-  dim3 grid((Tn + 127) / 128, H, B), block(256);
+  // forward-only NDT = 4 build in bf16: the frozen teacher's 64-wide heads (HuBERT Base 768 / 12, Large 1024 / 16)
+  if (int rc = check_dims(dtype, H, dh, dtype == 0 ? 48 : 64)) return rc;
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype == 0) {
     const int res = resident_tiles<float>(Tn);
-    const size_t smem = (size_t)(res ? res : 1) * 2 * 64 * AT<float>::RS;
-    set_lds(attn_fwd_kernel<float, 3>, smem);
-    hipLaunchKernelGGL((attn_fwd_kernel<float, 3>), grid, block, smem, st, (const float*)qkv, (float*)out, lse, key_len, B, Tn, H,
-                       dh, sl2, drop, res);
-  } else {
-    const int res = resident_tiles<bf16>(Tn);
-    const size_t smem = (size_t)(res ? res : 1) * 2 * 64 * AT<bf16>::RS;
-    set_lds(attn_fwd_kernel<bf16, 3>, smem);
-    hipLaunchKernelGGL((attn_fwd_kernel<bf16, 3>), grid, block, smem, st, (const bf16*)qkv, (bf16*)out, lse, key_len, B, Tn, H, dh,
-                       sl2, drop, res);
+    const float* q = (const float*)qkv;
+    switch (wide_waves(res, Tn)) {
+      case 16: return fwd_launch_t<float, 3, 16>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+      case 8: return fwd_launch_t<float, 3, 8>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+      default: return fwd_launch_t<float, 3, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+    }
   }
-  FH_CHECK_LAUNCH();
-  return 0;
+  const int res = resident_tiles<bf16>(Tn);
+  const bf16* q = (const bf16*)qkv;
+  const int nw = wide_waves(res, Tn);
+  if (dh > 48) {
+    switch (nw) {
+      case 16: return fwd_launch_t<bf16, 4, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+      case 8: return fwd_launch_t<bf16, 4, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+      default: return fwd_launch_t<bf16, 4, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+    }
+  }
+  switch (nw) {
+    case 16: return fwd_launch_t<bf16, 3, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+    case 8: return fwd_launch_t<bf16, 3, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+    default: return fwd_launch_t<bf16, 3, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+  }
 }
 
 int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                             float* delta, void* dqkv, const int* key_len, int B, int Tn, int H, int dh, float scale,
                             fh_drop drop, hipStream_t st) {
   if (int rc = check_dims(dtype, H, dh)) return rc;
-  dim3 grid((Tn + 127) / 128, H, B), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype == 0) {
     const int res = resident_tiles<float>(Tn);
-    const size_t s1 = (size_t)(res ? res : 1) * 2 * 64 * AT<float>::RS, s2 = (size_t)(res ? res : 1) * (2 * 64 * AT<float>::RS + 512);
-    set_lds(attn_bwd_dq_kernel<float, 3>, s1);
-    set_lds(attn_bwd_dkv_kernel<float, 3>, s2);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<float, 3>), grid, block, s1, st, (const float*)qkv, (const float*)out,
-                       (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
-    FH_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 3>), grid, block, s2, st, (const float*)qkv, (const float*)dout, lse, delta,
-                       (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
-  } else {
-    const int res = resident_tiles<bf16>(Tn);
-    const size_t s1 = (size_t)(res ? res : 1) * 2 * 64 * AT<bf16>::RS, s2 = (size_t)(res ? res : 1) * (2 * 64 * AT<bf16>::RS + 512);
-    set_lds(attn_bwd_dq_kernel<bf16, 3>, s1);
-    set_lds(attn_bwd_dkv_kernel<bf16, 3>, s2);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16, 3>), grid, block, s1, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
-                       lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
-    FH_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 3>), grid, block, s2, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
-                       (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res);
+    switch (wide_waves(res, Tn, 8)) {
+      case 16: return bwd_launch_t<float, 3, 16>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+      case 8: return bwd_launch_t<float, 3, 8>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+      default: return bwd_launch_t<float, 3, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+    }
   }
-  FH_CHECK_LAUNCH();
-  return 0;
+  const int res = resident_tiles<bf16>(Tn);
+  switch (wide_waves(res, Tn, 8)) {  // the 16-wave backward builds spill under the 128-VGPR cap
+    case 16: return bwd_launch_t<bf16, 3, 16>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+    case 8: return bwd_launch_t<bf16, 3, 8>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+    default: return bwd_launch_t<bf16, 3, 4>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+  }
 }

@@ -8,6 +8,7 @@
 // (output row i) the MFMA "B" matrix, so a lane's 4 accumulator registers are 4 CONSECUTIVE j
 // of one output row -> 8/16-byte vector stores and vector bias/residual loads in the epilogue.
 #include <cstdlib>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -823,6 +824,270 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
   gemm_epilogue_staged<bf16>(p, acc, lds, i0, j0, xi0, yj0, lane, wave, g);
 }
 
+// ------------------------------------------------------------------ bf16 main loop, large tiles (LDS-DMA ring, 16x16x32 MFMA)
+// The 128x128 loops above re-read every operand element from LDS once per 64 output columns / rows of a wave and keep
+// 3-4 small workgroups per CU; on the student's compute-bound shapes they sit at 0.4-0.6 PFLOP/s.  This loop follows the
+// guide's large-tile recipe instead: a 256 x 256 (or 256 x 128) output tile, each wave owning 128 x 64 of it (128 fp32
+// accumulators per lane, half the LDS bytes per flop), operands streamed HBM -> LDS by global_load_lds_dwordx4 into an
+// NST-deep ring with a counted vmcnt and ONE raw s_barrier per K-tile, no staging VGPRs and no ds_write at all.
+//   R_CONTIG image : 16-row x 32-k sub-tiles of 1 KiB, one per wave instruction, st_16x32 swizzle (16-B chunk c of row r at
+//                    chunk c ^ ((r >> 3) << 1)): ds_read_b128 of an MFMA fragment touches 16 distinct 16-B bank slots per group.
+//   R_STRIDED image: [32 k][128 cols] blocks of 8 KiB (256-B k-rows, chunk c at c ^ strided_key(k)), read transposed with
+//                    ds_read_b64_tr_b16 exactly as in the 128-tile DMA loop above.
+// Out-of-range rows / columns / reduction indices fetch from a 16-byte zero chunk, so the K tail needs no masking.
+template <int LAYOUT, int ROWS, int BK_, int NW> struct RingLoader;
+
+template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_CONTIG, ROWS, BK_, NW> {
+  static constexpr int KS = BK_ / 32;             // 32-k sub-tiles per row tile
+  static constexpr int NI = ROWS / 16 * KS / NW;  // wave instructions per K-tile
+  static constexpr int NR = NI / KS;              // distinct rows per lane
+  static constexpr int TILE = ROWS * BK_ * 2;
+  static_assert(NI >= KS && NI % KS == 0, "tile too small for this wave count");
+  const bf16* base;
+  long off[NR];
+  long segdelta;
+  unsigned vmask;
+  int kch;  // logical k-chunk (8 elements) of this lane inside a sub-tile
+  int wave;
+  const unsigned char* ptr[NI];
+  int step[NI];
+  __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid) {
+    base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
+    wave = tid >> 6;
+    const int lane = tid & 63, r = lane >> 2;
+    kch = (lane & 3) ^ ((r >> 3) << 1);
+    vmask = 0;
+    segdelta = (long)(o.tshift[1] - o.tshift[0]) * o.ld + (o.segoff[1] - o.segoff[0]);
+#pragma unroll
+    for (int ur = 0; ur < NR; ++ur) {
+      const int idx = idx0 + (wave * NR + ur) * 16 + r;
+      const bool rv = idx < idx_limit;
+      RowMap rm = map_row(rv ? idx : 0, o.rpb);
+      off[ur] = (long)rm.b * o.bstride + (long)(rm.t + o.tshift[0]) * o.ld + o.segoff[0];
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        const int ts = rm.t + o.tshift[sg];
+        const bool v = rv && (sg < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid));
+        vmask |= (v ? 1u : 0u) << (2 * ur + sg);
+      }
+    }
+  }
+  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {  // slow path
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int ur = u / KS, ks = u % KS;
+      const int k = k0 + ks * 32 + kch * 8;
+      const bool v = (k < Kseg) && ((vmask >> (2 * ur + seg)) & 1u);
+      ptr[u] = v ? (const unsigned char*)(base + off[ur] + (long)seg * segdelta + k) : (const unsigned char*)g_zero_chunk;
+      step[u] = v ? BK_ * 2 : 0;
+    }
+  }
+  __device__ __forceinline__ void set_zero() {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      ptr[u] = (const unsigned char*)g_zero_chunk;
+      step[u] = 0;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * NI + u) * 1024), 16, 0, 0);
+      ptr[u] += step[u];
+    }
+  }
+  // fragment of row tile `row0 / 16`, k-step ks: lane (r = lane & 15, q = lane >> 4) gets k = 32 ks + 8 q .. + 7 of row r
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row0, int ks, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(tile + ((row0 >> 4) * KS + ks) * 1024 + r * 64 + ((q ^ ((r >> 3) << 1)) << 4));
+  }
+};
+
+template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_STRIDED, ROWS, BK_, NW> {
+  static constexpr int KB = BK_ / 32;                    // 32-k blocks per K-tile
+  static constexpr int NI = (ROWS / 128) * KB * 8 / NW;  // wave instructions per K-tile (4 k-rows x 256 B each)
+  static constexpr int TILE = ROWS * BK_ * 2;
+  static_assert(NI >= 1 && ((ROWS / 128) * KB * 8) % NW == 0, "tile too small for this wave count");
+  const bf16* base;
+  int col[NI];
+  int kt[NI];  // reduction row inside the K-tile
+  unsigned cvalid;
+  int wave;
+  const unsigned char* ptr[NI];
+  int tcur[NI];
+  long step;   // bytes per K-tile
+  long wrap;   // extra bytes when the mapped row index crosses a batch item
+  int rpb;
+  __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid) {
+    base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
+    wave = tid >> 6;
+    const int lane = tid & 63;
+    cvalid = 0;
+    rpb = o.rpb;
+    step = (long)BK_ * o.ld * 2;
+    wrap = (o.bstride - (long)o.rpb * o.ld) * 2;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int si = wave * NI + u, blk = si >> 3, within = si & 7;
+      const int mp = blk / KB, kb = blk % KB;
+      const int klb = within * 4 + (lane >> 4);
+      kt[u] = kb * 32 + klb;
+      const int c = (lane & 15) ^ strided_key(klb);
+      col[u] = idx0 + mp * 128 + c * 8;
+      cvalid |= (col[u] < idx_limit ? 1u : 0u) << u;
+    }
+  }
+  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {  // slow path
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int r = k0 + kt[u];
+      ptr[u] = (const unsigned char*)g_zero_chunk;
+      tcur[u] = -1;  // < 0: this lane stays on the zero chunk
+      if (((cvalid >> u) & 1u) && r < Kseg) {
+        RowMap rm = map_row(r, o.rpb);
+        ptr[u] = (const unsigned char*)(base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col[u]);
+        tcur[u] = rm.t;
+      }
+    }
+  }
+  __device__ __forceinline__ void set_zero() {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      ptr[u] = (const unsigned char*)g_zero_chunk;
+      tcur[u] = -1;
+    }
+  }
+  __device__ __forceinline__ void issue(unsigned char* tile) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * NI + u) * 1024), 16, 0, 0);
+      if (tcur[u] >= 0) {
+        ptr[u] += step;
+        if (rpb > 0) {
+          tcur[u] += BK_;
+          if (tcur[u] >= rpb) {  // requires rpb >= BK (checked on the host)
+            tcur[u] -= rpb;
+            ptr[u] += wrap;
+          }
+        }
+      }
+    }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row0, int ks, int lane) {
+    return frag_dma<FH_R_STRIDED>(tile + ((row0 >> 7) * KB + ks) * 8192, row0 & 127, lane);
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int XL, int YL, int BM_, int BN_, int WM, int WN, int BK_, int NST>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MT = TM / 16, NT = TN / 16, KS = BK_ / 32;
+  typedef RingLoader<XL, BM_, BK_, NW> LX;
+  typedef RingLoader<YL, BN_, BK_, NW> LY;
+  constexpr int STAGE = LX::TILE + LY::TILE;
+  constexpr int LPT = LX::NI + LY::NI;  // LDS-DMA instructions per lane per K-tile
+  static_assert(TM % 32 == 0 && TN % 64 == 0, "epilogue passes are 32 rows x 64 columns per wave");
+  static_assert(NST * STAGE >= NW * EPI_WAVE, "ring smaller than the epilogue staging area");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.z;
+  const int tiles_j = (p.N + BN_ - 1) / BN_;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
+  const int i0 = ti * BM_, j0 = tj * BN_;
+  const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
+  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
+  const int t0 = blockIdx.y * per_split;
+  const int t1 = min(ntiles, t0 + per_split);
+  if (t0 >= t1) return;
+  const int nt = t1 - t0;
+
+  LX lx;
+  LY ly;
+  lx.init(p.X, g, i0, p.M, tid);
+  ly.init(p.Y, g, j0, p.N, tid);
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xi0 = (wave % WM) * TM, yj0 = (wave / WM) * TN;
+
+  int is_seg = t0 / tiles_per_seg;
+  int is_k0 = (t0 - is_seg * tiles_per_seg) * BK_;
+  int issued = 0;
+  bool need_slow = true;
+  auto issue_next = [&](int stage) {
+    unsigned char* st = lds + stage * STAGE;
+    if (issued == nt) {  // pipeline drain: harmless zero-chunk loads keep the vmcnt bookkeeping uniform
+      lx.set_zero();
+      ly.set_zero();
+    } else if (issued < nt) {
+      const bool partial = is_k0 + BK_ > p.Kseg;
+      if (need_slow || partial) {
+        lx.set_tile(p.X, is_seg, is_k0, p.Kseg);
+        ly.set_tile(p.Y, is_seg, is_k0, p.Kseg);
+      }
+      is_k0 += BK_;
+      need_slow = false;
+      if (is_k0 >= p.Kseg) {
+        is_k0 = 0;
+        is_seg = min(is_seg + 1, 1);
+        need_slow = true;
+      }
+    }
+    lx.issue(st);
+    ly.issue(st + LX::TILE);
+    ++issued;
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue_next(s);
+
+  int stage = 0;
+  for (int it = 0; it < nt; ++it) {
+    // this wave's loads of tile `it` have landed (NST-2 younger tiles may still be in flight) ...
+    wait_vm_barrier<(NST - 2) * LPT>();
+    // ... and after the barrier so have everyone's; the stage read in iteration it-1 is free again: refill it
+    issue_next(stage == 0 ? NST - 1 : stage - 1);
+    const unsigned char* bx = lds + stage * STAGE;
+    const unsigned char* by = bx + LX::TILE;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 fx[MT], fy[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fy[n] = LY::frag(by, yj0 + 16 * n, ks, lane);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fx[m] = LX::frag(bx, xi0 + 16 * m, ks, lane);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
+    }
+    stage = stage == NST - 1 ? 0 : stage + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero-chunk) tail loads before LDS is reused
+  __syncthreads();                                   // every wave is done reading the ring
+  // staged epilogue, wave-local from here on (each wave owns its staging rows): passes of 32 rows x 64 columns
+  unsigned char* my = lds + wave * EPI_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int cb = 0; cb < TN / 64; ++cb)
+#pragma unroll
+    for (int h = 0; h < TM / 32; ++h) {
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[cb * 4 + n][2 * h + mm];
+      epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0 + 64 * cb, lane, g);
+    }
+}
+
 template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM - 1) / BM, tiles_j = (p.N + BN - 1) / BN;
   dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(256);
@@ -880,27 +1145,150 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
-// FH_GEMM_PATH=dma selects the LDS-DMA main loop for bf16 (A/B comparisons; see tools/gemm_bench.py)
-int g_gemm_path = -1;  // -1: from env FH_GEMM_PATH; 0: 16x16x32 register staging; 1: 16x16x32 LDS-DMA ring; 2: 32x32x16 register staging (default)
+template <int BM_, int BN_, int WM, int WN, int BK_, int NST> int launch_ring(const GemmParams& p, hipStream_t stream) {
+  const int tiles_i = (p.M + BM_ - 1) / BM_, tiles_j = (p.N + BN_ - 1) / BN_;
+  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(WM * WN * 64);
+  const size_t smem = (size_t)NST * (BM_ + BN_) * BK_ * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_ring_kernel<FH_R_CONTIG, FH_R_CONTIG, BM_, BN_, WM, WN, BK_, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_ring_kernel<FH_R_CONTIG, FH_R_STRIDED, BM_, BN_, WM, WN, BK_, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_ring_kernel<FH_R_STRIDED, FH_R_CONTIG, BM_, BN_, WM, WN, BK_, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_ring_kernel<FH_R_STRIDED, FH_R_STRIDED, BM_, BN_, WM, WN, BK_, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int xl = p.X.layout, yl = p.Y.layout;
+  if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_ring_kernel<FH_R_CONTIG, FH_R_CONTIG, BM_, BN_, WM, WN, BK_, NST>), grid, block, smem, stream, p);
+  else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
+    hipLaunchKernelGGL((gemm_ring_kernel<FH_R_CONTIG, FH_R_STRIDED, BM_, BN_, WM, WN, BK_, NST>), grid, block, smem, stream, p);
+  else if (xl == FH_R_STRIDED && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_ring_kernel<FH_R_STRIDED, FH_R_CONTIG, BM_, BN_, WM, WN, BK_, NST>), grid, block, smem, stream, p);
+  else
+    hipLaunchKernelGGL((gemm_ring_kernel<FH_R_STRIDED, FH_R_STRIDED, BM_, BN_, WM, WN, BK_, NST>), grid, block, smem, stream, p);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+bool ring_ok(const GemmParams& p, int bk) {
+  if (p.X.layout == FH_R_STRIDED && p.X.rpb > 0 && p.X.rpb < bk) return false;
+  if (p.Y.layout == FH_R_STRIDED && p.Y.rpb > 0 && p.Y.rpb < bk) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------ bf16 main-loop selection
+// g_gemm_path: 0 = 16x16x32 register staging, 1 = 128-tile LDS-DMA ring, 2 = 32x32x16 register staging, 3 = 256x256 ring
+// (BK 64, 2 stages), 4 = 256x128 ring (BK 32, 3 stages, 2 workgroups / CU), 5 = 256x256 ring (BK 32, 4 stages),
+// 9 = per-shape choice (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
+// FH_GEMM_PATH = reg | dma | 2..5 forces one loop (A/B comparisons; tools/gemm_bench.py).
+int g_gemm_path = -1;
+int g_tune_mode = 0;
+struct TuneChoice { int path, splitk; };
+std::unordered_map<unsigned long long, TuneChoice> g_tune;
+
 bool dma_ok(const GemmParams& p) {
   if (p.X.layout == FH_R_STRIDED && p.X.rpb > 0 && p.X.rpb < DMA_BK) return false;
   if (p.Y.layout == FH_R_STRIDED && p.Y.rpb > 0 && p.Y.rpb < DMA_BK) return false;
   return true;
 }
-int launch_bf16(const GemmParams& p, hipStream_t stream);
-bool use_dma() {
+void resolve_path() {
   if (g_gemm_path < 0) {
     const char* e = getenv("FH_GEMM_PATH");
-    g_gemm_path = (e && e[0] == 'd') ? 1 : ((e && e[0] == 'r') ? 0 : 2);
+    g_gemm_path = !e ? 9 : (e[0] == 'd' ? 1 : (e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '5') ? e[0] - '0' : 9)));
   }
-  return g_gemm_path == 1;
+}
+int launch_path(const GemmParams& p, int path, hipStream_t stream) {
+  if (path == 1 && dma_ok(p)) return launch_dma(p, stream);
+  if (path == 0) return launch_t<bf16>(p, stream);
+  if (path == 3 && ring_ok(p, 64)) return launch_ring<256, 256, 2, 4, 64, 2>(p, stream);
+  if (path == 4 && ring_ok(p, 32)) return launch_ring<256, 128, 2, 2, 32, 3>(p, stream);
+  if (path == 5 && ring_ok(p, 32)) return launch_ring<256, 256, 2, 4, 32, 4>(p, stream);
+  return launch_32(p, stream);
+}
+
+// shape class of a launch: exact in the small dimensions, quarter-octave buckets in the long one(s) (row counts that follow
+// the batch / utterance length), so that length-bucketed batches share their measurements
+int qoct(long v) {
+  if (v <= 4096) return (int)v;
+  int lg = 0;
+  while ((v >> (lg + 1)) > 0) ++lg;
+  return 100000 + lg * 4 + (int)(((v - (1L << lg)) * 4) >> lg);
+}
+unsigned long long tune_key(const GemmParams& p) {
+  unsigned long long h = 1469598103934665603ULL;
+  auto mix = [&](long v) { h = (h ^ (unsigned long long)v) * 1099511628211ULL; };
+  mix(qoct(p.M)); mix(qoct(p.N)); mix(qoct(p.Kseg)); mix(p.X.nseg); mix(p.X.layout); mix(p.Y.layout); mix(p.groups);
+  mix(p.ep.atomic); mix(p.ep.atomic ? 0 : p.splitk);
+  mix(p.ep.preact != nullptr); mix(p.ep.act); mix(p.ep.gelu_aux != nullptr); mix(p.ep.residual != nullptr);
+  return h;
+}
+int ring_splitk(const GemmParams& p, int tm, int tn, int target) {
+  const long tiles = (long)((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn) * p.groups;
+  const long red = (long)p.Kseg * p.X.nseg;
+  long sk = (target + tiles - 1) / tiles;
+  const long maxsk = red / 512 > 0 ? red / 512 : 1;
+  if (sk > maxsk) sk = maxsk;
+  if (sk < 1) sk = 1;
+  if (sk > 256) sk = 256;
+  return (int)sk;
+}
+// Times the candidate loops for this launch's shape class on `stream` (blocking; the output is written / accumulated
+// several times, so only throw-away passes -- StudentEngine.autotune -- may run with tuning on).
+TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
+  std::vector<TuneChoice> cand;
+  cand.push_back({2, p.splitk});
+  auto add = [&](int path, int sk) {
+    for (auto& c : cand)
+      if (c.path == path && c.splitk == sk) return;
+    cand.push_back({path, sk});
+  };
+  const long red = (long)p.Kseg * p.X.nseg;
+  if (red >= 256) {
+    if (p.ep.atomic) {
+      for (int target : {256, 512}) {
+        if (ring_ok(p, 64)) add(3, ring_splitk(p, 256, 256, target));
+        if (ring_ok(p, 32)) add(5, ring_splitk(p, 256, 256, target));
+      }
+      add(2, ring_splitk(p, 128, 128, 1024));
+    } else {
+      if (ring_ok(p, 64)) add(3, p.splitk);
+      if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); }
+    }
+  }
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  TuneChoice best = cand[0];
+  float best_ms = 1e30f;
+  for (auto& c : cand) {
+    GemmParams q = p;
+    q.splitk = c.splitk;
+    if (launch_path(q, c.path, stream) != 0) continue;
+    hipEventRecord(a, stream);
+    launch_path(q, c.path, stream);
+    launch_path(q, c.path, stream);
+    hipEventRecord(b, stream);
+    if (hipEventSynchronize(b) != hipSuccess) continue;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, a, b);
+    if (ms < best_ms) { best_ms = ms; best = c; }
+  }
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return best;
 }
 
 int launch_bf16(const GemmParams& p, hipStream_t stream) {
-  use_dma();  // resolves g_gemm_path from the environment on first use
-  if (g_gemm_path == 1 && dma_ok(p)) return launch_dma(p, stream);
-  if (g_gemm_path == 0) return launch_t<bf16>(p, stream);
-  return launch_32(p, stream);
+  resolve_path();
+  if (g_gemm_path != 9) return launch_path(p, g_gemm_path, stream);
+  const unsigned long long key = tune_key(p);
+  auto it = g_tune.find(key);
+  if (it == g_tune.end()) {
+    if (!g_tune_mode) return launch_32(p, stream);
+    it = g_tune.emplace(key, tune_measure(p, stream)).first;
+  }
+  GemmParams q = p;
+  if (p.ep.atomic) q.splitk = it->second.splitk;
+  return launch_path(q, it->second.path, stream);
 }
 
 }  // namespace
@@ -916,6 +1304,11 @@ bool g_prof_on = false;
 extern "C" int fh_gemm_set_path(int path) {
   g_gemm_path = path;
   return 0;
+}
+extern "C" int fh_gemm_tune(int mode) {
+  if (mode < 0) g_tune.clear();
+  g_tune_mode = mode > 0;
+  return (int)g_tune.size();
 }
 extern "C" int fh_prof_enable(int on) {
   g_prof_on = on != 0;

@@ -18,7 +18,9 @@ template <typename T, int NCH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
-                                                     int C, float eps, DropCfg drop) {
+                                                     int C, float eps, DropCfg drop, const T* __restrict__ res) {
+  // res != nullptr: normalises T(x + res) -- the post-LN residual add of the frozen teacher's layers, rounded to the
+  // storage type first so that the result equals the unfused add-then-LayerNorm
   constexpr int VEC = ElemTraits<T>::VEC;
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
@@ -32,6 +34,22 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
     for (int u = 0; u < NCH; ++u) {
       const int ch = lane + 64 * u;
       if (ch < nchunk) unpack16<T>(ld16(x + (long)row * C + ch * VEC), v[rr][u]);
+    }
+  }
+  if (res) {
+#pragma unroll
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+      const int row = min(row0 + rr, M - 1);
+#pragma unroll
+      for (int u = 0; u < NCH; ++u) {
+        const int ch = lane + 64 * u;
+        if (ch < nchunk) {
+          float a[VEC];
+          unpack16<T>(ld16(res + (long)row * C + ch * VEC), a);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[rr][u][e] = (float)(T)(v[rr][u][e] + a[e]);
+        }
+      }
     }
   }
   float gm[NCH][VEC], bt[NCH][VEC];
@@ -252,17 +270,17 @@ __global__ void zero_rows_kernel(T* x, int B, int Tn, int C, int from) {
 
 template <typename T>
 int ln_fwd_t(const T* x, const float* g, const float* b, T* y, float* mean, float* rstd, int M, int C, float eps,
-             DropCfg drop, hipStream_t st) {
+             DropCfg drop, hipStream_t st, const T* res = nullptr) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return -301;
   const int nch = (C / VEC + 63) / 64;
   dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
   if (nch == 1)
-    hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop);
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res);
   else if (nch == 2)
-    hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop);
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res);
   else if (nch <= 4)
-    hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop);
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res);
   else
     return -302;
   FH_CHECK_LAUNCH();
@@ -301,6 +319,14 @@ int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const 
   if (M <= 0) return 0;
   return dtype == 0 ? ln_fwd_t<float>((const float*)x, gamma, beta, (float*)y, mean, rstd, M, C, eps, drop, st)
                     : ln_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, C, eps, drop, st);
+}
+
+int fh_add_layernorm_fwd_launch(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                                int M, int C, float eps, hipStream_t st) {
+  if (M <= 0) return 0;
+  fh_drop nodrop{0.f, 0u, 0u};
+  return dtype == 0 ? ln_fwd_t<float>((const float*)x, gamma, beta, (float*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const float*)res)
+                    : ln_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const bf16*)res);
 }
 
 int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,

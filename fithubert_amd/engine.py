@@ -143,6 +143,10 @@ class StudentEngine:
         self._prepared_version = -1
         self.version = 0
         self.layers = cfg.conv_layers()
+        # per-shape choice of the bf16 GEMM main loop (fh_gemm_tune): measured once per (batch, length class) in a
+        # throw-away forward + backward before the first training step of that shape; FH_GEMM_AUTOTUNE=0 turns it off
+        self.auto_tune = self.c.dtype != L.DT_F32 and os.environ.get("FH_GEMM_AUTOTUNE", "1") != "0"
+        self._tuned = set()
 
     # ------------------------------------------------------------------ parameters
     def param_views(self, flat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -195,6 +199,8 @@ class StudentEngine:
                 seed: int = 0) -> Workspace:
         assert wave.is_cuda and wave.dtype == torch.float32 and wave.dim() == 2 and wave.is_contiguous()
         B, S = wave.shape
+        if training and self.auto_tune and (self._shape_class(B, S) + (bool(heads_on),)) not in self._tuned:
+            self.autotune(B, S, bool(heads_on))
         call = StudentCallC(B, S, int(training), int(heads_on), seed & 0xFFFFFFFF)
         nbytes = self.lib.fh_student_ws_bytes(C.byref(self.c), C.byref(call))
         if nbytes <= 0:
@@ -213,6 +219,32 @@ class StudentEngine:
                                             buf.data_ptr(), wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None,
                                             self.stream()), "fh_student_forward")
         return ws
+
+    @staticmethod
+    def _shape_class(B: int, S: int) -> Tuple[int, int]:
+        lg = max(S, 1).bit_length() - 1
+        return B, lg * 4 + (((S - (1 << lg)) * 4) >> lg)
+
+    def autotune(self, B: int, S: int, heads_on: bool = True) -> int:
+        """Measure the GEMM main-loop candidates for every launch of a training step on [B, S] waveforms: one throw-away
+        forward + backward on noise with fh_gemm_tune(1) (blocking; weight gradients go to a scratch buffer).  Returns the
+        number of shape classes in the library's table."""
+        self._tuned.add(self._shape_class(B, S) + (heads_on,))
+        torch.cuda.synchronize(self.device)
+        self.lib.fh_gemm_tune(1)
+        try:
+            wave = 0.1 * torch.randn(B, S, device=self.device, dtype=torch.float32)
+            ws = self.forward(wave, None, training=True, heads_on=heads_on, seed=12345)
+            scratch = torch.zeros_like(self.grads)
+            if heads_on:
+                self.backward(ws, d_pred=(1e-3 * torch.randn_like(ws.view("pred"), dtype=torch.float32)).to(self.elem), grads=scratch)
+            else:
+                xo = ws.view("xo")[1:]
+                self.backward(ws, d_hidden=(1e-3 * torch.randn_like(xo, dtype=torch.float32)).to(self.elem).contiguous(), grads=scratch)
+            torch.cuda.synchronize(self.device)
+        finally:
+            n = self.lib.fh_gemm_tune(0)
+        return n
 
     def backward(self, ws: Workspace, d_pred: Optional[torch.Tensor] = None, d_hidden: Optional[torch.Tensor] = None,
                  grads: Optional[torch.Tensor] = None) -> None:

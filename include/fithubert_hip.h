@@ -81,7 +81,15 @@ typedef struct {
 int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 /* Optional per-launch HIP-event timing of the GEMM kernel on its own stream (used by bench.py's roofline object).
  * Variants are indexed dtype*4 + X.layout*2 + Y.layout.  collect() waits for the recorded events, sums, and clears. */
-int fh_gemm_set_path(int path); /* bf16 main loop: 0 = 16x16x32 MFMA register staging, 1 = 16x16x32 LDS-DMA ring, 2 = 32x32x16 MFMA register staging (default), -1 = env FH_GEMM_PATH (reg|dma) */
+/* bf16 main loop: 0 = 16x16x32 MFMA register staging (128x128 tile), 1 = 128x128 LDS-DMA ring, 2 = 32x32x16 MFMA register
+ * staging (128x128), 3 / 4 / 5 = large-tile LDS-DMA rings (256x256 BK 64, 256x128 BK 32, 256x256 BK 32), 9 = per-shape choice
+ * (default), -1 = re-read env FH_GEMM_PATH (reg | dma | 2..5). */
+int fh_gemm_set_path(int path);
+/* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
+ * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the
+ * output several times -- only for throw-away passes (StudentEngine.autotune).  mode 0: stop measuring; unmeasured shapes
+ * run path 2.  mode -1: forget the table.  Returns the number of measured shape classes. */
+int fh_gemm_tune(int mode);
 int fh_prof_enable(int on);
 int fh_prof_collect(double* ms /*[8]*/, double* flops /*[8]*/, long* launches /*[8]*/);
 
@@ -108,6 +116,10 @@ int fh_conv0_backward(int dtype, const float* wave, const float* w, const float*
  * ------------------------------------------------------------------------------------------ */
 int fh_layernorm_forward(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                          float* rstd, int M, int C, float eps, fh_drop drop, fh_stream_t stream);
+/* y = LayerNorm(T(x + res)): the post-LN residual add + LayerNorm of the frozen teacher's transformer layers (fairseq
+ * TransformerSentenceEncoderLayer, layer_norm_first = False; reference teacher via utils/utils.py:51-99).  Forward only. */
+int fh_add_layernorm_forward(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                             int M, int C, float eps, fh_stream_t stream);
 int fh_layernorm_backward(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                           const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
                           int M, int C, fh_drop out_drop, fh_drop in_drop, fh_stream_t stream);
@@ -138,6 +150,7 @@ int fh_posconv_weightnorm_backward(const float* g, const float* v, const float* 
  * Multi-head self-attention on packed qkv [B][T][3*H*dh] -> out [B][T][H*dh]; lse [B][H][T] (log2 domain).
  * Replaces fairseq MultiheadAttention called at modules/module.py:558-564 (q scaling, key_padding_mask as
  * per-batch valid key count key_len, fp32 softmax, dropout on probabilities).  Backward writes dqkv.
+ * Head dim: forward dh <= 64 in bf16 (the teacher's 64-wide heads), dh <= 48 in fp32 and for backward.
  * ------------------------------------------------------------------------------------------ */
 int fh_attention_forward(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int T, int H,
                          int dh, float scale, fh_drop drop, fh_stream_t stream);

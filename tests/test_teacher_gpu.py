@@ -27,3 +27,27 @@ def test_native_frontend_matches_torch_path(kind, dtype, tol):
         got = w.hidden_stack(wav, mask).float()
         err = ((got - ref).norm() / ref.norm()).item()
         assert err < tol, (kind, dtype, err)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.bfloat16, 4e-2)])
+def test_native_transformer_layers_match_torch_path(dtype, tol):
+    """Post-LN layers on the HIP path (fused q|k|v, attention kernel, add+LayerNorm, fc1+GELU epilogue) against the
+    nn.Module layers, on a narrow teacher whose 32-wide heads the fp32 attention build covers; right-padded batch."""
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers, tc.encoder_embed_dim, tc.encoder_ffn_embed_dim, tc.encoder_attention_heads = 3, 384, 1024, 12
+    w = build_teacher(tc, seed=5, dtype=dtype, device=DEV)
+    g = torch.Generator().manual_seed(1)
+    wav = (0.3 * torch.randn(3, 24000, generator=g)).to(DEV)
+    pm = torch.zeros(3, 24000, dtype=torch.bool, device=DEV)
+    pm[1, 15000:] = True
+    pm[2, 20000:] = True
+    wav[pm] = 0
+    for mask in (None, pm):
+        w.model.enable_native_frontend(False)
+        ref = w.extract_features(wav, mask)
+        w.model.enable_native_frontend(True)
+        got = w.extract_features(wav, mask)
+        assert w.model._native.layers_native
+        for (xr, (_, fr)), (xg, (_, fg)) in zip(ref["layer_results"], got["layer_results"]):
+            assert ((xg.float() - xr.float()).norm() / xr.float().norm()).item() < tol
+            assert ((fg.float() - fr.float()).norm() / fr.float().norm()).item() < tol

@@ -10,10 +10,18 @@ lib = L.lib()
 st = lambda: torch.cuda.current_stream().cuda_stream
 bf = torch.bfloat16
 
-def run(name, d, flops, bytes_, n=20):
+PATHS = [int(x) for x in os.environ.get("PATHS", "2,3,4,5").split(",")]
+TILE = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (256, 256), 4: (256, 128), 5: (256, 256)}
+
+def run(name, d, flops, bytes_, n=20, wg=None):
     res = []
-    for path in (0, 2):
+    for path in PATHS:
         lib.fh_gemm_set_path(path)
+        if wg is not None:  # weight-gradient shape: split the reduction so that ~512 workgroups exist
+            N_, K_, Mred, groups = wg
+            tm, tn = TILE[path]
+            tiles = -(-N_ // tm) * -(-K_ // tn) * groups
+            d.splitk = max(1, min(-(-512 // tiles), Mred // 512, 256))
         for _ in range(3):
             L.check(lib.fh_gemm(d, 1, st()), name)
         torch.cuda.synchronize()
@@ -24,7 +32,7 @@ def run(name, d, flops, bytes_, n=20):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         res.append(us)
-    print(f"{name:42s} reg {res[0]:8.1f} us {flops/res[0]/1e6:7.1f} TF/s {bytes_/res[0]/1e3:6.0f} GB/s | mfma32 {res[1]:8.1f} us {flops/res[1]/1e6:7.1f} TF/s {bytes_/res[1]/1e3:6.0f} GB/s", flush=True)
+    print(f"{name:44s} " + " | ".join(f"p{pa} {us:7.1f}us {flops/us/1e6:6.0f}TF" for pa, us in zip(PATHS, res)) + f" | {bytes_/1e6:7.0f} MB", flush=True)
 
 def lin(M, N, K, groups=1):
     X = torch.randn(groups, M, K, device=dev).to(bf); W = torch.randn(groups, N, K, device=dev).to(bf)
@@ -54,7 +62,7 @@ def wgrad(N, K, Mred, groups, splitk):
     d.X = L.operand(dC.data_ptr(), 1, N, gstride=Mred * N); d.Y = L.operand(A.data_ptr(), 1, K, gstride=Mred * K)
     d.C = dW.data_ptr(); d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk, d.c_gstride = N, K, Mred, K, groups, splitk, N * K
     d.ep = L.epilogue(atomic=1)
-    run(f"wgrad SS N={N} K={K} Mred={Mred} g={groups} sk={splitk}", d, 2.0 * N * K * Mred * groups, 2.0 * groups * Mred * (N + K))
+    run(f"wgrad SS N={N} K={K} Mred={Mred} g={groups}", d, 2.0 * N * K * Mred * groups, 2.0 * groups * Mred * (N + K), wg=(N, K, Mred, groups))
     d._keep = (dC, A, dW)
 
 M2 = B * 249
