@@ -835,6 +835,19 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
 //   R_STRIDED image: [32 k][128 cols] blocks of 8 KiB (256-B k-rows, chunk c at c ^ strided_key(k)), read transposed with
 //                    ds_read_b64_tr_b16 exactly as in the 128-tile DMA loop above.
 // Out-of-range rows / columns / reduction indices fetch from a 16-byte zero chunk, so the K tail needs no masking.
+// LDS-DMA issued from an asm statement: hipcc does not model it, so it neither drains it (vmcnt(0)) in front of the
+// transposing LDS reads -- which it does for the builtin form, treating every pending DMA as a may-alias LDS write -- nor
+// counts it; the ring's own counted vmcnt + barrier protocol orders the data (guide 5.7: M0 is written and restored
+// inside the statement, the destination base is wave-uniform).
+__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* lds_dst) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lptr_t)lds_dst));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
 template <int LAYOUT, int ROWS, int BK_, int NW> struct RingLoader;
 
 template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_CONTIG, ROWS, BK_, NW> {
@@ -892,9 +905,13 @@ template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_CONTIG, ROWS, BK_, N
   __device__ __forceinline__ void issue(unsigned char* tile) {
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
-      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * NI + u) * 1024), 16, 0, 0);
+      glds16(ptr[u], tile + (wave * NI + u) * 1024);
       ptr[u] += step[u];
     }
+  }
+  __device__ __forceinline__ void issue_one(unsigned char* tile, int u) {
+    glds16(ptr[u], tile + (wave * NI + u) * 1024);
+    ptr[u] += step[u];
   }
   // fragment of row tile `row0 / 16`, k-step ks: lane (r = lane & 15, q = lane >> 4) gets k = 32 ks + 8 q .. + 7 of row r
   static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row0, int ks, int lane) {
@@ -923,9 +940,9 @@ template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_STRIDED, ROWS, BK_, 
     wave = tid >> 6;
     const int lane = tid & 63;
     cvalid = 0;
-    rpb = o.rpb;
+    rpb = o.rpb > 0 ? o.rpb : 0x7fffffff;
+    wrap = o.rpb > 0 ? (o.bstride - (long)o.rpb * o.ld) * 2 : 0;
     step = (long)BK_ * o.ld * 2;
-    wrap = (o.bstride - (long)o.rpb * o.ld) * 2;
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
       const int si = wave * NI + u, blk = si >> 3, within = si & 7;
@@ -958,20 +975,25 @@ template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_STRIDED, ROWS, BK_, 
     }
   }
   __device__ __forceinline__ void issue(unsigned char* tile) {
+    // branch-free pointer advance (a branch here splits the loop into blocks and hipcc then drains vmcnt(0) before the
+    // LDS reads): rpb == 0 is stored as INT_MAX, so the batch wrap never fires for it
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
-      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * NI + u) * 1024), 16, 0, 0);
-      if (tcur[u] >= 0) {
-        ptr[u] += step;
-        if (rpb > 0) {
-          tcur[u] += BK_;
-          if (tcur[u] >= rpb) {  // requires rpb >= BK (checked on the host)
-            tcur[u] -= rpb;
-            ptr[u] += wrap;
-          }
-        }
-      }
+      glds16(ptr[u], tile + (wave * NI + u) * 1024);
+      const bool live = tcur[u] >= 0;
+      const int tn = tcur[u] + BK_;
+      const bool w = live && tn >= rpb;  // requires rpb >= BK (checked on the host)
+      ptr[u] += (live ? step : 0) + (w ? wrap : 0);
+      tcur[u] = live ? (w ? tn - rpb : tn) : -1;
     }
+  }
+  __device__ __forceinline__ void issue_one(unsigned char* tile, int u) {
+    glds16(ptr[u], tile + (wave * NI + u) * 1024);
+    const bool live = tcur[u] >= 0;
+    const int tn = tcur[u] + BK_;
+    const bool w = live && tn >= rpb;
+    ptr[u] += (live ? step : 0) + (w ? wrap : 0);
+    tcur[u] = live ? (w ? tn - rpb : tn) : -1;
   }
   static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row0, int ks, int lane) {
     return frag_dma<FH_R_STRIDED>(tile + ((row0 >> 7) * KB + ks) * 8192, row0 & 127, lane);
@@ -1041,8 +1063,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
         need_slow = true;
       }
     }
-    lx.issue(st);
-    ly.issue(st + LX::TILE);
+    if (issued < NST - 1) {  // prologue tiles go out as a burst; in the loop the DMA rides between the MFMA groups
+      lx.issue(st);
+      ly.issue(st + LX::TILE);
+    }
     ++issued;
   };
 #pragma unroll
@@ -1053,7 +1077,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
     // this wave's loads of tile `it` have landed (NST-2 younger tiles may still be in flight) ...
     wait_vm_barrier<(NST - 2) * LPT>();
     // ... and after the barrier so have everyone's; the stage read in iteration it-1 is free again: refill it
-    issue_next(stage == 0 ? NST - 1 : stage - 1);
+    issue_next(stage == 0 ? NST - 1 : stage - 1);  // pointers only: the loads themselves are spread over the MFMA groups
     const unsigned char* bx = lds + stage * STAGE;
     const unsigned char* by = bx + LX::TILE;
 #pragma unroll
@@ -1064,9 +1088,22 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
 #pragma unroll
       for (int m = 0; m < MT; ++m) fx[m] = LX::frag(bx, xi0 + 16 * m, ks, lane);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
+        {
+          // the tile's LPT LDS-DMA instructions, spread evenly behind the KS * MT MFMA groups: issued as one burst at the
+          // top of the tile they held every wave's (and the SIMD's) issue for ~1k cycles while the MFMA pipe idled
+          unsigned char* st = lds + (stage == 0 ? NST - 1 : stage - 1) * STAGE;
+          constexpr int S = KS * MT;
+          const int slot = ks * MT + m;
+#pragma unroll
+          for (int u = slot * LPT / S; u < (slot + 1) * LPT / S; ++u) {
+            if (u < LX::NI) lx.issue_one(st, u);
+            else ly.issue_one(st + LX::TILE, u - LX::NI);
+          }
+        }
+      }
     }
     stage = stage == NST - 1 ? 0 : stage + 1;
   }
@@ -1145,6 +1182,168 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
+// Ping-pong form of the ring (256 x 256 tile, 8 waves, BK = 32, 4 tile buffers): each K-tile is two phases of 16 MFMAs
+// (the wave's upper / lower 64 output rows), every phase = { LDS reads of its fragments + two LDS-DMA issues | barrier |
+// 16 MFMAs | barrier }.  Waves 4-7 run one barrier behind waves 0-3 (one extra s_barrier up front, made up at the end), and
+// each SIMD hosts one wave of either half: while one wave of a SIMD reads LDS / issues DMA the other owns the MFMA pipe.
+//   RAW: a wave waits vmcnt(8) for its own DMA of tile t+1 in the read part of tile t's second phase; the first read of
+//        tile t+1 (waves 0-3, two barriers later) is behind a barrier that every wave passed after that wait.
+//   WAR: tile t+3 goes to the buffer of tile t-1, whose last reads were retired (lgkmcnt(0) before the barrier) one
+//        barrier before the earliest issue.
+template <int XL, int YL>
+__global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
+  constexpr int BM_ = 256, BN_ = 256, BK_ = 32, NW = 8, NST = 4, MT = 8, NT = 4;
+  typedef RingLoader<XL, BM_, BK_, NW> LX;
+  typedef RingLoader<YL, BN_, BK_, NW> LY;
+  constexpr int STAGE = LX::TILE + LY::TILE;
+  static_assert(LX::NI == 2 && LY::NI == 2, "vmcnt bookkeeping below assumes 4 LDS-DMA per lane per K-tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.z;
+  const int tiles_j = (p.N + BN_ - 1) / BN_;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
+  const int i0 = ti * BM_, j0 = tj * BN_;
+  const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
+  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
+  const int t0 = blockIdx.y * per_split;
+  const int t1 = min(ntiles, t0 + per_split);
+  if (t0 >= t1) return;
+  const int nt = t1 - t0;
+  const bool late = __builtin_amdgcn_readfirstlane(tid) >= 256;  // waves 4-7
+
+  LX lx;
+  LY ly;
+  lx.init(p.X, g, i0, p.M, tid);
+  ly.init(p.Y, g, j0, p.N, tid);
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xi0 = (wave & 1) * 128, yj0 = (wave >> 1) * 64;
+
+  int is_seg = t0 / tiles_per_seg;
+  int is_k0 = (t0 - is_seg * tiles_per_seg) * BK_;
+  int issued = 0;
+  bool need_slow = true;
+  auto advance = [&]() {  // source pointers of the next tile to issue (zero chunk past the end)
+    if (issued == nt) {
+      lx.set_zero();
+      ly.set_zero();
+    } else if (issued < nt) {
+      const bool partial = is_k0 + BK_ > p.Kseg;
+      if (need_slow || partial) {
+        lx.set_tile(p.X, is_seg, is_k0, p.Kseg);
+        ly.set_tile(p.Y, is_seg, is_k0, p.Kseg);
+      }
+      is_k0 += BK_;
+      need_slow = false;
+      if (is_k0 >= p.Kseg) {
+        is_k0 = 0;
+        is_seg = min(is_seg + 1, 1);
+        need_slow = true;
+      }
+    }
+    ++issued;
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) {
+    advance();
+    lx.issue(lds + s * STAGE);
+    ly.issue(lds + s * STAGE + LX::TILE);
+  }
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // tile 0 has landed everywhere
+  if (late) __builtin_amdgcn_s_barrier();                          // the stagger
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 fx[4], fy[NT];
+  int rd = 0, wr = NST - 1;
+  for (int it = 0; it < nt; ++it) {
+    const unsigned char* bx = lds + rd * STAGE;
+    const unsigned char* by = bx + LX::TILE;
+    unsigned char* wx = lds + wr * STAGE;
+    // ---- phase 1: rows 0-63 of the wave's tile; DMA the X half of tile it+3
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fy[n] = LY::frag(by, yj0 + 16 * n, 0, lane);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fx[m] = LX::frag(bx, xi0 + 16 * m, 0, lane);
+    advance();
+    lx.issue(wx);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: rows 64-127; DMA the Y half of tile it+3; tile it+1 must have landed when the next phase reads it
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fx[m] = LX::frag(bx, xi0 + 64 + 16 * m, 0, lane);
+    ly.issue(wx + LX::TILE);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n][4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][4 + m], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    rd = rd == NST - 1 ? 0 : rd + 1;
+    wr = wr == NST - 1 ? 0 : wr + 1;
+  }
+  if (!late) __builtin_amdgcn_s_barrier();  // make up the stagger
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tail DMA drained, every wave done with the ring
+  unsigned char* my = lds + wave * EPI_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
+    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g);
+  }
+}
+
+int launch_pp(const GemmParams& p, hipStream_t stream) {
+  const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256;
+  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(512);
+  const size_t smem = (size_t)4 * 512 * 32 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<FH_R_CONTIG, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<FH_R_STRIDED, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_pp_kernel<FH_R_STRIDED, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int xl = p.X.layout, yl = p.Y.layout;
+  if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_pp_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p);
+  else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
+    hipLaunchKernelGGL((gemm_pp_kernel<FH_R_CONTIG, FH_R_STRIDED>), grid, block, smem, stream, p);
+  else if (xl == FH_R_STRIDED && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_pp_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p);
+  else
+    hipLaunchKernelGGL((gemm_pp_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int BM_, int BN_, int WM, int WN, int BK_, int NST> int launch_ring(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM_ - 1) / BM_, tiles_j = (p.N + BN_ - 1) / BN_;
   dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(WM * WN * 64);
@@ -1178,8 +1377,8 @@ bool ring_ok(const GemmParams& p, int bk) {
 // ------------------------------------------------------------------ bf16 main-loop selection
 // g_gemm_path: 0 = 16x16x32 register staging, 1 = 128-tile LDS-DMA ring, 2 = 32x32x16 register staging, 3 = 256x256 ring
 // (BK 64, 2 stages), 4 = 256x128 ring (BK 32, 3 stages, 2 workgroups / CU), 5 = 256x256 ring (BK 32, 4 stages),
-// 9 = per-shape choice (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
-// FH_GEMM_PATH = reg | dma | 2..5 forces one loop (A/B comparisons; tools/gemm_bench.py).
+// 6 = 256x256 ping-pong ring (BK 32, two barrier-staggered wave groups), 9 = per-shape choice (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
+// FH_GEMM_PATH = reg | dma | 2..6 forces one loop (A/B comparisons; tools/gemm_bench.py).
 int g_gemm_path = -1;
 int g_tune_mode = 0;
 struct TuneChoice { int path, splitk; };
@@ -1193,7 +1392,7 @@ bool dma_ok(const GemmParams& p) {
 void resolve_path() {
   if (g_gemm_path < 0) {
     const char* e = getenv("FH_GEMM_PATH");
-    g_gemm_path = !e ? 9 : (e[0] == 'd' ? 1 : (e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '5') ? e[0] - '0' : 9)));
+    g_gemm_path = !e ? 9 : (e[0] == 'd' ? 1 : (e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '6') ? e[0] - '0' : 9)));
   }
 }
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
@@ -1202,6 +1401,7 @@ int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   if (path == 3 && ring_ok(p, 64)) return launch_ring<256, 256, 2, 4, 64, 2>(p, stream);
   if (path == 4 && ring_ok(p, 32)) return launch_ring<256, 128, 2, 2, 32, 3>(p, stream);
   if (path == 5 && ring_ok(p, 32)) return launch_ring<256, 256, 2, 4, 32, 4>(p, stream);
+  if (path == 6 && ring_ok(p, 32)) return launch_pp(p, stream);
   return launch_32(p, stream);
 }
 
@@ -1251,7 +1451,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
       add(2, ring_splitk(p, 128, 128, 1024));
     } else {
       if (ring_ok(p, 64)) add(3, p.splitk);
-      if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); }
+      if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); add(6, p.splitk); }
     }
   }
   hipEvent_t a, b;
