@@ -32,8 +32,17 @@ SAMPLES_10S = 160000
 GF_STUDENT_FWD, GF_TEACHER_BASE = 35.23, 148.1
 GF_STEP = 3 * GF_STUDENT_FWD + GF_TEACHER_BASE  # 253.8
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
-VARIANTS = {0: "f32,R_CONTIG,R_CONTIG", 1: "f32,R_CONTIG,R_STRIDED", 2: "f32,R_STRIDED,R_CONTIG", 3: "f32,R_STRIDED,R_STRIDED",
-            4: "bf16,R_CONTIG,R_CONTIG", 5: "bf16,R_CONTIG,R_STRIDED", 6: "bf16,R_STRIDED,R_CONTIG", 7: "bf16,R_STRIDED,R_STRIDED"}
+LAYOUTS = {0: "0, 0", 1: "0, 1", 2: "1, 0", 3: "1, 1"}  # <X layout, Y layout>: 0 = R_CONTIG, 1 = R_STRIDED
+LOOPS = {0: "gemm_kernel<bf16, {l}>", 1: "gemm_dma_kernel<{l}>", 2: "gemm32_kernel<{l}>", 3: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 64, 2>",
+         4: "gemm_ring_kernel<{l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{l}>"}
+
+
+def kernel_name(slot: int) -> str:
+    """fh_prof_collect slot -> the kernel's name as rocprofv3 prints it (anonymous namespace prefix dropped)."""
+    loop, var = slot // 8, slot % 8
+    if var < 4:
+        return "gemm_kernel<float, %s>" % LAYOUTS[var]
+    return LOOPS[loop].format(l=LAYOUTS[var - 4])
 
 
 def cpu_baseline(cfg, seconds_budget: float = 25.0):
@@ -131,18 +140,18 @@ def main():
     loss = float(out[-1].item())
 
     # ---- roofline of the dominant kernel: the MFMA GEMM, per-launch HIP events on its own stream
-    ms = (C.c_double * 8)()
-    fl = (C.c_double * 8)()
-    ln = (C.c_long * 8)()
+    ms = (C.c_double * 64)()
+    fl = (C.c_double * 64)()
+    ln = (C.c_long * 64)()
     lib.fh_prof_collect(ms, fl, ln)
     roof = None
     tot_ms = sum(ms)
     if tot_ms > 0:
-        v = max(range(8), key=lambda i: ms[i])
+        v = max(range(64), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
                 "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
-                "kernel": f"gemm32_kernel<{VARIANTS[v]}>" if args.dtype == "bf16" else f"gemm_kernel<{VARIANTS[v]}>", "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
+                "kernel": kernel_name(v), "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
                 "avg_gflop_per_launch": round(fl[v] / ln[v] / 1e9, 3),
                 "all_gemm": {"achieved": round(sum(fl) / (tot_ms * 1e-3) / 1e12, 2), "launches": int(sum(ln)),
                              "ms_per_step": round(tot_ms / max(1, min(args.prof_steps, args.steps)), 3)},
@@ -161,7 +170,7 @@ def main():
         lib.fh_prof_enable(0)
         torch.cuda.synchronize()
         task.teacher_stream = side
-        ms2, fl2, ln2 = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_long * 8)()
+        ms2, fl2, ln2 = (C.c_double * 64)(), (C.c_double * 64)(), (C.c_long * 64)()
         lib.fh_prof_collect(ms2, fl2, ln2)
         if ms2[v] > 0:
             ach2 = fl2[v] / (ms2[v] * 1e-3) / 1e12

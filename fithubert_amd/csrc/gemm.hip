@@ -1381,6 +1381,7 @@ bool ring_ok(const GemmParams& p, int bk) {
 // FH_GEMM_PATH = reg | dma | 2..6 forces one loop (A/B comparisons; tools/gemm_bench.py).
 int g_gemm_path = -1;
 int g_tune_mode = 0;
+int g_last_loop = 2;  // main loop the last bf16 launch ran (for the per-launch profile)
 struct TuneChoice { int path, splitk; };
 std::unordered_map<unsigned long long, TuneChoice> g_tune;
 
@@ -1396,6 +1397,8 @@ void resolve_path() {
   }
 }
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
+  g_last_loop = 2;
+  if ((path == 1 && dma_ok(p)) || path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32))) g_last_loop = path;
   if (path == 1 && dma_ok(p)) return launch_dma(p, stream);
   if (path == 0) return launch_t<bf16>(p, stream);
   if (path == 3 && ring_ok(p, 64)) return launch_ring<256, 256, 2, 4, 64, 2>(p, stream);
@@ -1514,9 +1517,10 @@ extern "C" int fh_prof_enable(int on) {
   g_prof_on = on != 0;
   return 0;
 }
-// sums per (dtype*4 + X layout*2 + Y layout) variant; returns the number of launches recorded and clears the log
-extern "C" int fh_prof_collect(double* ms /*[8]*/, double* flops /*[8]*/, long* launches /*[8]*/) {
-  for (int i = 0; i < 8; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+// sums per slot = loop * 8 + (dtype*4 + X layout*2 + Y layout), loop = the main loop that ran (fh_gemm_set_path numbering,
+// 0 for fp32); returns the number of launches recorded and clears the log
+extern "C" int fh_prof_collect(double* ms /*[64]*/, double* flops /*[64]*/, long* launches /*[64]*/) {
+  for (int i = 0; i < 64; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   int n = 0;
   for (auto& r : g_prof) {
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
@@ -1558,6 +1562,7 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   r.variant = (dtype ? 4 : 0) + p.X.layout * 2 + p.Y.layout;
   hipEventRecord(r.a, stream);
   const int rc = dtype == 0 ? launch_t<float>(p, stream) : launch_bf16(p, stream);
+  if (dtype != 0) r.variant += 8 * (g_last_loop & 7);
   hipEventRecord(r.b, stream);
   g_prof.push_back(r);
   return rc;

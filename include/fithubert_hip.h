@@ -80,7 +80,8 @@ typedef struct {
 
 int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 /* Optional per-launch HIP-event timing of the GEMM kernel on its own stream (used by bench.py's roofline object).
- * Variants are indexed dtype*4 + X.layout*2 + Y.layout.  collect() waits for the recorded events, sums, and clears. */
+ * Slots are indexed loop*8 + dtype*4 + X.layout*2 + Y.layout (loop: the main loop that ran, fh_gemm_set_path numbering).
+ * collect() waits for the recorded events, sums into 64-entry arrays, and clears. */
 /* bf16 main loop: 0 = 16x16x32 MFMA register staging (128x128 tile), 1 = 128x128 LDS-DMA ring, 2 = 32x32x16 MFMA register
  * staging (128x128), 3 / 4 / 5 = large-tile LDS-DMA rings (256x256 BK 64, 256x128 BK 32, 256x256 BK 32), 6 = 256x256 ping-pong
  * ring, 9 = per-shape choice (default), -1 = re-read env FH_GEMM_PATH (reg | dma | 2..6). */
@@ -91,7 +92,7 @@ int fh_gemm_set_path(int path);
  * run path 2.  mode -1: forget the table.  Returns the number of measured shape classes. */
 int fh_gemm_tune(int mode);
 int fh_prof_enable(int on);
-int fh_prof_collect(double* ms /*[8]*/, double* flops /*[8]*/, long* launches /*[8]*/);
+int fh_prof_collect(double* ms /*[64]*/, double* flops /*[64]*/, long* launches /*[64]*/);
 
 /* ------------------------------------------------------------------------------------------
  * Waveform frontend layer 0: Conv1d(1, C0, K, stride, bias=False) + GroupNorm(C0, C0) + GELU.
