@@ -162,6 +162,15 @@ __device__ __forceinline__ float drop_apply(const DropKey& k, uint32_t idx_lo) {
 __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
   return drop_apply(drop_key(d, (uint32_t)(idx >> 32)), (uint32_t)idx);
 }
+// N consecutive elements starting at an index that is a multiple of N (N <= 8): one key for all of them -- the low word
+// cannot carry into the high word inside an aligned group.  (drop_scale per element re-derived the key, a hash and an IEEE
+// division, for every element.)
+template <int N> __device__ __forceinline__ void drop_scale_vec(const DropCfg& d, unsigned long long idx, float* v) {
+  const DropKey k = drop_key(d, (uint32_t)(idx >> 32));
+  const uint32_t lo = (uint32_t)idx;
+#pragma unroll
+  for (int e = 0; e < N; ++e) v[e] *= drop_apply(k, lo + e);
+}
 // Pair form (attention probabilities): ONE hash serves the two adjacent even/odd indices, 16 random bits each
 // (keep <=> 16 bits >= p * 2^16).  `idx_lo_even` must be even; s0 / s1 are the scales of idx_lo_even and idx_lo_even + 1.
 __device__ __forceinline__ void drop_pair(const DropKey& k, uint32_t idx_lo_even, float& s0, float& s1) {

@@ -100,10 +100,11 @@ __global__ void mask_drop_kernel(const T* __restrict__ src, T* __restrict__ dst,
       const long b = row / rpb;
       zero = (int)(row - b * rpb) >= row_len[b];
     }
+    if (zero) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      if (zero) a[e] = 0.f;
-      else if (drop.p > 0.f) a[e] *= drop_scale(drop, (unsigned long long)row * C + c0 + e);
+      for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+    } else if (drop.p > 0.f) {
+      drop_scale_vec<VEC>(drop, (unsigned long long)row * C + c0, a);
     }
     st16(dst + i * VEC, pack16<T>(a));
   }

@@ -266,8 +266,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
       }
       if (ep.drop.p > 0.f) {
         const unsigned long long didx = ((unsigned long long)g * p.M + i) * (unsigned long long)p.N + j;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= drop_scale(ep.drop, didx + e);
+        drop_scale_vec<4>(ep.drop, didx, v);
       }
       if (ep.gelu_aux) {
         float a[4];
@@ -362,8 +361,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     }
     if (ep.drop.p > 0.f) {
       const unsigned long long didx = ((unsigned long long)g * p.M + i) * (unsigned long long)p.N + j;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= drop_scale(ep.drop, didx + e);
+      drop_scale_vec<8>(ep.drop, didx, v);
     }
     if (ep.gelu_aux) {
       float a[8];

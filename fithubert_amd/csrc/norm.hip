@@ -104,10 +104,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
       if (ch < nchunk) {
         float o[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          o[e] = fmaf((v[rr][u][e] - mean[rr]) * rstd[rr], gm[u][e], bt[u][e]);
-          if (drop.p > 0.f) o[e] *= drop_scale(drop, (unsigned long long)row * C + ch * VEC + e);
-        }
+        for (int e = 0; e < VEC; ++e) o[e] = fmaf((v[rr][u][e] - mean[rr]) * rstd[rr], gm[u][e], bt[u][e]);
+        if (drop.p > 0.f) drop_scale_vec<VEC>(drop, (unsigned long long)row * C + ch * VEC, o);
         st16(y + (long)row * C + ch * VEC, pack16<T>(o));
       }
     }
@@ -158,9 +156,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
           for (int e = 0; e < VEC; ++e) d[e] += d2[e];
         }
         unpack16<T>(ld16(x + (long)row * C + ch * VEC), xv);
+        if (out_drop.p > 0.f) drop_scale_vec<VEC>(out_drop, (unsigned long long)row * C + ch * VEC, d);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          if (out_drop.p > 0.f) d[e] *= drop_scale(out_drop, (unsigned long long)row * C + ch * VEC + e);
           xh[u][e] = (xv[e] - mean) * rstd;
           dg[u][e] = fmaf(d[e], xh[u][e], dg[u][e]);
           db[u][e] += d[e];
@@ -181,9 +179,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, c
         for (int e = 0; e < VEC; ++e) o[e] = rstd * (g[u][e] - c1 - xh[u][e] * c2);
         st16(dx + (long)row * C + ch * VEC, pack16<T>(o));
         if (dx2) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            if (in_drop.p > 0.f) o[e] *= drop_scale(in_drop, (unsigned long long)row * C + ch * VEC + e);
+          if (in_drop.p > 0.f) drop_scale_vec<VEC>(in_drop, (unsigned long long)row * C + ch * VEC, o);
           st16(dx2 + (long)row * C + ch * VEC, pack16<T>(o));
         }
       }
