@@ -150,6 +150,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
+  // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * (unsigned long long)Tn);
 
   const int ntile = (klen + 63) / 64;
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
         for (int e = 0; e < 4; ++e) o[qt][dt][e] *= alpha;
       if (drop.p > 0.f) {
         const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
-        const DropKey dk = drop_key(drop, (uint32_t)(rowbase >> 32));
+        const DropKey dk = drop_key_at(dspan, rowbase);
         const uint32_t lo = (uint32_t)rowbase;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -287,6 +289,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
+  // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * (unsigned long long)Tn);
 
   const int ntile = (klen + 63) / 64;
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
@@ -361,7 +365,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
         for (int qt = 0; qt < 2; ++qt) {
           const int query = q0 + 16 * qt + r;
           const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
-          const DropKey dk = drop_key(drop, (uint32_t)(rowbase >> 32));
+          const DropKey dk = drop_key_at(dspan, rowbase);
           const uint32_t lo = (uint32_t)rowbase;
           float dsc[4] = {1.f, 1.f, 1.f, 1.f};
           if (drop.p > 0.f) {
@@ -415,6 +419,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const T* dobase = dout + (long)b * Tn * D + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
+  // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * (unsigned long long)Tn);
 
   const int ntile = (Tn + 63) / 64;
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
@@ -494,7 +500,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
               // same (key-tile-relative) split of the index as the forward: hi word of (row base + tile start), lo + offset
               const int kt0 = key & ~63;
               const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
-              dsc = drop_pair_one(drop_key(drop, (uint32_t)(rowbase >> 32)), (uint32_t)rowbase + (key - kt0));
+              dsc = drop_pair_one(drop_key_at(dspan, rowbase), (uint32_t)rowbase + (key - kt0));
             }
             pd[half][kt][e] = p * dsc;
             ds[half][kt][e] = p * (dp[kt][e] * dsc - Dls[ql]) * scale;

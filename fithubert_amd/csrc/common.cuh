@@ -162,6 +162,25 @@ __device__ __forceinline__ float drop_apply(const DropKey& k, uint32_t idx_lo) {
 __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
   return drop_apply(drop_key(d, (uint32_t)(idx >> 32)), (uint32_t)idx);
 }
+// Keys for an index RANGE of at most 2^32 elements (it touches at most two values of the high word): derived once per
+// workgroup, then per element a compare + select instead of a hash and a division.
+struct DropKeySpan {
+  DropKey k;       // thresh / inv_keep shared; k.k = key of the range's first high word
+  uint32_t k_next; // key of the following high word
+  uint32_t hi0;
+};
+__device__ __forceinline__ DropKeySpan drop_key_span(const DropCfg& d, unsigned long long first_idx) {
+  DropKeySpan s;
+  s.hi0 = (uint32_t)(first_idx >> 32);
+  s.k = drop_key(d, s.hi0);
+  s.k_next = drop_key(d, s.hi0 + 1u).k;
+  return s;
+}
+__device__ __forceinline__ DropKey drop_key_at(const DropKeySpan& s, unsigned long long idx) {
+  DropKey k = s.k;
+  k.k = (uint32_t)(idx >> 32) == s.hi0 ? s.k.k : s.k_next;
+  return k;
+}
 // N consecutive elements starting at an index that is a multiple of N (N <= 8): one key for all of them -- the low word
 // cannot carry into the high word inside an aligned group.  (drop_scale per element re-derived the key, a hash and an IEEE
 // division, for every element.)

@@ -213,3 +213,36 @@ def test_forward_is_bitwise_deterministic_across_engines_and_calls():
             ref = cur
         for a, b in zip(cur, ref):
             assert torch.equal(a, b), it
+
+
+def test_gemm_autotune_table_changes_speed_not_results():
+    """The per-shape main-loop table (fh_gemm_tune) may pick any of the bf16 loops and split-K factors; a training-mode
+    forward + backward with the tuned table must agree with the same pass forced onto the default 128-tile loop."""
+    from fithubert_amd import _lib as L
+    lib = L.lib()
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=2)
+    eng, _ = _engine(cfg, 4, "bf16")
+    wav = 0.5 * torch.randn(8, 48000, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run():
+        eng.grads.zero_()
+        ws = eng.forward(wav, None, training=True, seed=11)
+        pred = ws.view("pred").float().clone()
+        d = (1e-2 * torch.randn(ws.view("pred").shape, generator=torch.Generator().manual_seed(2))).to(DEV).to(eng.elem)
+        eng.backward(ws, d_pred=d)
+        torch.cuda.synchronize()
+        return pred, eng.grads.clone()
+
+    try:
+        assert lib.fh_gemm_tune(-1) == 0          # forget whatever earlier tests measured
+        n = eng.autotune(8, 48000)                # measures every GEMM of the step on a throw-away pass
+        assert n > 10
+        assert lib.fh_gemm_tune(0) == n           # the table persists; measuring is off again
+        pred_t, grad_t = run()
+        lib.fh_gemm_set_path(2)
+        pred_d, grad_d = run()
+    finally:
+        lib.fh_gemm_set_path(9)
+    assert _rel_l2(pred_t, pred_d) < 2e-3       # forward GEMMs: same bf16 inputs, fp32 accumulation in a different order
+    assert _rel_l2(grad_t, grad_d) < 1e-2

@@ -218,7 +218,7 @@ def _attn_ref(qkv, H, dh, key_len):
 
 
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
-@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (2, 249, True), (1, 130, False), (3, 70, True)])
+@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (2, 249, True), (1, 130, False), (3, 70, True), (2, 300, True), (1, 499, False)])
 def test_attention_fwd_bwd(dt, B, T, masked):
     torch.manual_seed(B * 7 + T)
     H, dh = 12, 40
@@ -247,6 +247,27 @@ def test_attention_fwd_bwd(dt, B, T, masked):
     tol = _tol(dt) * (1.5 if dt == L.DT_F32 else 2.5)
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert _rel(dqkv[..., sl], qr.grad[..., sl]) < tol, name
+
+
+@pytest.mark.parametrize("B,T,masked", [(2, 499, True), (1, 96, False), (2, 200, True)])
+def test_attention_forward_64_wide_heads(B, T, masked):
+    """bf16 forward-only build for the frozen teacher's 64-wide heads (HuBERT Base / Large)."""
+    torch.manual_seed(T)
+    H, dh = 12, 64
+    D = H * dh
+    lib = L.lib()
+    qkv = (torch.randn(B, T, 3 * D, device=DEV) * 1.1).to(torch.bfloat16)
+    key_len = torch.tensor([T, max(1, T * 2 // 3)][:B], device=DEV, dtype=torch.int32) if masked else None
+    out = torch.full((B, T, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.check(lib.fh_attention_forward(L.DT_BF16, _p(qkv), _p(out), None, _p(key_len), B, T, H, dh, dh ** -0.5, L.drop(), _st()), "attn64")
+    ref, _ = _attn_ref(qkv.double(), H, dh, key_len)
+    assert _rel(out, ref) < _tol(L.DT_BF16)
+    # backward has no 64-wide build: it must refuse, not compute garbage
+    dq = torch.empty_like(qkv)
+    lse = torch.empty(B, H, T, device=DEV)
+    rc = lib.fh_attention_backward(L.DT_BF16, _p(qkv), _p(out), _p(out), _p(lse), _p(lse), _p(dq), _p(key_len), B, T, H, dh, dh ** -0.5,
+                                   L.drop(), _st())
+    assert rc != 0
 
 
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
