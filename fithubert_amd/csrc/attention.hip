@@ -28,9 +28,9 @@ template <> struct AT<bf16> {
   typedef bf16x8 frag;
 };
 template <> struct AT<float> {
-  static constexpr int DP = 48;
+  static constexpr int DP = 64;
   static constexpr int RS = DP * 4 + 16;
-  static constexpr int NK = 3;              // 16 d-values each (4 MFMA steps)
+  static constexpr int NK = 4;              // 16 d-values each (4 MFMA steps)
   static constexpr int KD = 16;
   typedef f32x4 frag;
 };
@@ -534,9 +534,9 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
   }
 }
 
-int check_dims(int dtype, int H, int dh, int dh_max = 48) {
+int check_dims(int dtype, int H, int dh, int dh_max = 64) {
   const int vec = dtype == 0 ? 4 : 8;
-  if (dh % vec || dh % 4 || dh > dh_max || H <= 0) return -601;  // NDT = 3 builds cover dh <= 48 (student dh = 40)
+  if (dh % vec || dh % 4 || dh > dh_max || H <= 0) return -601;  // NDT = 3 builds cover dh <= 48 (student dh = 40), NDT = 4 dh <= 64
   return 0;
 }
 
@@ -601,22 +601,18 @@ int wide_waves(int res, int Tn, int max_nw = 16) {  // waves per workgroup: FH_A
 
 int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int Tn, int H,
                             int dh, float scale, fh_drop drop, hipStream_t st) {
-  // forward-only NDT = 4 build in bf16: the frozen teacher's 64-wide heads (HuBERT Base 768 / 12, Large 1024 / 16)
-  if (int rc = check_dims(dtype, H, dh, dtype == 0 ? 48 : 64)) return rc;
+  if (int rc = check_dims(dtype, H, dh, 64)) return rc;
   const float sl2 = scale * 1.4426950408889634f;
-  if (dtype == 0) {
+  if (dtype == 0) {  // fp32 parity mode: 4-wave workgroups (the wider builds are tuned for the bf16 register budget)
     const int res = resident_tiles<float>(Tn);
     const float* q = (const float*)qkv;
-    switch (wide_waves(res, Tn)) {
-      case 16: return fwd_launch_t<float, 3, 16>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-      case 8: return fwd_launch_t<float, 3, 8>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-      default: return fwd_launch_t<float, 3, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-    }
+    if (dh > 48) return fwd_launch_t<float, 4, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+    return fwd_launch_t<float, 3, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
   }
   const int res = resident_tiles<bf16>(Tn);
   const bf16* q = (const bf16*)qkv;
   const int nw = wide_waves(res, Tn);
-  if (dh > 48) {
+  if (dh > 48) {  // 64-wide heads: the teacher (HuBERT Base 768 / 12, Large 1024 / 16), the ex.yaml student
     switch (nw) {
       case 16: return fwd_launch_t<bf16, 4, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
       case 8: return fwd_launch_t<bf16, 4, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
@@ -633,20 +629,21 @@ int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, c
 int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                             float* delta, void* dqkv, const int* key_len, int B, int Tn, int H, int dh, float scale,
                             fh_drop drop, hipStream_t st) {
-  if (int rc = check_dims(dtype, H, dh)) return rc;
+  if (int rc = check_dims(dtype, H, dh, 64)) return rc;
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype == 0) {
     const int res = resident_tiles<float>(Tn);
-    switch (wide_waves(res, Tn, 8)) {
-      case 16: return bwd_launch_t<float, 3, 16>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-      case 8: return bwd_launch_t<float, 3, 8>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-      default: return bwd_launch_t<float, 3, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-    }
+    if (dh > 48)
+      return bwd_launch_t<float, 4, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+    return bwd_launch_t<float, 3, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
   }
   const int res = resident_tiles<bf16>(Tn);
-  switch (wide_waves(res, Tn, 8)) {  // the 16-wave backward builds spill under the 128-VGPR cap
-    case 16: return bwd_launch_t<bf16, 3, 16>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-    case 8: return bwd_launch_t<bf16, 3, 8>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-    default: return bwd_launch_t<bf16, 3, 4>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+  const int nw = wide_waves(res, Tn, 8);  // the 16-wave backward builds spill under the 128-VGPR cap
+  const bf16 *q = (const bf16*)qkv, *o = (const bf16*)out, *d = (const bf16*)dout;
+  if (dh > 48) {
+    if (nw == 8) return bwd_launch_t<bf16, 4, 8>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+    return bwd_launch_t<bf16, 4, 4>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
   }
+  if (nw == 8) return bwd_launch_t<bf16, 3, 8>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+  return bwd_launch_t<bf16, 3, 4>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
 }

@@ -151,7 +151,7 @@ int fh_posconv_weightnorm_backward(const float* g, const float* v, const float* 
  * Multi-head self-attention on packed qkv [B][T][3*H*dh] -> out [B][T][H*dh]; lse [B][H][T] (log2 domain).
  * Replaces fairseq MultiheadAttention called at modules/module.py:558-564 (q scaling, key_padding_mask as
  * per-batch valid key count key_len, fp32 softmax, dropout on probabilities).  Backward writes dqkv.
- * Head dim: forward dh <= 64 in bf16 (the teacher's 64-wide heads), dh <= 48 in fp32 and for backward.
+ * Head dim dh <= 64 (multiple of 8): 40 (fithubert.yaml), 64 (ex.yaml student, HuBERT Base / Large teachers).
  * ------------------------------------------------------------------------------------------ */
 int fh_attention_forward(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int T, int H,
                          int dh, float scale, fh_drop drop, fh_stream_t stream);
