@@ -125,6 +125,8 @@ SIGNATURES = {
     "fh_attention_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, Drop, _P]),
     "fh_kd_loss_nblk": (_I, [_I, _I, _I, _I]),
     "fh_kd_loss": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _P]),
+    "fh_kd_loss_rows_nblk": (_I, [_I, _I]),
+    "fh_kd_loss_rows": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _F, _P]),
     "fh_conv1d_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fh_posconv_wide_prepare": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fh_posconv_wide_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

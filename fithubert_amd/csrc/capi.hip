@@ -90,6 +90,13 @@ int fh_kd_loss(int dtype, int teacher_dtype, const void* pred, const void* teach
                            B, Tp, Tt, P, teacher_lstride, loss_type, grad_scale, ST(stream));
 }
 
+int fh_kd_loss_rows(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
+                    const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,
+                    long teacher_lstride, int loss_type, float rec_weight, float sim_weight, fh_stream_t stream) {
+  return fh_kd_loss_rows_launch(dtype, teacher_dtype, pred, teacher, dpred, layer_w, teacher_layer, partials, out_losses, L,
+                                B, Tp, Tt, P, teacher_lstride, loss_type, rec_weight, sim_weight, ST(stream));
+}
+
 int fh_cast(int dtype, const float* src, void* dst, long n, fh_stream_t stream) {
   return fh_cast_launch(dtype, src, dst, n, ST(stream));
 }

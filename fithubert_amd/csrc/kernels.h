@@ -48,6 +48,10 @@ int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const v
 int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
                       const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L, int B,
                       int Tp, int Tt, int P, long teacher_lstride, int loss_type, float grad_scale, hipStream_t st);
+int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
+                           const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L,
+                           int B, int Tp, int Tt, int P, long teacher_lstride, int loss_type, float rec_weight,
+                           float sim_weight, hipStream_t st);
 
 // ---- elementwise.hip
 int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t st);

@@ -109,6 +109,124 @@ __global__ void kd_loss_final_kernel(const float* partials, const float* layer_w
   if (threadIdx.x == 0) out[L] = total;
 }
 
+// ---- row-wise variant with the cosine term (train.py:302-314): one wavefront per (layer, b, t) row keeps the row of
+// pred and teacher in registers, reduces  sum f(p - t),  p.t,  |p|^2,  |t|^2  with shuffles, and writes
+//   d/dp [ rec_w * w_l * mean f(p - t)  +  sim_w * w_l * mean_rows( -logsigmoid(cos(p, t)) ) ].
+// cos = p.t / (max(|p|, eps) * max(|t|, eps)), eps = 1e-8 (ATen cosine_similarity).
+constexpr int ROWS_PER_BLOCK = 4 * 8;  // 4 waves x 8 rows each
+
+template <typename T, typename TT, int NCH>
+__global__ void __launch_bounds__(256) kd_loss_rows_kernel(const T* __restrict__ pred, const TT* __restrict__ teacher,
+                                                           T* __restrict__ dpred, const float* __restrict__ layer_w,
+                                                           const int* __restrict__ teacher_layer,
+                                                           float* __restrict__ partials, int B, int Tp, int Tt, int P,
+                                                           long teacher_lstride, int loss_type, float rec_w, float sim_w,
+                                                           int nblk) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ float red[2][4];
+  const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float w = layer_w[l];
+  const int nchunk = P / VEC;
+  const long rows = (long)B * Tp;
+  const T* pl = pred + (long)l * rows * P;
+  T* dl = dpred ? dpred + (long)l * rows * P : nullptr;
+  const TT* tl = teacher + (long)teacher_layer[l] * teacher_lstride;
+  const float rcoef = rec_w * w / ((float)rows * (float)P) * (loss_type == 0 ? 2.0f : 1.0f);
+  const float scoef = sim_w * w / (float)rows;
+  float acc_rec = 0.f, acc_sim = 0.f;
+  for (int rr = 0; rr < 8; ++rr) {
+    const long row = ((long)blockIdx.x * 4 + wave) * 8 + rr;
+    if (row >= rows) break;
+    const long b = row / Tp, t = row - b * Tp;
+    float pv[NCH][VEC], tv[NCH][VEC];
+    float f = 0.f, dot = 0.f, pp = 0.f, tt = 0.f;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunk) {
+        unpack16<T>(ld16(pl + row * P + ch * VEC), pv[u]);
+        load_teacher<TT, VEC>(tl + (b * Tt + t) * P + (long)ch * VEC, tv[u]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = pv[u][e] - tv[u][e];
+          f += loss_type == 0 ? d * d : fabsf(d);
+          dot = fmaf(pv[u][e], tv[u][e], dot);
+          pp = fmaf(pv[u][e], pv[u][e], pp);
+          tt = fmaf(tv[u][e], tv[u][e], tt);
+        }
+      }
+    }
+    f = wave_sum(f);
+    dot = wave_sum(dot);
+    pp = wave_sum(pp);
+    tt = wave_sum(tt);
+    const float np = fmaxf(sqrtf(pp), 1e-8f), nt = fmaxf(sqrtf(tt), 1e-8f);
+    const float inv = 1.0f / (np * nt);
+    const float c = dot * inv;
+    // -logsigmoid(c) = softplus(-c), stable form; d/dc = -1 / (1 + exp(c))
+    const float sim = fmaxf(-c, 0.f) + log1pf(expf(-fabsf(c)));
+    const float dsim_dc = -1.0f / (1.0f + expf(c));
+    if (w != 0.f) {
+      acc_rec += f;
+      acc_sim += sim;
+    }
+    if (dl) {
+      const float a = scoef * dsim_dc * inv;             // * t
+      const float bq = sqrtf(pp) > 1e-8f ? scoef * dsim_dc * c / (np * np) : 0.f;  // * p (the clamped norm has no gradient)
+#pragma unroll
+      for (int u = 0; u < NCH; ++u) {
+        const int ch = lane + 64 * u;
+        if (ch < nchunk) {
+          float g[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float d = pv[u][e] - tv[u][e];
+            const float gr = loss_type == 0 ? rcoef * d : (d > 0.f ? rcoef : (d < 0.f ? -rcoef : 0.f));
+            g[e] = gr + a * tv[u][e] - bq * pv[u][e];
+          }
+          st16(dl + row * P + ch * VEC, pack16<T>(g));
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    red[0][wave] = acc_rec;
+    red[1][wave] = acc_sim;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[(long)l * nblk + blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partials[(long)(gridDim.y + l) * nblk + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// out[l] = mean_rec_l + mean_sim_l (unweighted), out[L] = rec_w * sum_l w_l mean_rec_l + sim_w * sum_l w_l mean_sim_l
+__global__ void kd_loss_rows_final_kernel(const float* partials, const float* layer_w, double* out, int L, int nblk,
+                                          double inv_rec, double inv_sim, double rec_w, double sim_w) {
+  __shared__ double sh[256];
+  double total = 0.0;
+  for (int l = 0; l < L; ++l) {
+    double m[2];
+    for (int k = 0; k < 2; ++k) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partials[(long)(k * L + l) * nblk + i];
+      sh[threadIdx.x] = s;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+      }
+      m[k] = sh[0] * (k == 0 ? inv_rec : inv_sim);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out[l] = m[0] + m[1];
+      total += (double)layer_w[l] * (rec_w * m[0] + sim_w * m[1]);
+    }
+  }
+  if (threadIdx.x == 0) out[L] = total;
+}
+
 }  // namespace
 
 extern "C" int fh_kd_loss_nblk(int dtype, int B, int Tp, int P) {
@@ -136,6 +254,37 @@ int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void
   FH_CHECK_LAUNCH();
   hipLaunchKernelGGL(kd_loss_final_kernel, dim3(1), dim3(256), 0, st, partials, layer_w, out_losses, L, nblk,
                      1.0 / ((double)B * Tp * P));
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int fh_kd_loss_rows_nblk(int B, int Tp) { return (int)(((long)B * Tp + 31) / 32); }
+
+int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
+                           const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L,
+                           int B, int Tp, int Tt, int P, long teacher_lstride, int loss_type, float rec_weight,
+                           float sim_weight, hipStream_t st) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if (P % 8 || Tp > Tt) return -401;
+  const int nch = (P / vec + 63) / 64;
+  if (nch > 4) return -402;
+  const int nblk = fh_kd_loss_rows_nblk(B, Tp);
+  dim3 grid(nblk, L), block(256);
+#define FH_LAUNCH_ROWS(T, TT, N)                                                                                       \
+  hipLaunchKernelGGL((kd_loss_rows_kernel<T, TT, N>), grid, block, 0, st, (const T*)pred, (const TT*)teacher, (T*)dpred, \
+                     layer_w, teacher_layer, partials, B, Tp, Tt, P, teacher_lstride, loss_type, rec_weight, sim_weight, nblk)
+#define FH_ROWS_N(T, TT)                    \
+  if (nch <= 2) FH_LAUNCH_ROWS(T, TT, 2);   \
+  else FH_LAUNCH_ROWS(T, TT, 4)
+  if (dtype == 0 && teacher_dtype == 0) { FH_ROWS_N(float, float); }
+  else if (dtype == 0) { FH_ROWS_N(float, bf16); }
+  else if (teacher_dtype == 0) { FH_ROWS_N(bf16, float); }
+  else { FH_ROWS_N(bf16, bf16); }
+#undef FH_ROWS_N
+#undef FH_LAUNCH_ROWS
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(kd_loss_rows_final_kernel, dim3(1), dim3(256), 0, st, partials, layer_w, out_losses, L, nblk,
+                     1.0 / ((double)B * Tp * P), 1.0 / ((double)B * Tp), (double)rec_weight, (double)sim_weight);
   FH_CHECK_LAUNCH();
   return 0;
 }

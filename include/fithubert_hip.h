@@ -169,6 +169,14 @@ int fh_kd_loss_nblk(int dtype, int B, int Tp, int P);
 int fh_kd_loss(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
                const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,
                long teacher_lstride, int loss_type, float grad_scale, fh_stream_t stream);
+/* Same with the cosine term of the DistilHuBERT-style loss (train.py:302-314,372-378; ex.yaml: l1 + cosine):
+ *   sim_l = mean_{b,t} -logsigmoid(cos(pred_l[b,t,:], teacher[b,t,:])),
+ *   out[l] = mean f + sim_l (what the reference logs per layer), out[L] = rec_weight * sum_l w[l] mean f + sim_weight * sum_l w[l] sim_l,
+ *   dpred = d out[L] / d pred.   partials: 2 * L * fh_kd_loss_rows_nblk(B, Tp) floats. */
+int fh_kd_loss_rows_nblk(int B, int Tp);
+int fh_kd_loss_rows(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
+                    const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,
+                    long teacher_lstride, int loss_type, float rec_weight, float sim_weight, fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight preparation and optimizer (train.py:407-421; AMP casts implicit at train.py:469,496).

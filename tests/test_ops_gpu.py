@@ -335,6 +335,40 @@ def test_kd_loss(dt, tdt, loss_type):
     assert _rel(dpred, pr.grad) < (1e-6 if dt == L.DT_F32 else 5e-3)
 
 
+@pytest.mark.parametrize("dt,tdt", [(L.DT_F32, L.DT_F32), (L.DT_BF16, L.DT_BF16), (L.DT_BF16, L.DT_F32)])
+@pytest.mark.parametrize("loss_type", [0, 1])
+@pytest.mark.parametrize("P", [768, 1024])
+def test_kd_loss_with_cosine_term(dt, tdt, loss_type, P):
+    """ex.yaml loss (train.py:284-314, 372-378): rec (l1 | mse) + -logsigmoid(cosine), pred_layer_id path (w_l = 1/N)."""
+    import torch.nn.functional as F
+    torch.manual_seed(6)
+    N, B, Tp, Tt = 3, 2, 37, 40
+    lib = L.lib()
+    pred = torch.randn(N, B, Tp, P, device=DEV).to(_tdt(dt))
+    teacher = torch.randn(12, B, Tt, P, device=DEV).to(_tdt(tdt))
+    pred[1, 0, 5] = 0  # a zero row: the clamped norm must not produce NaN / a gradient through the clamp
+    w = torch.full((N,), 1.0 / N, device=DEV)
+    tl = torch.tensor([3, 7, 11], device=DEV, dtype=torch.int32)
+    rec_w, sim_w = 0.7, 1.3
+    nblk = lib.fh_kd_loss_rows_nblk(B, Tp)
+    partials = torch.empty(2 * N * nblk, device=DEV)
+    out = torch.empty(N + 1, device=DEV, dtype=torch.float64)
+    dpred = torch.full_like(pred, float("nan"))
+    L.check(lib.fh_kd_loss_rows(dt, tdt, _p(pred), _p(teacher), _p(dpred), _p(w), _p(tl), _p(partials), _p(out), N, B, Tp, Tt, P,
+                                B * Tt * P, loss_type, rec_w, sim_w, _st()), "loss rows")
+    pr = pred.double().requires_grad_(True)
+    tgt = teacher.double()[[3, 7, 11]][:, :, :Tp]
+    diff = pr - tgt
+    rec = (diff ** 2 if loss_type == 0 else diff.abs()).mean((1, 2, 3))
+    sim = (-F.logsigmoid(F.cosine_similarity(pr, tgt, dim=-1))).mean((1, 2))
+    total = rec_w * rec.mean() + sim_w * sim.mean()
+    total.backward()
+    assert (out[:N] - (rec + sim)).abs().max().item() < 2e-6 * (rec + sim).abs().max().item()
+    assert abs(out[N].item() - total.item()) < 2e-6 * abs(total.item())
+    assert not torch.isnan(dpred.float()).any()
+    assert _rel(dpred, pr.grad) < (2e-6 if dt == L.DT_F32 else 5e-3)
+
+
 # ------------------------------------------------------------------------------------------ cast / permute / AdamW
 def test_cast_permute_adamw():
     torch.manual_seed(5)
