@@ -44,6 +44,7 @@ struct ParamLayout {
   long l_qkv_w, l_qkv_b, l_o_w, l_o_b, l_ln1_w, l_ln1_b, l_fc1_w, l_fc1_b, l_fc2_w, l_fc2_b, l_ln2_w, l_ln2_b;
   long enc_ln_w, enc_ln_b, ups_w, ups_b;
   long head0, head_stride, h_up_w, h_up_b, h_lin_w, h_lin_b;
+  long sp_w0 = -1, sp_b0 = -1, sp_w2 = -1, sp_b2 = -1;  // DistilHuBERT-style head (n_tasks >= 2)
 
   long add(const std::string& name, std::initializer_list<long> dims) {
     PEntry e;
@@ -111,6 +112,15 @@ struct ParamLayout {
       ups_b = add("upsampler.bias", {D});
     }
     head0 = total;
+    if (c.n_tasks > 0) {
+      head_stride = 0; h_up_w = h_up_b = h_lin_w = h_lin_b = -1;
+      const long I = c.inter_dim, Nt = c.n_tasks;
+      sp_w0 = add("proj_head.0.weight", {I * Nt, D});
+      sp_b0 = add("proj_head.0.bias", {I * Nt});
+      sp_w2 = add("proj_head.2.weight", {Nt, I, P});   // SplitLinear: [task][Din][Dout]
+      sp_b2 = add("proj_head.2.bias", {1, 1, Nt, P});
+      return;
+    }
     for (int l = 0; l < c.layers; ++l) {
       const std::string p = "proj_head." + std::to_string(l) + ".";
       const long base = total;
@@ -182,7 +192,8 @@ struct WcLayout {
       head_wup = o; head_wup_stride = D * D * c.tr_factor;  // elements
       o += rup(head_wup_stride * c.layers * es, 256);
     }
-    const long pw = (long)c.conv_pos_groups * c.conv_pos * 32 * 32;
+    const long cp = fh_posconv_cp(c.embed_dim / c.conv_pos_groups);
+    const long pw = (long)c.conv_pos_groups * c.conv_pos * cp * cp;
     pos_wf = o; o += rup(pw * es, 256);
     pos_wb = o; o += rup(pw * es, 256);
     pos_norm = o; o += rup(3L * c.conv_pos * 4, 256);
@@ -223,7 +234,7 @@ struct Plan {
   long c0_mean, c0_rstd, c0_scratch;
   long ln0, ln0_mean, ln0_rstd, features, x0, zc, psum, ln1_mean, ln1_rstd, x1;
   long xo, qkv, attn, lse, s1, st1_mean, st1_rstd, xa, z1, hbuf, f2, s2, st2_mean, st2_rstd;
-  long u, pred;
+  long u, pred, hz = -1, hh = -1, dhz = -1;
   // backward
   long du, ghead, dxin, ds2, df2, dz1, dx1b, ds1, dao, da, dqkv, delta;
   long dx1tr, dpsum, dzc, dx0, dfeat, dln0, dylast, pos_dws;
@@ -272,11 +283,19 @@ struct Plan {
     s2 = ws.add("s2", {L, M2, D}, es);
     st2_mean = ws.add("st2_mean", {L, M2}, 4);
     st2_rstd = ws.add("st2_rstd", {L, M2}, 4);
-    const long Lh = k.heads_on ? L : 1;
-    u = ws.add("u", {Lh, B, sh.T2 * sh.f, D}, es);
+    const long Lh = c.n_tasks > 0 ? c.n_tasks : (k.heads_on ? L : 1);
+    if (c.n_tasks > 0) {
+      const long IN = (long)c.inter_dim * c.n_tasks;
+      u = -1;
+      if (tr) hz = ws.add("hz", {M2, IN}, es);
+      hh = ws.add("hh", {M2, IN}, es);
+      if (tr) dhz = ws.add("dhz", {M2, IN}, es);
+    } else {
+      u = ws.add("u", {Lh, B, sh.T2 * sh.f, D}, es);
+    }
     pred = ws.add("pred", {Lh, B, sh.T2 * sh.f, P}, es);
     if (tr) {
-      du = ws.add("du", {Lh, B, sh.T2 * sh.f, D}, es);
+      du = c.n_tasks > 0 ? -1 : ws.add("du", {Lh, B, sh.T2 * sh.f, D}, es);
       ghead = ws.add("ghead", {L, M2, D}, es);
       dxin = ws.add("dxin", {2, M2, D}, es);
       ds2 = ws.add("ds2", {M2, D}, es);
@@ -295,7 +314,8 @@ struct Plan {
       dfeat = ws.add("dfeat", {B, sh.Tp, D}, es);
       dln0 = ws.add("dln0", {Mp, E}, es);
       dylast = ws.add("dylast", {Mp, E}, es);
-      pos_dws = ws.add("pos_dws", {(long)c.conv_pos_groups * c.conv_pos * 32 * 32}, 4);
+      const long cp = fh_posconv_cp(c.embed_dim / c.conv_pos_groups);
+      pos_dws = ws.add("pos_dws", {(long)c.conv_pos_groups * c.conv_pos * cp * cp}, 4);
       for (int i = 0; i < c.n_conv; ++i) dz[i] = ws.add("dz" + std::to_string(i), {B, sh.T[i], c.conv_dim[i]}, es);
     }
   }
@@ -311,6 +331,8 @@ inline int validate(const fh_student_config& c) {
   if (c.embed_dim % c.heads || c.embed_dim % c.conv_pos_groups || c.embed_dim % vec || c.ffn_dim % vec || c.pred_dim % 8)
     return -814;
   if (c.tr_factor != 0 && c.tr_factor != 2) return -815;  // shipped configs: conv1d TR with factor 2 at index 0
+  if (!fh_posconv_cp(c.embed_dim / c.conv_pos_groups) || (c.embed_dim / c.conv_pos_groups) % 2) return -818;
+  if (c.n_tasks < 0 || c.n_tasks == 1 || (c.n_tasks > 0 && (c.inter_dim <= 0 || c.inter_dim % vec || c.tr_factor != 0))) return -817;
   for (int i = 1; i < c.n_conv; ++i) {
     const int kk = c.conv_k[i], s = c.conv_stride[i];
     if (!((kk == s) || (kk == 1 && s == 1) || (kk == 3 && s == 2))) return -816;
@@ -526,6 +548,33 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
                                x.W<float>(p.st2_mean) + l * M2, x.W<float>(p.st2_rstd) + l * M2, (int)M2, D, 1e-5f,
                                x.drop(0.f, 0), x.st));
   }
+  // ---- DistilHuBERT-style head on the last layer (model.py:508-516): Linear -> GELU -> SplitLinear (module.py:606-619)
+  if (c.n_tasks > 0) {
+    if (!p.k.heads_on) return 0;
+    const int Nt = c.n_tasks, I = c.inter_dim;
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(x.at(p.xo, (long)L * M2 * D), FH_R_CONTIG, D);
+    g.Y = fh_operand(x.nat(p.pl.sp_w0), FH_R_CONTIG, D);
+    g.C = x.W(p.hh);
+    g.M = (int)M2; g.N = I * Nt; g.Kseg = D; g.ldc = (long)I * Nt;
+    g.ep.bias = prm + p.pl.sp_b0;
+    g.ep.act = FH_ACT_GELU;
+    if (tr) g.ep.preact = x.W(p.hz);
+    RC(fh_gemm_launch(g, dt, x.st));
+    GemmParams g2 = fh_gemm_params();  // pred[n] = hh[:, n*I:(n+1)*I] . W2[n]  (+ b2[n])
+    g2.X = fh_operand(x.W(p.hh), FH_R_CONTIG, (long)I * Nt);
+    g2.X.gstride = I;
+    g2.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_STRIDED, P);
+    g2.Y.gstride = (long)I * P;
+    g2.C = x.W(p.pred);
+    g2.M = (int)M2; g2.N = P; g2.Kseg = I; g2.ldc = P;
+    g2.c_gstride = M2 * P;
+    g2.groups = Nt;
+    g2.ep.bias = prm + p.pl.sp_b2;
+    g2.ep.bias_gstride = P;
+    RC(fh_gemm_launch(g2, dt, x.st));
+    return 0;
+  }
   // ---- projection heads (LayerWiseProjHead, module.py:649-661): ConvTranspose1d(k = s = f) then Linear D -> P
   {
     const int Lh = p.k.heads_on ? L : 1;
@@ -582,7 +631,43 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
 
   // ---------------- heads: d_pred -> du -> ghead (+ d_hidden), and head weight gradients
   bool have_ghead = false;
-  if (d_pred) {
+  const bool split_head = c.n_tasks > 0;
+  if (d_pred && split_head) {
+    const int Nt = c.n_tasks, I = c.inter_dim;
+    const long IN = (long)I * Nt;
+    {  // dhz[:, n-block] = (d_pred[n] . W2[n]^T) * gelu'(hz)
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(d_pred, FH_R_CONTIG, P);
+      g.X.gstride = M2 * P;
+      g.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_CONTIG, P);
+      g.Y.gstride = (long)I * P;
+      g.C = x.W(p.dhz);
+      g.M = (int)M2; g.N = I; g.Kseg = P; g.ldc = IN;
+      g.c_gstride = I;
+      g.groups = Nt;
+      g.ep.gelu_aux = x.W(p.hz);
+      RC(fh_gemm_launch(g, dt, x.st));
+    }
+    {  // dW2[n][r][j] += sum_m hh[m][n*I + r] * d_pred[n][m][j] ; db2[n] = colsum(d_pred[n])
+      GemmOperand A = fh_operand(d_pred, FH_R_STRIDED, P);
+      A.gstride = M2 * P;
+      RC(wgrad(x, x.W(p.hh), IN, A, grads + p.pl.sp_w2, I, P, M2, Nt, I, (long)I * P));
+      RC(fh_colsum_launch(dt, d_pred, grads + p.pl.sp_b2, (int)M2, P, P, Nt, M2 * P, P, 0, 1.f, x.st));
+    }
+    {  // ghead[L-1] = dhz . W0 (+ d_hidden[L-1])
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.W(p.dhz), FH_R_CONTIG, IN);
+      g.Y = fh_operand(x.nat(p.pl.sp_w0), FH_R_STRIDED, D);
+      g.C = x.at(p.ghead, (long)(L - 1) * M2 * D);
+      g.M = (int)M2; g.N = D; g.Kseg = (int)IN; g.ldc = D;
+      if (d_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)(L - 1) * M2 * D * p.es;
+      RC(fh_gemm_launch(g, dt, x.st));
+      GemmOperand A = fh_operand(x.at(p.xo, (long)L * M2 * D), FH_R_STRIDED, D);
+      RC(wgrad(x, x.W(p.dhz), IN, A, grads + p.pl.sp_w0, (int)IN, D, M2, 1, 0, 0));
+      RC(fh_colsum_launch(dt, x.W(p.dhz), grads + p.pl.sp_b0, (int)M2, (int)IN, IN, 1, 0, 0, 0, 1.f, x.st));
+    }
+    have_ghead = true;
+  } else if (d_pred) {
     const void* dlin_in;  // gradient w.r.t. the Linear's input
     if (c.tr_factor > 0) {
       GemmParams g = fh_gemm_params();
@@ -654,7 +739,7 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     float* lg = grads + lpo;
     const uint32_t site = SITE_LAYER0 + 4 * l;
     const void* g_head = nullptr;
-    if (have_ghead && (p.k.heads_on || l == L - 1)) g_head = x.at(p.ghead, (long)l * M2 * D);
+    if (have_ghead && ((p.k.heads_on && !split_head) || l == L - 1)) g_head = x.at(p.ghead, (long)l * M2 * D);
     else if (d_hidden) g_head = (const unsigned char*)d_hidden + (long)l * M2 * D * p.es;
     const void* dy = dy_next ? dy_next : g_head;
     const void* dy2 = dy_next ? g_head : nullptr;
@@ -757,7 +842,10 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
                              (int)s.Mp, D, x.drop(c.dropout, SITE_ENC), x.drop(0.f, 0), x.st));
   RC(fh_posconv_bwd_data_launch(dt, x.W(p.dpsum), x.W(p.zc), x.rel(p.wl.pos_wb), x.W(p.dzc), x.W(p.dx0), B, s.Tp, D,
                                 c.conv_pos_groups, c.conv_pos, x.st));
-  RC((int)hipMemsetAsync(x.W(p.pos_dws), 0, (long)c.conv_pos_groups * c.conv_pos * 32 * 32 * 4, x.st));
+  {
+    const long cp = fh_posconv_cp(D / c.conv_pos_groups);
+    RC((int)hipMemsetAsync(x.W(p.pos_dws), 0, (long)c.conv_pos_groups * c.conv_pos * cp * cp * 4, x.st));
+  }
   RC(fh_posconv_bwd_weight_launch(dt, x.W(p.dzc), x.W(p.x0), x.W<float>(p.pos_dws), grads + p.pl.pos_b, B, s.Tp, D,
                                   c.conv_pos_groups, c.conv_pos, x.st));
   RC(fh_posconv_wn_bwd_launch(x.params + p.pl.pos_g, x.params + p.pl.pos_v, (const float*)x.rel(p.wl.pos_norm),

@@ -26,6 +26,7 @@ int fh_colsum_launch(int dtype, const void* X, float* out, int M, int N, long ld
 int fh_zero_rows_launch(int dtype, void* x, int B, int Tn, int C, int from, hipStream_t st);
 
 // ---- posconv.hip : weight-normed grouped positional conv (+ GELU + residual), its backward, weight-norm fwd/bwd
+int fh_posconv_cp(int cg);  // padded group width (32 | 64) the positional-conv kernels use, 0 = unsupported
 int fh_posconv_prep_launch(int dtype, const float* g, const float* v, void* w_fwd, void* w_bwd, float* norm, int D,
                            int groups, int K, hipStream_t st);
 int fh_posconv_fwd_launch(int dtype, const void* x, const void* w_fwd, const float* bias, void* zc, void* y, int B,

@@ -4,8 +4,9 @@
 //   reference: built at modules/module.py:186-208 (weight_norm(dim=2): w = g * v / ||v||_(0,1) per tap, SamePad
 //   drops the last frame, GELU), applied at module.py:276-278 (x = x + pos_conv(x)).
 //
-// Per group this is a [T x (cg*128)] x [(cg*128) x cg] product with cg = 30 channels: every tap is ONE 16x16x32
-// MFMA K-step over the (zero-padded to 32) input channels of the group.  The input window of a 128-frame tile
+// Per group this is a [T x (cg*128)] x [(cg*128) x cg] product with cg = 30 channels (fithubert.yaml; 48 for the 768-wide
+// ex.yaml student): every tap is one (CP = 32) or two (CP = 64) 16x16x32 MFMA K-steps over the zero-padded input
+// channels of the group.  All kernels are templated on the padded group width CP.  The input window of a 128-frame tile
 // (128 + 127 rows x 32 channels) is staged once in LDS and re-read for all 128 taps; the per-tap 32x32 weight
 // blocks stream from L2.  Data-gradient = the same kernel on flipped/transposed weights with pad 63 and a fused
 // GELU' on the staged operand; weight-gradient reduces over time with transposing LDS reads (ds_read_b64_tr_b16).
@@ -14,12 +15,13 @@
 
 namespace {
 
-constexpr int CP = 32;    // padded channels per group
 constexpr int TT = 128;   // output frames per block (fwd / dgrad)
-constexpr int TS = 256;   // frames per staged tile (wgrad)
 
-template <typename T> struct PC {
+template <typename T, int CP> struct PC {
   static constexpr int RS = CP * (int)sizeof(T) + 16;  // LDS row stride in bytes
+  static constexpr int CB = CP / 16;                    // 16-channel MFMA blocks per group
+  static constexpr int TS = (sizeof(T) == 4 && CP == 64) ? 128 : 256;  // frames per staged tile (wgrad; LDS budget)
+  static constexpr int JW = CP == 64 ? 2 : 8;          // taps per wave in wgrad (accumulator registers)
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -45,7 +47,7 @@ __global__ void __launch_bounds__(256) wn_norm2_kernel(const float* __restrict__
 }
 
 // w_fwd[g][j][co][ci] = w[g*cg+co][ci][j] ; w_bwd[g][j'][ci][co] = w[g*cg+co][ci][K-1-j']  (zero padded to CP)
-template <typename T>
+template <typename T, int CP>
 __global__ void wn_layout_kernel(const float* __restrict__ gsc, const float* __restrict__ v,
                                  const float* __restrict__ norm2, T* __restrict__ w_fwd, T* __restrict__ w_bwd,
                                  float* __restrict__ norm, int G, int cg, int K) {
@@ -68,25 +70,25 @@ __global__ void wn_layout_kernel(const float* __restrict__ gsc, const float* __r
 }
 
 // ---------------------------------------------------------------- fragment helpers
-template <typename T> struct Frag;
-template <> struct Frag<bf16> {
+template <typename T, int CP> struct Frag;
+template <int CP> struct Frag<bf16, CP> {
   typedef bf16x8 type;
-  static constexpr int NK = 1;  // fragment loads per 32-channel reduction
-  static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int) {
-    return *reinterpret_cast<const bf16x8*>(lds + row * PC<bf16>::RS + (lane >> 4) * 16);
+  static constexpr int NK = CP / 32;  // fragment loads per group reduction (32 channels each)
+  static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int kr) {
+    return *reinterpret_cast<const bf16x8*>(lds + row * PC<bf16, CP>::RS + kr * 64 + (lane >> 4) * 16);
   }
-  static __device__ __forceinline__ type gmem_row(const bf16* w, int row, int lane, int) {
-    return *reinterpret_cast<const bf16x8*>(w + (long)row * CP + (lane >> 4) * 8);
+  static __device__ __forceinline__ type gmem_row(const bf16* w, int row, int lane, int kr) {
+    return *reinterpret_cast<const bf16x8*>(w + (long)row * CP + kr * 32 + (lane >> 4) * 8);
   }
   static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
-template <> struct Frag<float> {
+template <int CP> struct Frag<float, CP> {
   typedef f32x4 type;
-  static constexpr int NK = 2;
+  static constexpr int NK = CP / 16;
   static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int kr) {
-    return *reinterpret_cast<const f32x4*>(lds + row * PC<float>::RS + kr * 64 + (lane >> 4) * 16);
+    return *reinterpret_cast<const f32x4*>(lds + row * PC<float, CP>::RS + kr * 64 + (lane >> 4) * 16);
   }
   static __device__ __forceinline__ type gmem_row(const float* w, int row, int lane, int kr) {
     return *reinterpret_cast<const f32x4*>(w + (long)row * CP + kr * 16 + (lane >> 4) * 4);
@@ -114,7 +116,7 @@ __device__ __forceinline__ void st2(bf16* p, const float* f) {
 
 // stage `nrows` window rows (frame t_first + row, group g) of `src` into LDS as [row][CP] (zero outside [0,Tn)
 // and for padded channels).  GP: multiply by gelu'(zc) and, for rows in [own0, own1), also write the product to dz.
-template <typename T, bool GP>
+template <typename T, int CP, bool GP>
 __device__ __forceinline__ void stage_rows(unsigned char* lds, const T* src, const T* zc, T* dz, int b, int Tn, int D,
                                            int cg, int g, int t_first, int nrows, int own0, int own1) {
   const int units = CP / 2;
@@ -134,56 +136,57 @@ __device__ __forceinline__ void stage_rows(unsigned char* lds, const T* src, con
         if (row >= own0 && row < own1) st2(dz + off, f);
       }
     }
-    st2(reinterpret_cast<T*>(lds + row * PC<T>::RS) + 2 * u, f);
+    st2(reinterpret_cast<T*>(lds + row * PC<T, CP>::RS) + 2 * u, f);
   }
 }
 
 // ---------------------------------------------------------------- forward / data-gradient
-template <typename T, bool BWD>
+template <typename T, int CP, bool BWD>
 __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, const T* __restrict__ zc_in,
                                                       const T* __restrict__ w, const float* __restrict__ bias,
                                                       T* __restrict__ out1, T* __restrict__ out2, int B, int Tn, int D,
                                                       int cg, int K, int pad_left) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  typedef Frag<T> F;
+  typedef Frag<T, CP> F;
+  constexpr int CB = PC<T, CP>::CB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
   const int nrows = TT + K - 1;
-  stage_rows<T, BWD>(lds, in, zc_in, out1, b, Tn, D, cg, g, t0 - pad_left, nrows, pad_left, pad_left + TT);
+  stage_rows<T, CP, BWD>(lds, in, zc_in, out1, b, Tn, D, cg, g, t0 - pad_left, nrows, pad_left, pad_left + TT);
   __syncthreads();
 
-  f32x4 acc[2][2];
+  f32x4 acc[CB][2];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * K * CP * CP;
   const int r = lane & 15;
   // weights stream from L2 (identical for every workgroup of the group): keep the NEXT tap's fragments in flight
-  typename F::type wn[F::NK][2];
+  typename F::type wn[F::NK][CB];
 #pragma unroll
   for (int kr = 0; kr < F::NK; ++kr)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) wn[kr][cb] = F::gmem_row(wg, cb * 16 + r, lane, kr);
+    for (int cb = 0; cb < CB; ++cb) wn[kr][cb] = F::gmem_row(wg, cb * 16 + r, lane, kr);
 #pragma unroll 2
   for (int j = 0; j < K; ++j) {
-    typename F::type wf[F::NK][2];
+    typename F::type wf[F::NK][CB];
 #pragma unroll
     for (int kr = 0; kr < F::NK; ++kr)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) wf[kr][cb] = wn[kr][cb];
+      for (int cb = 0; cb < CB; ++cb) wf[kr][cb] = wn[kr][cb];
     const int jn = j + 1 < K ? j + 1 : j;
 #pragma unroll
     for (int kr = 0; kr < F::NK; ++kr)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) wn[kr][cb] = F::gmem_row(wg + (long)jn * CP * CP, cb * 16 + r, lane, kr);
+      for (int cb = 0; cb < CB; ++cb) wn[kr][cb] = F::gmem_row(wg + (long)jn * CP * CP, cb * 16 + r, lane, kr);
 #pragma unroll
     for (int kr = 0; kr < F::NK; ++kr) {
       typename F::type xf[2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) xf[tt] = F::lds_row(lds, wave * 32 + tt * 16 + r + j, lane, kr);
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = F::mma(wf[kr][cb], xf[tt], acc[cb][tt]);
     }
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
     const int t = t0 + tl;
     if (t >= Tn) continue;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int co = cb * 16 + q * 4 + 2 * h;
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
           v[1] += bias[g * cg + co + 1];
           st2(out1 + off, v);
           float xv[2];
-          ld2(reinterpret_cast<const T*>(lds + (tl + pad_left) * PC<T>::RS) + co, xv);
+          ld2(reinterpret_cast<const T*>(lds + (tl + pad_left) * PC<T, CP>::RS) + co, xv);
           v[0] = xv[0] + gelu_f(v[0]);
           v[1] = xv[1] + gelu_f(v[1]);
           st2(out2 + off, v);
@@ -227,14 +230,13 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
 
 // ---------------------------------------------------------------- weight gradient
 // dws[g][j][co][ci] += sum_{b,t} dzc[b,t,g*cg+co] * x[b, t + j - pad_left, g*cg+ci]
-template <typename T> struct WgFrag;
-template <> struct WgFrag<bf16> {
+template <int CP> struct WgFrag {
   // 8 consecutive frames k = base + 8*(lane>>4) + e for column (c0 + lane&15): two transposing reads
   static __device__ __forceinline__ bf16x8 load(const unsigned char* lds, int base_row, int c0, int lane) {
     const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
-    const unsigned char* a0 = lds + (base_row + 8 * q + qq) * PC<bf16>::RS + (c0 + 4 * pp) * 2;
+    const unsigned char* a0 = lds + (base_row + 8 * q + qq) * PC<bf16, CP>::RS + (c0 + 4 * pp) * 2;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * PC<bf16>::RS));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * PC<bf16, CP>::RS));
     union {
       struct { s16x4 lo, hi; } s;
       bf16x8 v;
@@ -245,47 +247,47 @@ template <> struct WgFrag<bf16> {
   }
 };
 
-template <typename T>
+template <typename T, int CP>
 __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict__ dzc, const T* __restrict__ x,
                                                             float* __restrict__ dws, int B, int Tn, int D, int cg, int K,
                                                             int pad_left, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int RS = PC<T>::RS;
+  constexpr int RS = PC<T, CP>::RS, CB = PC<T, CP>::CB, TS = PC<T, CP>::TS, JW = PC<T, CP>::JW;
   unsigned char* ldsA = lds;              // dzc tile  [TS][CP]
   unsigned char* ldsB = lds + TS * RS;    // x window  [TS + K - 1][CP]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.y;
-  const int jbase = blockIdx.x * 32 + wave * 8;
+  const int jbase = blockIdx.x * (4 * JW) + wave * JW;
   const int ntt = (Tn + TS - 1) / TS;
-  f32x4 acc[8][2][2];
+  f32x4 acc[JW][CB][CB];
 #pragma unroll
-  for (int jj = 0; jj < 8; ++jj)
+  for (int jj = 0; jj < JW; ++jj)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib) acc[jj][cb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ib = 0; ib < CB; ++ib) acc[jj][cb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int tile = blockIdx.z; tile < B * ntt; tile += nsplit) {
     const int b = tile / ntt, t0 = (tile - b * ntt) * TS;
     __syncthreads();
-    stage_rows<T, false>(ldsA, dzc, nullptr, nullptr, b, Tn, D, cg, g, t0, TS, 0, 0);
-    stage_rows<T, false>(ldsB, x, nullptr, nullptr, b, Tn, D, cg, g, t0 - pad_left, TS + K - 1, 0, 0);
+    stage_rows<T, CP, false>(ldsA, dzc, nullptr, nullptr, b, Tn, D, cg, g, t0, TS, 0, 0);
+    stage_rows<T, CP, false>(ldsB, x, nullptr, nullptr, b, Tn, D, cg, g, t0 - pad_left, TS + K - 1, 0, 0);
     __syncthreads();
     if constexpr (sizeof(T) == 2) {
 #pragma unroll 1
       for (int ks = 0; ks < TS / 32; ++ks) {
-        bf16x8 fa[2];
+        bf16x8 fa[CB];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) fa[cb] = WgFrag<bf16>::load(ldsA, ks * 32, cb * 16, lane);
+        for (int cb = 0; cb < CB; ++cb) fa[cb] = WgFrag<CP>::load(ldsA, ks * 32, cb * 16, lane);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          bf16x8 fb[2];
+        for (int jj = 0; jj < JW; ++jj) {
+          bf16x8 fb[CB];
 #pragma unroll
-          for (int ib = 0; ib < 2; ++ib) fb[ib] = WgFrag<bf16>::load(ldsB, ks * 32 + jbase + jj, ib * 16, lane);
+          for (int ib = 0; ib < CB; ++ib) fb[ib] = WgFrag<CP>::load(ldsB, ks * 32 + jbase + jj, ib * 16, lane);
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
+            for (int ib = 0; ib < CB; ++ib)
               acc[jj][cb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], fb[ib], acc[jj][cb][ib], 0, 0, 0);
         }
       }
@@ -293,20 +295,20 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
       const int r = lane & 15, q = lane >> 4;
 #pragma unroll 1
       for (int kk = 0; kk < TS / 4; ++kk) {  // 4 frames per MFMA: frame = 4*kk + q
-        float fa[2];
+        float fa[CB];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
           fa[cb] = *reinterpret_cast<const float*>(ldsA + (4 * kk + q) * RS + (cb * 16 + r) * 4);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          float fb[2];
+        for (int jj = 0; jj < JW; ++jj) {
+          float fb[CB];
 #pragma unroll
-          for (int ib = 0; ib < 2; ++ib)
+          for (int ib = 0; ib < CB; ++ib)
             fb[ib] = *reinterpret_cast<const float*>(ldsB + (4 * kk + q + jbase + jj) * RS + (ib * 16 + r) * 4);
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
+            for (int ib = 0; ib < CB; ++ib)
               acc[jj][cb][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cb], fb[ib], acc[jj][cb][ib], 0, 0, 0);
         }
       }
@@ -314,13 +316,13 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
   }
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-  for (int jj = 0; jj < 8; ++jj) {
+  for (int jj = 0; jj < JW; ++jj) {
     const int j = jbase + jj;
     if (j >= K) continue;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
+      for (int ib = 0; ib < CB; ++ib)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int co = cb * 16 + 4 * q + e, ci = ib * 16 + r;
@@ -331,7 +333,7 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
 
 // ---------------------------------------------------------------- weight norm backward
 __global__ void __launch_bounds__(256) wn_dot_kernel(const float* __restrict__ dws, const float* __restrict__ v,
-                                                     float* __restrict__ dot, int cg, int K) {
+                                                     float* __restrict__ dot, int cg, int K, int CP) {
   __shared__ float red[4];
   const int j = blockIdx.x, g = blockIdx.y;
   float s = 0.f;
@@ -347,7 +349,7 @@ __global__ void __launch_bounds__(256) wn_dot_kernel(const float* __restrict__ d
 
 __global__ void wn_apply_kernel(const float* __restrict__ gsc, const float* __restrict__ v, const float* __restrict__ norm,
                                 const float* __restrict__ dws, const float* __restrict__ dot, float* __restrict__ dg,
-                                float* __restrict__ dv, int G, int cg, int K) {
+                                float* __restrict__ dv, int G, int cg, int K, int CP) {
   const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)G * cg * cg * K;
   if (o >= n) return;
@@ -361,95 +363,111 @@ __global__ void wn_apply_kernel(const float* __restrict__ gsc, const float* __re
   if (oc == 0 && ci == 0) dg[j] += dj / nj;
 }
 
-template <typename T> size_t fwd_lds(int K) { return (size_t)(TT + K - 1) * PC<T>::RS; }
-template <typename T> size_t wg_lds(int K) { return (size_t)(2 * TS + K - 1) * PC<T>::RS; }
+template <typename T, int CP> size_t fwd_lds(int K) { return (size_t)(TT + K - 1) * PC<T, CP>::RS; }
+template <typename T, int CP> size_t wg_lds(int K) { return (size_t)(2 * PC<T, CP>::TS + K - 1) * PC<T, CP>::RS; }
+template <typename Kern> void set_lds(Kern k, size_t bytes) {
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T, int CP>
+int prep_t(const float* g, const float* v, const float* norm2, void* w_fwd, void* w_bwd, float* norm, int groups, int cg, int K,
+           hipStream_t st) {
+  const long n = (long)groups * K * CP * CP;
+  hipLaunchKernelGGL((wn_layout_kernel<T, CP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2, (T*)w_fwd,
+                     (T*)w_bwd, norm, groups, cg, K);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+template <typename T, int CP, bool BWD>
+int conv_t(const void* in, const void* zc, const void* w, const float* bias, void* o1, void* o2, int B, int Tn, int D, int groups,
+           int K, int pad_left, hipStream_t st) {
+  dim3 grid((Tn + TT - 1) / TT, groups, B), block(256);
+  const size_t smem = fwd_lds<T, CP>(K);
+  set_lds(posconv_kernel<T, CP, BWD>, smem);
+  hipLaunchKernelGGL((posconv_kernel<T, CP, BWD>), grid, block, smem, st, (const T*)in, (const T*)zc, (const T*)w, bias, (T*)o1,
+                     (T*)o2, B, Tn, D, D / groups, K, pad_left);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+template <typename T, int CP>
+int wgrad_t(const void* dzc, const void* x, float* dws, int B, int Tn, int D, int groups, int K, hipStream_t st) {
+  constexpr int TS = PC<T, CP>::TS, JW = PC<T, CP>::JW;
+  const int ntt = (Tn + TS - 1) / TS;
+  int nsplit = B * ntt;
+  if (nsplit > 8) nsplit = 8;
+  dim3 grid(K / (4 * JW), groups, nsplit), block(256);
+  const size_t smem = wg_lds<T, CP>(K);
+  set_lds(posconv_wgrad_kernel<T, CP>, smem);
+  hipLaunchKernelGGL((posconv_wgrad_kernel<T, CP>), grid, block, smem, st, (const T*)dzc, (const T*)x, dws, B, Tn, D, D / groups, K,
+                     K / 2, nsplit);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
 
 }  // namespace
 
+// padded group width the kernels use for D / groups channels per group (0: not supported)
+int fh_posconv_cp(int cg) { return cg <= 32 ? 32 : (cg <= 64 ? 64 : 0); }
+
 int fh_posconv_prep_launch(int dtype, const float* g, const float* v, void* w_fwd, void* w_bwd, float* norm, int D,
                            int groups, int K, hipStream_t st) {
-  const int cg = D / groups;
-  if (cg > CP || cg % 2 || K > 1024 || K % 32) return -501;
+  const int cg = D / groups, cp = fh_posconv_cp(cg);
+  if (!cp || cg % 2 || K > 1024 || K % 32) return -501;
   // norm doubles as the ||v||^2 accumulator: [0, K) = norm, [K, 2K) = norm2 scratch
   float* norm2 = norm + K;
   hipLaunchKernelGGL(wn_norm2_kernel, dim3(K), dim3(256), 0, st, v, norm2, D * cg, K);
   FH_CHECK_LAUNCH();
-  const long n = (long)groups * K * CP * CP;
-  if (dtype == 0)
-    hipLaunchKernelGGL(wn_layout_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2,
-                       (float*)w_fwd, (float*)w_bwd, norm, groups, cg, K);
-  else
-    hipLaunchKernelGGL(wn_layout_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2,
-                       (bf16*)w_fwd, (bf16*)w_bwd, norm, groups, cg, K);
-  FH_CHECK_LAUNCH();
-  return 0;
+  if (cp == 32) return dtype == 0 ? prep_t<float, 32>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st)
+                                  : prep_t<bf16, 32>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st);
+  return dtype == 0 ? prep_t<float, 64>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st)
+                    : prep_t<bf16, 64>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st);
 }
 
 int fh_posconv_fwd_launch(int dtype, const void* x, const void* w_fwd, const float* bias, void* zc, void* y, int B,
                           int Tn, int D, int groups, int K, hipStream_t st) {
-  const int cg = D / groups;
-  if (cg > CP || cg % 2 || K % 2) return -501;
-  dim3 grid((Tn + TT - 1) / TT, groups, B), block(256);
-  if (dtype == 0)
-    hipLaunchKernelGGL((posconv_kernel<float, false>), grid, block, fwd_lds<float>(K), st, (const float*)x, nullptr,
-                       (const float*)w_fwd, bias, (float*)zc, (float*)y, B, Tn, D, cg, K, K / 2);
-  else
-    hipLaunchKernelGGL((posconv_kernel<bf16, false>), grid, block, fwd_lds<bf16>(K), st, (const bf16*)x, nullptr,
-                       (const bf16*)w_fwd, bias, (bf16*)zc, (bf16*)y, B, Tn, D, cg, K, K / 2);
-  FH_CHECK_LAUNCH();
-  return 0;
+  const int cg = D / groups, cp = fh_posconv_cp(cg);
+  if (!cp || cg % 2 || K % 2) return -501;
+  if (cp == 32) return dtype == 0 ? conv_t<float, 32, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st)
+                                  : conv_t<bf16, 32, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st);
+  return dtype == 0 ? conv_t<float, 64, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st)
+                    : conv_t<bf16, 64, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st);
 }
 
 int fh_posconv_bwd_data_launch(int dtype, const void* dsum, const void* zc, const void* w_bwd, void* dzc, void* dx,
                                int B, int Tn, int D, int groups, int K, hipStream_t st) {
-  const int cg = D / groups;
-  if (cg > CP || cg % 2 || K % 2) return -501;
-  dim3 grid((Tn + TT - 1) / TT, groups, B), block(256);
-  if (dtype == 0)
-    hipLaunchKernelGGL((posconv_kernel<float, true>), grid, block, fwd_lds<float>(K), st, (const float*)dsum,
-                       (const float*)zc, (const float*)w_bwd, nullptr, (float*)dzc, (float*)dx, B, Tn, D, cg, K,
-                       K - 1 - K / 2);
-  else
-    hipLaunchKernelGGL((posconv_kernel<bf16, true>), grid, block, fwd_lds<bf16>(K), st, (const bf16*)dsum,
-                       (const bf16*)zc, (const bf16*)w_bwd, nullptr, (bf16*)dzc, (bf16*)dx, B, Tn, D, cg, K,
-                       K - 1 - K / 2);
-  FH_CHECK_LAUNCH();
-  return 0;
+  const int cg = D / groups, cp = fh_posconv_cp(cg);
+  if (!cp || cg % 2 || K % 2) return -501;
+  const int pl = K - 1 - K / 2;
+  if (cp == 32) return dtype == 0 ? conv_t<float, 32, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st)
+                                  : conv_t<bf16, 32, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st);
+  return dtype == 0 ? conv_t<float, 64, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st)
+                    : conv_t<bf16, 64, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st);
 }
 
 int fh_posconv_bwd_weight_launch(int dtype, const void* dzc, const void* x, float* dws, float* dbias, int B, int Tn,
                                  int D, int groups, int K, hipStream_t st) {
-  const int cg = D / groups;
-  if (cg > CP || cg % 2 || K % 32) return -501;
-  const int ntt = (Tn + TS - 1) / TS;
-  int nsplit = B * ntt;
-  if (nsplit > 8) nsplit = 8;
-  dim3 grid(K / 32, groups, nsplit), block(256);
-  if (dtype == 0) {
-    hipFuncSetAttribute((const void*)posconv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)wg_lds<float>(K));
-    hipLaunchKernelGGL(posconv_wgrad_kernel<float>, grid, block, wg_lds<float>(K), st, (const float*)dzc,
-                       (const float*)x, dws, B, Tn, D, cg, K, K / 2, nsplit);
-  } else {
-    hipLaunchKernelGGL(posconv_wgrad_kernel<bf16>, grid, block, wg_lds<bf16>(K), st, (const bf16*)dzc, (const bf16*)x,
-                       dws, B, Tn, D, cg, K, K / 2, nsplit);
-  }
-  FH_CHECK_LAUNCH();
+  const int cg = D / groups, cp = fh_posconv_cp(cg);
+  if (!cp || cg % 2 || K % 32) return -501;
+  int rc;
+  if (cp == 32) rc = dtype == 0 ? wgrad_t<float, 32>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 32>(dzc, x, dws, B, Tn, D, groups, K, st);
+  else rc = dtype == 0 ? wgrad_t<float, 64>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64>(dzc, x, dws, B, Tn, D, groups, K, st);
+  if (rc) return rc;
   if (dbias) return fh_colsum_launch(dtype, dzc, dbias, B * Tn, D, D, 1, 0, 0, 0, 1.0f, st);
   return 0;
 }
 
 int fh_posconv_wn_bwd_launch(const float* g, const float* v, const float* norm, const float* dws, float* dg, float* dv,
                              int D, int groups, int K, hipStream_t st) {
-  const int cg = D / groups;
+  const int cg = D / groups, cp = fh_posconv_cp(cg);
+  if (!cp) return -501;
   // dot scratch lives behind norm / norm2: [2K, 3K)
   float* dot = const_cast<float*>(norm) + 2 * K;
   hipMemsetAsync(dot, 0, sizeof(float) * K, st);
-  hipLaunchKernelGGL(wn_dot_kernel, dim3(K, groups), dim3(256), 0, st, dws, v, dot, cg, K);
+  hipLaunchKernelGGL(wn_dot_kernel, dim3(K, groups), dim3(256), 0, st, dws, v, dot, cg, K, cp);
   FH_CHECK_LAUNCH();
   const long n = (long)groups * cg * cg * K;
   hipLaunchKernelGGL(wn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm, dws, dot, dg, dv,
-                     groups, cg, K);
+                     groups, cg, K, cp);
   FH_CHECK_LAUNCH();
   return 0;
 }

@@ -60,9 +60,13 @@ class W2V2Distil:
         self.attn_loss_type = t["attn_loss_type"]
         self.v_rel_loss_weight = t["v_rel_loss_weight"]
         self.random_layer_weight = t["random_layer_weight"]
-        for k in ("cnn_loss_weight", "sim_loss_weight", "attn_loss_weight", "v_rel_loss_weight"):
+        for k in ("cnn_loss_weight", "attn_loss_weight", "v_rel_loss_weight"):
             if t[k] > 0:
-                raise NotImplementedError(f"train.{k} > 0 is a next-scope loss option (SURVEY 8f rank 2); the fused kernel covers rec_loss (mse / l1)")
+                raise NotImplementedError(f"train.{k} > 0 is a next-scope loss option (SURVEY 8f rank 2); the fused kernels cover "
+                                          "rec_loss (mse / l1) and the cosine sim_loss")
+        if t["sim_loss_weight"] > 0 and t["distil_random_layer"] > 0:
+            # the reference itself cannot run this: sim_loss is 3-D and train.py:305 takes mean((0, 2, 3))
+            raise NotImplementedError("sim_loss_weight > 0 needs distil_random_layer == 0 (train.py:302-306 fails otherwise)")
         if t.get("delete_projections"):
             self.student_model._disable_projection_heads()
         if t.get("specaug"):
@@ -81,6 +85,7 @@ class W2V2Distil:
         self.batch_size = t["batch_size"]
         self.num_gpus = len(t["gpus"]) if isinstance(t["gpus"], list) else t["gpus"]
         self.accumulate = int(t.get("accumulate_grad_batches", 1))
+        self._rows_loss = self.sim_loss_weight > 0   # row-wise kernel (rec + cosine); its out[-1] is the fully weighted total
         self._set_loss_tables()
         # ---- optimizer state (configure_optimizers fills the schedule)
         self.opt_m = torch.zeros_like(self.engine.params)
@@ -108,6 +113,13 @@ class W2V2Distil:
             w[Lr - 1] = 1.0
             tl[Lr - 1] = n_teacher - 1  # teacher_results["layer_results"][-1] (train.py:255-257)
             self._mean_over_layers = 1.0
+        elif not self.student_model.layerwise_proj:
+            # DistilHuBERT-style head: task k predicts teacher layer pred_layer_id[k] (train.py:268-281)
+            ids = self.student_model.pred_layer_id
+            w = torch.full((len(ids),), 1.0 / len(ids))
+            tl = torch.tensor(ids, dtype=torch.int32)
+            if max(ids) >= n_teacher:
+                raise ValueError("pred_layer_id indexes teacher layers out of range")
         else:
             ids = self.student_model.pred_layer_id
             for i in ids:
@@ -130,10 +142,10 @@ class W2V2Distil:
         """train.py:236-405 for the built branch (rec_loss mse / l1, random-layer or pred_layer_id selection).
         Differentiable w.r.t. the student through the fused loss kernel's gradient."""
         proj = student_results["projections"]
-        pred = torch.stack(proj, dim=0)
+        pred = torch.stack(proj, dim=0) if isinstance(proj, (list, tuple)) else proj.permute(1, 0, 2, 3)  # -> [tasks][B][T][P]
         teacher = torch.stack([lr[0].transpose(0, 1) for lr in teacher_results["layer_results"]], dim=0).contiguous()
         out = _KDLossFn.apply(pred, teacher, self)
-        total = self.rec_loss_weight * out[-1]
+        total = out[-1] if self._rows_loss else self.rec_loss_weight * out[-1]
         return total.float(), self._loss_dict(out)
 
     def _loss_dict(self, out) -> Dict[str, torch.Tensor]:
@@ -143,6 +155,9 @@ class W2V2Distil:
             for i, l in enumerate(self.rand_l):
                 losses[f"rand_l{i}"] = out[l] * self.random_layer_weight
             losses[f"l{Lr - 1}"] = out[Lr - 1]
+        elif not self.student_model.layerwise_proj:
+            for k, pid in enumerate(self.student_model.pred_layer_id):
+                losses[f"layer{pid}"] = out[k]
         else:
             for pid in self.student_model.pred_layer_id:
                 losses[f"layer{pid}"] = out[pid]
@@ -214,8 +229,13 @@ class W2V2Distil:
         ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed)
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
-        out, d_pred = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer,
-                                          loss_type=0 if self.rec_loss_type == "mse" else 1, grad_scale=float(self.rec_loss_weight))
+        if self._rows_loss:
+            out, d_pred = self.engine.kd_loss_rows(ws, hid, self.layer_w, self.teacher_layer,
+                                                   loss_type=0 if self.rec_loss_type == "mse" else 1,
+                                                   rec_weight=float(self.rec_loss_weight), sim_weight=float(self.sim_loss_weight))
+        else:
+            out, d_pred = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer,
+                                              loss_type=0 if self.rec_loss_type == "mse" else 1, grad_scale=float(self.rec_loss_weight))
         self.engine.backward(ws, d_pred=d_pred)
         self._micro += 1
         if self._micro >= self.accumulate:
@@ -259,6 +279,17 @@ class _KDLossFn(torch.autograd.Function):
         Lh, B, Tp, P = pred.shape
         tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16
         lib = L.lib()
+        if task._rows_loss:
+            nblk = lib.fh_kd_loss_rows_nblk(B, Tp)
+            partials = torch.empty(2 * Lh * nblk, device=pred.device, dtype=torch.float32)
+            out = torch.empty(Lh + 1, device=pred.device, dtype=torch.float64)
+            d_pred = torch.empty_like(pred)
+            L.check(lib.fh_kd_loss_rows(eng.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(), d_pred.data_ptr(), task.layer_w.data_ptr(),
+                                        task.teacher_layer.data_ptr(), partials.data_ptr(), out.data_ptr(), Lh, B, Tp, teacher.shape[2], P,
+                                        B * teacher.shape[2] * P, 0 if task.rec_loss_type == "mse" else 1, float(task.rec_loss_weight),
+                                        float(task.sim_loss_weight), eng.stream()), "fh_kd_loss_rows")
+            ctx.save_for_backward(d_pred)
+            return out
         nblk = lib.fh_kd_loss_nblk(eng.c.dtype, B, Tp, P)
         partials = torch.empty(Lh * nblk, device=pred.device, dtype=torch.float32)
         out = torch.empty(Lh + 1, device=pred.device, dtype=torch.float64)

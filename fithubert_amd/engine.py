@@ -44,8 +44,12 @@ def unsupported(cfg: CustomStudentModelConfig) -> Optional[str]:
     if cfg.enable_tr_layer and (cfg.tr_layer_type != "conv1d" or cfg.tr_layer_index != 0 or cfg.tr_reduce_factor != 2):
         return "time reduction is built for tr_layer_type='conv1d', tr_layer_index=0, tr_reduce_factor=2 (fithubert.yaml)"
     if not cfg.layerwise_proj:
-        return "DistilHuBERT-style SplitLinear heads (layerwise_proj=False, ex.yaml) are the next scope row, not built yet"
-    if cfg.pred_head_final_dim == cfg.encoder_embed_dim:
+        # DistilHuBERT-style head (model.py:364-368): Linear -> GELU -> SplitLinear over len(pred_layer_id) tasks
+        if len(cfg.pred_layers()) < 2:
+            return "layerwise_proj=False needs at least two pred_layer_id tasks (SplitLinear); the single-task nn.Linear form is not built"
+        if cfg.enable_tr_layer:
+            return "layerwise_proj=False together with enable_tr_layer (shared upsampler, model.py:504-505) is not built"
+    elif cfg.pred_head_final_dim == cfg.encoder_embed_dim:
         return "pred_head_final_dim == encoder_embed_dim (no lin_proj) is not built"
     if cfg._cnn_weight > 0:
         return "cnn_proj_head / cnn_loss_weight > 0 is not built yet"
@@ -77,6 +81,8 @@ def make_config_c(cfg: CustomStudentModelConfig, dtype: str) -> StudentConfigC:
     c.activation_dropout = cfg.activation_dropout
     c.dropout_input = cfg.dropout_input
     c.feature_grad_mult = cfg.feature_grad_mult
+    c.n_tasks = 0 if cfg.layerwise_proj else len(cfg.pred_layers())
+    c.inter_dim = cfg.pred_head_inter_dim if cfg.pred_head_inter_dim > 0 else cfg.encoder_embed_dim  # model.py:334-335
     return c
 
 
@@ -257,6 +263,25 @@ class StudentEngine:
             ws.wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None,
             d_pred.data_ptr() if d_pred is not None else None, d_hidden.data_ptr() if d_hidden is not None else None,
             self.stream()), "fh_student_backward")
+
+    def kd_loss_rows(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
+                     loss_type: int = 1, rec_weight: float = 1.0, sim_weight: float = 1.0, want_grad: bool = True):
+        """rec (l1 | mse) + cosine loss of the DistilHuBERT-style recipe (train.py:284-314, 372-378), fused with its
+        gradient.  Returns (out fp64 [L+1]: per-task rec+sim means, weighted total; d_pred = d total / d pred or None)."""
+        pred = ws.view("pred")
+        Lh, B, Tp, P = pred.shape
+        assert teacher.is_cuda and teacher.is_contiguous() and teacher.dim() == 4 and teacher.shape[1] == B and teacher.shape[3] == P
+        tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16
+        Tt = teacher.shape[2]
+        nblk = self.lib.fh_kd_loss_rows_nblk(B, Tp)
+        partials = torch.empty(2 * Lh * nblk, device=self.device, dtype=torch.float32)
+        out = torch.empty(Lh + 1, device=self.device, dtype=torch.float64)
+        d_pred = torch.empty_like(pred) if want_grad else None
+        L.check(self.lib.fh_kd_loss_rows(self.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(),
+                                         d_pred.data_ptr() if want_grad else None, layer_w.data_ptr(), teacher_layer.data_ptr(),
+                                         partials.data_ptr(), out.data_ptr(), Lh, B, Tp, Tt, P, B * Tt * P, loss_type,
+                                         float(rec_weight), float(sim_weight), self.stream()), "fh_kd_loss_rows")
+        return out, d_pred
 
     def kd_loss(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
                 loss_type: int = 0, grad_scale: float = 1.0, want_grad: bool = True):

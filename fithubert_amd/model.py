@@ -114,6 +114,9 @@ class CustomStudentModel(nn.Module):
                 t = torch.randn(shape, generator=g) * math.sqrt(4.0 / (k * e))
             elif name.endswith("weight_g"):
                 t = None  # set from weight_v below (weight_norm initialises g = ||v||)
+            elif name in ("proj_head.2.weight", "proj_head.2.bias"):  # SplitLinear, module.py:596-603
+                bound = float(self.engine.c.inter_dim) ** -0.5
+                t = (torch.rand(shape, generator=g) * 2 - 1) * bound
             elif "layer_norm.weight" in name or name.endswith(".2.weight"):
                 t = torch.ones(shape)
             elif name.endswith("bias") and ("upsampler" in name or name == "encoder.layers.0.bias" and self.cfg.enable_tr_layer):
@@ -142,7 +145,7 @@ class CustomStudentModel(nn.Module):
             if self._heads_on:
                 m[name] = name
             elif name.startswith("proj_head."):
-                if name.startswith(last):
+                if self.layerwise_proj and name.startswith(last):  # model.py:393-399: the non-layerwise head is dropped whole
                     m["final_proj." + name[len(last):]] = name
             else:
                 m[name] = name
@@ -230,7 +233,10 @@ class CustomStudentModel(nn.Module):
         L = self.cfg.encoder_layers
         layer_results = [(xo[i + 1].transpose(0, 1), None, f2[i].transpose(0, 1)) for i in range(L)]
         tr_layer_results = [xo[0].transpose(0, 1)] if self.cfg.enable_tr_layer else []
-        if self._heads_on:
+        if not self.layerwise_proj:  # model.py:503-516: x is the encoder output, projections B x N x T x D
+            x = xo[L]
+            projections = pred.permute(1, 0, 2, 3) if self._heads_on else None
+        elif self._heads_on:
             projections = [pred[i] for i in range(L)]
             x = projections[-1]
         else:

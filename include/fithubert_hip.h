@@ -204,6 +204,10 @@ typedef struct {
   int pred_dim;                    /* pred_head_final_dim */
   float dropout, attention_dropout, activation_dropout, dropout_input;
   float feature_grad_mult;
+  /* heads: n_tasks == 0: one LayerWiseProjHead per layer (layerwise_proj, modules/module.py:625-661).
+   * n_tasks >= 2: DistilHuBERT-style head on the LAST layer only (modules/model.py:364-368,508-516): Linear(D, inter*n_tasks)
+   * -> GELU -> SplitLinear(inter, n_tasks, pred_dim) (modules/module.py:585-619); "pred" is then [n_tasks][B][T][pred_dim]. */
+  int n_tasks, inter_dim;
 } fh_student_config;
 
 /* per-call shape info */

@@ -246,3 +246,60 @@ def test_gemm_autotune_table_changes_speed_not_results():
         lib.fh_gemm_set_path(9)
     assert _rel_l2(pred_t, pred_d) < 2e-3       # forward GEMMs: same bf16 inputs, fp32 accumulation in a different order
     assert _rel_l2(grad_t, grad_d) < 1e-2
+
+
+@pytest.mark.parametrize("dtype,tol_l2", [("float32", 2e-4), ("bf16", 2.5e-2)])
+def test_ex_config_split_linear_heads_l1_cosine(dtype, tol_l2, golden_dir):
+    """ex.yaml path: standard 7 x 512 frontend, 64-wide heads, no TR layer, Linear -> GELU -> SplitLinear
+    head on the last layer, l1 + cosine loss over pred_layer_id, feature_grad_mult = 0.1.  Forward / loss against the golden
+    vectors captured from the reference; gradients against the oracle's autograd."""
+    fx = np.load(os.path.join(golden_dir, "student_ex.npz"))
+    cfg = yaml.safe_load(str(fx["cfg_yaml"]))
+    cfg = dict(cfg, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    eng, sd = _engine(cfg, int(fx["weight_seed"]), dtype)
+    assert eng.c.n_tasks == 3 and eng.c.inter_dim == 768 and eng.c.tr_factor == 0
+    wav = torch.from_numpy(fx["wav"])
+    ws = eng.forward(wav.to(DEV), None, training=True, seed=1)
+    L = cfg["encoder_layers"]
+    x = ws.view("xo")[L].float()                       # encoder output = results["x"] on this path
+    pred = ws.view("pred").float()                     # [task][B][T][P]
+    assert _rel_l2(x[:, ::2, ::8], torch.from_numpy(fx["x_sub"])) < tol_l2
+    assert _rel_l2(pred.permute(1, 0, 2, 3)[:, :, ::2, ::8], torch.from_numpy(fx["proj_sub"])) < tol_l2
+    Te = x.shape[1]
+    tg = torch.Generator().manual_seed(int(fx["teacher_seed"]))
+    t_layers = [torch.randn(Te, 2, 768, generator=tg) for _ in range(12)]
+    teacher = torch.stack([t.transpose(0, 1) for t in t_layers]).contiguous()
+    ids = [3, 7, 11]
+    w = torch.full((3,), 1.0 / 3)
+    out, d_pred = eng.kd_loss_rows(ws, teacher.to(DEV), w.to(DEV), torch.tensor(ids, dtype=torch.int32, device=DEV),
+                                   loss_type=1, rec_weight=1.0, sim_weight=1.0)
+    eng.grads.zero_()
+    eng.backward(ws, d_pred=d_pred)
+    torch.cuda.synchronize()
+    ref_loss = float(fx["loss"])
+    if dtype == "float32":
+        assert abs(out[3].item() - ref_loss) < 1e-4, (out[3].item(), ref_loss)
+        np.testing.assert_allclose(out[:3].cpu().numpy(), fx["layer_losses"], rtol=2e-4)
+    else:
+        assert abs(out[3].item() - ref_loss) < 2e-2 * ref_loss
+    # gradients: oracle autograd on the same weights / inputs
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = S.student_forward(sdg, cfg, wav.clone(), None, training=True)
+    tc = dict(rec_loss_weight=1.0, rec_loss_type="l1", sim_loss_weight=1.0, distil_random_layer=0, random_layer_weight=0)
+    loss, _ = LR.calculate_loss(ref, {"layer_results": [(t, (None, None)) for t in t_layers]}, tc, pred_layer_id=ids, layerwise_proj=False)
+    loss.backward()
+    grads = eng.param_views(eng.grads)
+    tol = 2e-3 if dtype == "float32" else 6e-2
+    bad = []
+    for k, gv in grads.items():
+        rg = sdg[k].grad
+        if rg is None:
+            assert gv.abs().max().item() == 0, k
+            continue
+        n = rg.norm().item()
+        if n < 1e-6:
+            continue
+        e = _rel_l2(gv.float(), rg)
+        if e > tol:
+            bad.append((k, e, n))
+    assert not bad, bad

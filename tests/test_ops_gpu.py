@@ -156,17 +156,19 @@ def _posconv_ref(x, g, v, bias, groups, K):
 
 
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("D", [480, 768])  # 30 channels per group (fithubert.yaml) / 48 (ex.yaml): padded to 32 / 64
 @pytest.mark.parametrize("B,T", [(2, 99), (1, 499), (3, 19)])
-def test_posconv_fwd_bwd(dt, B, T):
+def test_posconv_fwd_bwd(dt, B, T, D):
     torch.manual_seed(B * 1000 + T)
-    D, G, K = 480, 16, 128
+    G, K = 16, 128
     cg = D // G
+    CPAD = 32 if cg <= 32 else 64
     lib = L.lib()
     x = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
     g = 0.5 + torch.rand(1, 1, K, device=DEV)
     v = torch.randn(D, cg, K, device=DEV) * (4.0 / (K * D)) ** 0.5 * 3
     bias = 0.1 * torch.randn(D, device=DEV)
-    wf = torch.empty(G, K, 32, 32, device=DEV, dtype=_tdt(dt))
+    wf = torch.empty(G, K, CPAD, CPAD, device=DEV, dtype=_tdt(dt))
     wb = torch.empty_like(wf)
     norm = torch.empty(3 * K, device=DEV)
     L.check(lib.fh_posconv_prepare(dt, _p(g), _p(v), _p(wf), _p(wb), _p(norm), D, G, K, _st()), "prep")
@@ -190,7 +192,7 @@ def test_posconv_fwd_bwd(dt, B, T):
     zc_in = zc_ref.detach().to(_tdt(dt)).contiguous()
     L.check(lib.fh_posconv_backward_data(dt, _p(dsum), _p(zc_in), _p(wb), _p(dzc), _p(dx), B, T, D, G, K, _st()), "dgrad")
     assert _rel(dx, xr.grad) < _tol(dt) * 1.5
-    dws = torch.zeros(G, K, 32, 32, device=DEV)
+    dws = torch.zeros(G, K, CPAD, CPAD, device=DEV)
     dbias = torch.zeros(D, device=DEV)
     L.check(lib.fh_posconv_backward_weight(dt, _p(dzc), _p(x), _p(dws), _p(dbias), B, T, D, G, K, _st()), "wgrad")
     assert _rel(dbias, br.grad) < _tol(dt) * 3
