@@ -174,3 +174,52 @@ def test_baseline_configs_3_4_5_plumbing():
             ref = S.student_forward(sd, y["distiller"], b["x"], b["padding_mask"])
         assert torch.equal(res["padding_mask"].cpu(), ref["padding_mask"])
         assert _rel_l2(res["x"].float(), ref["x"]) < 3e-2
+
+
+def test_ex_yaml_distilhubert_recipe_end_to_end():
+    """BASELINE.json configs[3] second half / SURVEY 8f rank 2: the shipped ex.yaml (standard frontend initialised from the
+    teacher's, 2 wide layers initialised from the teacher's first two, SplitLinear heads over teacher layers 3/7/11,
+    l1 + cosine loss, feature_grad_mult 0.1) through the task surface: init-from-teacher, module-API loss against the oracle's
+    calculate_loss, fused training steps."""
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+    from oracle import loss_ref as LR
+
+    y = yaml.safe_load(open(os.path.join(ROOT, "conf", "ex.yaml")))
+    y["distiller"].update(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    y["train"].update(accumulate_grad_batches=1)
+    task = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=TeacherConfig.base("hubert"), seed=0, teacher_native_frontend=True)
+    sm = task.student_model
+    # init_conv_layers / init_encoder_layers (model.py:327-332, 560-587): weight copies from the teacher
+    tsd = task.teacher_model.model.state_dict()
+    ssd = sm.state_dict()
+    for k in ("feature_extractor.conv_layers.3.0.weight", "post_extract_proj.weight", "encoder.layers.1.fc1.weight",
+              "encoder.pos_conv.0.weight_v"):
+        assert torch.equal(ssd[k].float().cpu(), tsd[k].float().cpu()), k
+    assert [int(v) for v in task.teacher_layer.tolist()] == [3, 7, 11]
+    ds = SyntheticLibriDataset([16000, 14000, 12000, 9000], batch_size=2, seed=2)
+    b = {k: v.to(DEV) for k, v in ds[0].items()}
+    # module-API path: forward -> calculate_loss (autograd) against the oracle on the same weights
+    sm.train()
+    sres, tres = task(b["x"], b["padding_mask"])
+    assert sres["projections"].shape[:2] == (2, 3) and sres["x"].shape[-1] == 768
+    total, losses = task.calculate_loss(sres, tres)
+    total.backward()
+    assert sm.flat.grad is not None and torch.isfinite(sm.flat.grad).all()
+    sd = {k: v.detach().float().cpu() for k, v in sm.state_dict().items()}
+    with torch.no_grad():
+        ref = S.student_forward(sd, y["distiller"], b["x"].cpu(), b["padding_mask"].cpu(), training=True)
+        t_layers = [(lr[0].float().cpu(), (None, None)) for lr in tres["layer_results"]]
+        lo, ld = LR.calculate_loss(ref, {"layer_results": t_layers}, y["train"], pred_layer_id=[3, 7, 11], layerwise_proj=False)
+    assert abs(total.item() - lo.item()) < 3e-2 * abs(lo.item()), (total.item(), lo.item())
+    for k in ("layer3", "layer7", "layer11"):
+        assert abs(losses[k].item() - ld[k].item()) < 3e-2 * abs(ld[k].item()), k
+    # fused hot path
+    task.configure_optimizers(num_training_steps=20)
+    vals = []
+    for i in range(6):
+        bi = {k: v.to(DEV) for k, v in ds[i % 2].items()}
+        vals.append(task.training_step(bi, batch_idx=i, next_batch={k: v.to(DEV) for k, v in ds[(i + 1) % 2].items()})[-1].item())
+    assert all(v == v and v < 1e3 for v in vals), vals
+    assert min(vals[-2:]) < vals[0] + 1e-3, vals          # l1 + cosine goes down on a repeated pair of batches
