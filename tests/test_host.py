@@ -79,3 +79,20 @@ def test_unsupported_configs_fail_loudly():
     assert unsupported(CustomStudentModelConfig(**d))
     with pytest.raises(NotImplementedError):
         param_table(CustomStudentModelConfig(**d))
+
+
+def test_ex_yaml_param_table_equals_reference_state_dict():
+    """ex.yaml (DistilHuBERT-style head: proj_head.0 Linear, proj_head.2 SplitLinear [task][Din][Dout], no TR layer)."""
+    import os
+    y = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "ex.yaml")))
+    cfg = CustomStudentModelConfig(**y["distiller"])
+    assert unsupported(cfg) is None
+    table, total = param_table(cfg, "bf16")
+    ours = {n: s for n, _, s in table}
+    ref = S.param_shapes(y["distiller"])
+    assert set(ours) == set(ref), (set(ours) ^ set(ref))
+    for k in ref:
+        assert tuple(ours[k]) == tuple(ref[k]), k
+    assert ours["proj_head.2.weight"] == (3, 768, 768) and ours["proj_head.2.bias"] == (1, 1, 3, 768)
+    d = dict(y["distiller"], pred_layer_id="[11]")
+    assert unsupported(CustomStudentModelConfig(**d))  # single-task nn.Linear head: not built, fails loudly
