@@ -205,8 +205,9 @@ def main():
             "config": {"workload": "fithubert.yaml student (480-dim, 12 layers) + HuBERT-Base-shaped teacher (random init), "
                                    "full distillation step on fixed 10 s clips (BASELINE.json configs[1])",
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": SAMPLES_10S, "parallelism": f"dp{world}",
-                       "teacher": "bf16; transformer on PyTorch-ROCm (rocBLAS/hipBLASLt + SDPA); conv frontend + pos-conv: " +
-                                  ("HIP kernels shared with the student" if args.teacher_frontend == "native" else "PyTorch-ROCm (MIOpen)"), "optimizer": "fused AdamW every step"},
+                       "teacher": "bf16; " + ("conv frontend, pos-conv, attention, add+LayerNorm: HIP kernels shared with the student; "
+                                              "q|k|v / out-proj / fc1 / fc2 GEMMs: hipBLASLt via PyTorch-ROCm" if args.teacher_frontend == "native"
+                                              else "stock PyTorch-ROCm (MIOpen convs, hipBLASLt, SDPA)"), "optimizer": "fused AdamW every step"},
             "step_tflops": round(value * GF_STEP / 1e3, 1),
             "step_frac_of_mfma_peak": round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
             "final_loss": loss,

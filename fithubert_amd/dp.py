@@ -50,8 +50,8 @@ class GradSync:
     def launch(self) -> None:
         """Enqueue the reduction behind everything already queued on the current stream; returns immediately."""
         self._works = []
-        if self.world == 1:
-            return
+        if not dist.is_initialized():
+            return  # single process without a group; a 1-rank group still runs the (trivial) collective
         for a, b in self.bounds:
             self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
