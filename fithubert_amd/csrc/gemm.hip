@@ -1342,6 +1342,220 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
+// ------------------------------------------------------------------ 8-phase form (R_CONTIG x R_CONTIG), after the guide's 256^2 template
+// 256 x 256 tile, BK = 64, two 64-KiB tile buffers, 8 waves (2 x 4), each wave's 128 x 64 output in four quadrants.  A K-tile
+// is four phases { LDS reads of the quadrant's fragments + ONE quarter of the NEXT tile by LDS-DMA (2 instructions) | barrier |
+// 16 MFMAs | barrier }; the next tile's quarters are issued in the order the phases will need them
+//   A(mh0) B(nh0) B(nh1) A(mh1)      (mh / nh: upper / lower 64 rows, left / right 32 columns of every wave's tile)
+// so one counted wait per two phases suffices: vmcnt(4) in phase 2 (retires A(mh1) of this tile, read in phase 3) and
+// vmcnt(2) in phase 4 (retires the first three quarters of the next tile).  Waves 4-7 run one barrier behind waves 0-3, so
+// each SIMD alternates one wave reading / issuing with one wave in its MFMA cluster.
+struct QuarterLoader {  // one operand, R_CONTIG, 256 rows x 64 k, image = 16-row x 32-k sub-tiles (st_16x32), as RingLoader
+  const bf16* base;
+  long off[2];       // [half]
+  long segdelta;
+  unsigned vmask;
+  int kch, wave, rt[2];
+  const unsigned char* ptr[2][2];  // [half][ks]
+  int step[2][2];
+  // is_x: X operand (halves = upper / lower 64 rows of each of the 2 wave rows); else Y (halves = 32-column halves of 4 wave columns)
+  __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid, bool is_x) {
+    base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
+    wave = tid >> 6;
+    const int lane = tid & 63, r = lane >> 2;
+    kch = (lane & 3) ^ ((r >> 3) << 1);
+    vmask = 0;
+    segdelta = (long)(o.tshift[1] - o.tshift[0]) * o.ld + (o.segoff[1] - o.segoff[0]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      rt[h] = is_x ? (wave >> 2) * 8 + h * 4 + (wave & 3) : (wave >> 1) * 4 + h * 2 + (wave & 1);
+      const int idx = idx0 + rt[h] * 16 + r;
+      const bool rv = idx < idx_limit;
+      RowMap rm = map_row(rv ? idx : 0, o.rpb);
+      off[h] = (long)rm.b * o.bstride + (long)(rm.t + o.tshift[0]) * o.ld + o.segoff[0];
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        const int ts = rm.t + o.tshift[sg];
+        const bool v = rv && (sg < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid));
+        vmask |= (v ? 1u : 0u) << (2 * h + sg);
+      }
+    }
+  }
+  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int k = k0 + ks * 32 + kch * 8;
+        const bool v = (k < Kseg) && ((vmask >> (2 * h + seg)) & 1u);
+        ptr[h][ks] = v ? (const unsigned char*)(base + off[h] + (long)seg * segdelta + k) : (const unsigned char*)g_zero_chunk;
+        step[h][ks] = v ? 128 : 0;
+      }
+  }
+  __device__ __forceinline__ void set_zero() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        ptr[h][ks] = (const unsigned char*)g_zero_chunk;
+        step[h][ks] = 0;
+      }
+  }
+  __device__ __forceinline__ void issue_half(unsigned char* tile, int h) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      glds16(ptr[h][ks], tile + (rt[h] * 2 + ks) * 1024);
+      ptr[h][ks] += step[h][ks];
+    }
+  }
+};
+
+__global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
+  constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
+  typedef RingLoader<FH_R_CONTIG, 256, 64, 8> FR;  // fragment addressing of the shared image layout
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.z;
+  const int tiles_j = (p.N + 255) / 256;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
+  const int i0 = ti * 256, j0 = tj * 256;
+  const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
+  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
+  const int t0 = blockIdx.y * per_split;
+  const int t1 = min(ntiles, t0 + per_split);
+  if (t0 >= t1) return;
+  const int nt = t1 - t0;
+  const bool late = __builtin_amdgcn_readfirstlane(tid) >= 256;
+
+  QuarterLoader lx, ly;
+  lx.init(p.X, g, i0, p.M, tid, true);
+  ly.init(p.Y, g, j0, p.N, tid, false);
+  f32x4 acc[4][8];  // [n][m]
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xi0 = (wave >> 2) * 128, yj0 = (wave & 3) * 64;  // wave rows 0-1 (X), wave columns 0-3 (Y)
+
+  int is_seg = t0 / tiles_per_seg;
+  int is_k0 = (t0 - is_seg * tiles_per_seg) * BK_;
+  int issued = 0;
+  bool need_slow = true;
+  auto advance = [&]() {
+    if (issued == nt) {
+      lx.set_zero();
+      ly.set_zero();
+    } else if (issued < nt) {
+      const bool partial = is_k0 + BK_ > p.Kseg;
+      if (need_slow || partial) {
+        lx.set_tile(p.X, is_seg, is_k0, p.Kseg);
+        ly.set_tile(p.Y, is_seg, is_k0, p.Kseg);
+      }
+      is_k0 += BK_;
+      need_slow = false;
+      if (is_k0 >= p.Kseg) {
+        is_k0 = 0;
+        is_seg = min(is_seg + 1, 1);
+        need_slow = true;
+      }
+    }
+    ++issued;
+  };
+  // prologue: tile 0 in need order; its last quarter may still be in flight when the loop starts
+  advance();
+  lx.issue_half(lds, 0);
+  ly.issue_half(lds + XT, 0);
+  ly.issue_half(lds + XT, 1);
+  lx.issue_half(lds, 1);
+  asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+  if (late) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 fa[2][4], fb[2][2];  // [ks][m-tile of the half], [ks][n-tile of the half]
+#define FH_PHASE_TAIL(WAITSTR)                                   \
+  asm volatile(WAITSTR ::: "memory");                            \
+  __builtin_amdgcn_sched_barrier(0);                             \
+  __builtin_amdgcn_s_barrier();                                  \
+  __builtin_amdgcn_sched_barrier(0);                             \
+  __builtin_amdgcn_s_setprio(1);
+#define FH_PHASE_MMA(MH, NH)                                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m)                       \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[(NH) * 2 + n][(MH) * 4 + m] =                                  \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][n], fa[ks][m], acc[(NH) * 2 + n][(MH) * 4 + m], 0, 0, 0);     \
+  __builtin_amdgcn_s_setprio(0);                                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);
+#define FH_READ_A(MH)                                                                                                  \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m) fa[ks][m] =           \
+      FR::frag(bx, xi0 + (MH) * 64 + 16 * m, ks, lane);
+#define FH_READ_B(NH)                                                                                                  \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int n = 0; n < 2; ++n) fb[ks][n] =           \
+      FR::frag(by, yj0 + (NH) * 32 + 16 * n, ks, lane);
+
+  for (int it = 0; it < nt; ++it) {
+    const unsigned char* bx = lds + (it & 1) * STAGE;
+    const unsigned char* by = bx + XT;
+    unsigned char* wx = lds + ((it + 1) & 1) * STAGE;
+    unsigned char* wy = wx + XT;
+    // phase 1: quadrant (mh0, nh0); next tile's A(mh0)
+    FH_READ_B(0)
+    FH_READ_A(0)
+    advance();
+    lx.issue_half(wx, 0);
+    FH_PHASE_TAIL("s_waitcnt lgkmcnt(0)")
+    FH_PHASE_MMA(0, 0)
+    // phase 2: (mh0, nh1); next tile's B(nh0); this tile's A(mh1) must have landed for phase 3
+    FH_READ_B(1)
+    ly.issue_half(wy, 0);
+    FH_PHASE_TAIL("s_waitcnt vmcnt(4) lgkmcnt(0)")
+    FH_PHASE_MMA(0, 1)
+    // phase 3: (mh1, nh1); next tile's B(nh1)
+    FH_READ_A(1)
+    ly.issue_half(wy, 1);
+    FH_PHASE_TAIL("s_waitcnt lgkmcnt(0)")
+    FH_PHASE_MMA(1, 1)
+    // phase 4: (mh1, nh0); next tile's A(mh1); the next tile's first three quarters must have landed
+    FH_READ_B(0)
+    lx.issue_half(wx, 1);
+    FH_PHASE_TAIL("s_waitcnt vmcnt(2) lgkmcnt(0)")
+    FH_PHASE_MMA(1, 0)
+  }
+#undef FH_PHASE_TAIL
+#undef FH_PHASE_MMA
+#undef FH_READ_A
+#undef FH_READ_B
+  if (!late) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  unsigned char* my = lds + wave * EPI_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
+    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g);
+  }
+}
+
+int launch_8ph(const GemmParams& p, hipStream_t stream) {
+  const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256;
+  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(512);
+  const size_t smem = 131072;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_8ph_kernel, grid, block, smem, stream, p);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int BM_, int BN_, int WM, int WN, int BK_, int NST> int launch_ring(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM_ - 1) / BM_, tiles_j = (p.N + BN_ - 1) / BN_;
   dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(WM * WN * 64);
@@ -1375,8 +1589,9 @@ bool ring_ok(const GemmParams& p, int bk) {
 // ------------------------------------------------------------------ bf16 main-loop selection
 // g_gemm_path: 0 = 16x16x32 register staging, 1 = 128-tile LDS-DMA ring, 2 = 32x32x16 register staging, 3 = 256x256 ring
 // (BK 64, 2 stages), 4 = 256x128 ring (BK 32, 3 stages, 2 workgroups / CU), 5 = 256x256 ring (BK 32, 4 stages),
-// 6 = 256x256 ping-pong ring (BK 32, two barrier-staggered wave groups), 9 = per-shape choice (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
-// FH_GEMM_PATH = reg | dma | 2..6 forces one loop (A/B comparisons; tools/gemm_bench.py).
+// 6 = 256x256 ping-pong ring (BK 32, two barrier-staggered wave groups), 7 = 256x256 8-phase loop (BK 64, R_CONTIG x R_CONTIG
+// only), 9 = per-shape choice (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
+// FH_GEMM_PATH = reg | dma | 2..7 forces one loop (A/B comparisons; tools/gemm_bench.py).
 int g_gemm_path = -1;
 int g_tune_mode = 0;
 int g_last_loop = 2;  // main loop the last bf16 launch ran (for the per-launch profile)
@@ -1391,18 +1606,21 @@ bool dma_ok(const GemmParams& p) {
 void resolve_path() {
   if (g_gemm_path < 0) {
     const char* e = getenv("FH_GEMM_PATH");
-    g_gemm_path = !e ? 9 : (e[0] == 'd' ? 1 : (e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '6') ? e[0] - '0' : 9)));
+    g_gemm_path = !e ? 9 : (e[0] == 'd' ? 1 : (e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '7') ? e[0] - '0' : 9)));
   }
 }
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   g_last_loop = 2;
-  if ((path == 1 && dma_ok(p)) || path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32))) g_last_loop = path;
+  if ((path == 1 && dma_ok(p)) || path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32)) ||
+      (path == 7 && p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG))
+    g_last_loop = path;
   if (path == 1 && dma_ok(p)) return launch_dma(p, stream);
   if (path == 0) return launch_t<bf16>(p, stream);
   if (path == 3 && ring_ok(p, 64)) return launch_ring<256, 256, 2, 4, 64, 2>(p, stream);
   if (path == 4 && ring_ok(p, 32)) return launch_ring<256, 128, 2, 2, 32, 3>(p, stream);
   if (path == 5 && ring_ok(p, 32)) return launch_ring<256, 256, 2, 4, 32, 4>(p, stream);
   if (path == 6 && ring_ok(p, 32)) return launch_pp(p, stream);
+  if (path == 7 && p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG) return launch_8ph(p, stream);
   return launch_32(p, stream);
 }
 
@@ -1453,6 +1671,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
     } else {
       if (ring_ok(p, 64)) add(3, p.splitk);
       if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); add(6, p.splitk); }
+      if (p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG) add(7, p.splitk);
     }
   }
   hipEvent_t a, b;

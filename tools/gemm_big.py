@@ -6,7 +6,7 @@ from fithubert_amd import _lib as L
 
 lib = L.lib()
 st = lambda: torch.cuda.current_stream().cuda_stream
-PATHS = [int(x) for x in os.environ.get("PATHS", "2,3,4,5,6").split(",")]
+PATHS = [int(x) for x in os.environ.get("PATHS", "3,5,7").split(",")]
 SHAPES = [(8192, 8192, 8192), (4096, 4096, 4096), (63872, 2304, 768), (63872, 768, 3072), (63872, 768, 768), (63872, 3072, 768),
           (31872, 480, 480), (31872, 1440, 480), (31872, 480, 1440), (2047872, 256, 768), (2047872, 512, 1536)]
 
