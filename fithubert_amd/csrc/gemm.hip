@@ -1350,7 +1350,8 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
 // so one counted wait per two phases suffices: vmcnt(4) in phase 2 (retires A(mh1) of this tile, read in phase 3) and
 // vmcnt(2) in phase 4 (retires the first three quarters of the next tile).  Waves 4-7 run one barrier behind waves 0-3, so
 // each SIMD alternates one wave reading / issuing with one wave in its MFMA cluster.
-struct QuarterLoader {  // one operand, R_CONTIG, 256 rows x 64 k, image = 16-row x 32-k sub-tiles (st_16x32), as RingLoader
+template <int LAYOUT> struct QuarterLoader;
+template <> struct QuarterLoader<FH_R_CONTIG> {  // 256 rows x 64 k, image = 16-row x 32-k sub-tiles (st_16x32), as RingLoader
   const bf16* base;
   long off[2];       // [half]
   long segdelta;
@@ -1408,11 +1409,103 @@ struct QuarterLoader {  // one operand, R_CONTIG, 256 rows x 64 k, image = 16-ro
       ptr[h][ks] += step[h][ks];
     }
   }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row0, int ks, int lane) {
+    return RingLoader<FH_R_CONTIG, 256, 64, 8>::frag(tile, row0, ks, lane);
+  }
 };
 
+// R_STRIDED operand (reduction index is the memory row, 256 columns contiguous): image = eight 32-column panels of
+// [64 k][64 B]; the 32-byte window w (16 columns) of k-row k sits at window w ^ ((k >> 3) & 1), so the eight k-rows a
+// half-wave's ds_read_b64_tr_b16 touches (k0..k0+3 and k0+8..k0+11, 64-byte rows) land in eight different 32-byte bank
+// slots.  One LDS-DMA instruction = 16 k-rows x 64 B of one panel; a quarter = four panels x four k-chunks.
+template <> struct QuarterLoader<FH_R_STRIDED> {
+  const bf16* base;
+  int col[2][2];   // [half][u] first of this lane's 8 columns
+  int kt[2][2];    // reduction row inside the K-tile
+  unsigned cvalid;
+  int wave;
+  int dst[2][2];   // LDS byte offset of the instruction's 1 KiB
+  const unsigned char* ptr[2][2];
+  int tcur[2][2];
+  long step, wrap;
+  int rpb;
+  __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid, bool is_x) {
+    base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
+    wave = tid >> 6;
+    const int lane = tid & 63;
+    cvalid = 0;
+    rpb = o.rpb > 0 ? o.rpb : 0x7fffffff;
+    wrap = o.rpb > 0 ? (o.bstride - (long)o.rpb * o.ld) * 2 : 0;
+    step = (long)64 * o.ld * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = 2 * wave + u, pq = idx >> 2, kc = idx & 3;
+        const int P = is_x ? (pq >> 1) * 4 + h * 2 + (pq & 1) : 2 * pq + h;
+        const int klocal = 16 * kc + (lane >> 2);
+        const int pc = lane & 3;
+        const int w = (pc >> 1) ^ ((klocal >> 3) & 1);
+        kt[h][u] = klocal;
+        col[h][u] = idx0 + P * 32 + w * 16 + (pc & 1) * 8;
+        dst[h][u] = P * 4096 + kc * 1024;
+        cvalid |= (col[h][u] < idx_limit ? 1u : 0u) << (2 * h + u);
+      }
+  }
+  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = k0 + kt[h][u];
+        ptr[h][u] = (const unsigned char*)g_zero_chunk;
+        tcur[h][u] = -1;
+        if (((cvalid >> (2 * h + u)) & 1u) && r < Kseg) {
+          RowMap rm = map_row(r, o.rpb);
+          ptr[h][u] = (const unsigned char*)(base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col[h][u]);
+          tcur[h][u] = rm.t;
+        }
+      }
+  }
+  __device__ __forceinline__ void set_zero() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        ptr[h][u] = (const unsigned char*)g_zero_chunk;
+        tcur[h][u] = -1;
+      }
+  }
+  __device__ __forceinline__ void issue_half(unsigned char* tile, int h) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      glds16(ptr[h][u], tile + dst[h][u]);
+      const bool live = tcur[h][u] >= 0;
+      const int tn = tcur[h][u] + 64;
+      const bool w = live && tn >= rpb;  // requires rpb >= 64 (checked on the host)
+      ptr[h][u] += (live ? step : 0) + (w ? wrap : 0);
+      tcur[h][u] = live ? (w ? tn - rpb : tn) : -1;
+    }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row0, int ks, int lane) {
+    const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
+    const int k = ks * 32 + 8 * q + qq;
+    const int w = ((row0 >> 4) & 1) ^ ((k >> 3) & 1);
+    const unsigned char* a0 = tile + (row0 >> 5) * 4096 + k * 64 + w * 32 + pp * 8;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    union {
+      struct { s16x4 lo, hi; } v;
+      bf16x8 f;
+    } u;
+    u.v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    u.v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 64));
+    return u.f;
+  }
+};
+
+template <int XL, int YL>
 __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
-  typedef RingLoader<FH_R_CONTIG, 256, 64, 8> FR;  // fragment addressing of the shared image layout
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
@@ -1429,7 +1522,8 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   const int nt = t1 - t0;
   const bool late = __builtin_amdgcn_readfirstlane(tid) >= 256;
 
-  QuarterLoader lx, ly;
+  QuarterLoader<XL> lx;
+  QuarterLoader<YL> ly;
   lx.init(p.X, g, i0, p.M, tid, true);
   ly.init(p.Y, g, j0, p.N, tid, false);
   f32x4 acc[4][8];  // [n][m]
@@ -1490,10 +1584,10 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   __builtin_amdgcn_sched_barrier(0);
 #define FH_READ_A(MH)                                                                                                  \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m) fa[ks][m] =           \
-      FR::frag(bx, xi0 + (MH) * 64 + 16 * m, ks, lane);
+      QuarterLoader<XL>::frag(bx, xi0 + (MH) * 64 + 16 * m, ks, lane);
 #define FH_READ_B(NH)                                                                                                  \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int n = 0; n < 2; ++n) fb[ks][n] =           \
-      FR::frag(by, yj0 + (NH) * 32 + 16 * n, ks, lane);
+      QuarterLoader<YL>::frag(by, yj0 + (NH) * 32 + 16 * n, ks, lane);
 
   for (int it = 0; it < nt; ++it) {
     const unsigned char* bx = lds + (it & 1) * STAGE;
@@ -1548,10 +1642,21 @@ int launch_8ph(const GemmParams& p, hipStream_t stream) {
   const size_t smem = 131072;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_kernel<FH_R_CONTIG, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_kernel<FH_R_STRIDED, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_kernel<FH_R_STRIDED, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_8ph_kernel, grid, block, smem, stream, p);
+  const int xl = p.X.layout, yl = p.Y.layout;
+  if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_8ph_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p);
+  else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
+    hipLaunchKernelGGL((gemm_8ph_kernel<FH_R_CONTIG, FH_R_STRIDED>), grid, block, smem, stream, p);
+  else if (xl == FH_R_STRIDED && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_8ph_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p);
+  else
+    hipLaunchKernelGGL((gemm_8ph_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p);
   FH_CHECK_LAUNCH();
   return 0;
 }
@@ -1589,8 +1694,8 @@ bool ring_ok(const GemmParams& p, int bk) {
 // ------------------------------------------------------------------ bf16 main-loop selection
 // g_gemm_path: 0 = 16x16x32 register staging, 1 = 128-tile LDS-DMA ring, 2 = 32x32x16 register staging, 3 = 256x256 ring
 // (BK 64, 2 stages), 4 = 256x128 ring (BK 32, 3 stages, 2 workgroups / CU), 5 = 256x256 ring (BK 32, 4 stages),
-// 6 = 256x256 ping-pong ring (BK 32, two barrier-staggered wave groups), 7 = 256x256 8-phase loop (BK 64, R_CONTIG x R_CONTIG
-// only), 9 = per-shape choice (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
+// 6 = 256x256 ping-pong ring (BK 32, two barrier-staggered wave groups), 7 = 256x256 8-phase loop (BK 64), 9 = per-shape choice
+// (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
 // FH_GEMM_PATH = reg | dma | 2..7 forces one loop (A/B comparisons; tools/gemm_bench.py).
 int g_gemm_path = -1;
 int g_tune_mode = 0;
@@ -1612,7 +1717,7 @@ void resolve_path() {
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   g_last_loop = 2;
   if ((path == 1 && dma_ok(p)) || path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32)) ||
-      (path == 7 && p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG))
+      (path == 7 && ring_ok(p, 64)))
     g_last_loop = path;
   if (path == 1 && dma_ok(p)) return launch_dma(p, stream);
   if (path == 0) return launch_t<bf16>(p, stream);
@@ -1620,7 +1725,7 @@ int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   if (path == 4 && ring_ok(p, 32)) return launch_ring<256, 128, 2, 2, 32, 3>(p, stream);
   if (path == 5 && ring_ok(p, 32)) return launch_ring<256, 256, 2, 4, 32, 4>(p, stream);
   if (path == 6 && ring_ok(p, 32)) return launch_pp(p, stream);
-  if (path == 7 && p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG) return launch_8ph(p, stream);
+  if (path == 7 && ring_ok(p, 64)) return launch_8ph(p, stream);
   return launch_32(p, stream);
 }
 
@@ -1664,14 +1769,14 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
   if (red >= 256) {
     if (p.ep.atomic) {
       for (int target : {256, 512}) {
-        if (ring_ok(p, 64)) add(3, ring_splitk(p, 256, 256, target));
+        if (ring_ok(p, 64)) { add(3, ring_splitk(p, 256, 256, target)); add(7, ring_splitk(p, 256, 256, target)); }
         if (ring_ok(p, 32)) add(5, ring_splitk(p, 256, 256, target));
       }
       add(2, ring_splitk(p, 128, 128, 1024));
     } else {
       if (ring_ok(p, 64)) add(3, p.splitk);
       if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); add(6, p.splitk); }
-      if (p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG) add(7, p.splitk);
+      if (ring_ok(p, 64)) add(7, p.splitk);
     }
   }
   hipEvent_t a, b;

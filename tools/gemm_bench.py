@@ -10,8 +10,8 @@ lib = L.lib()
 st = lambda: torch.cuda.current_stream().cuda_stream
 bf = torch.bfloat16
 
-PATHS = [int(x) for x in os.environ.get("PATHS", "2,3,4,5,6").split(",")]
-TILE = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (256, 256), 4: (256, 128), 5: (256, 256), 6: (256, 256)}
+PATHS = [int(x) for x in os.environ.get("PATHS", "2,3,5,7").split(",")]
+TILE = {0: (128, 128), 1: (128, 128), 2: (128, 128), 3: (256, 256), 4: (256, 128), 5: (256, 256), 6: (256, 256), 7: (256, 256)}
 
 def run(name, d, flops, bytes_, n=20, wg=None):
     res = []
