@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int LN_RPW = 4;  // rows per wave, loaded together (4x the bytes in flight of a row-at-a-time loop)
+constexpr int LN_RPW = 1;  // rows per wave, loaded together (4x the bytes in flight of a row-at-a-time loop)
 
 template <typename T, int NCH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -289,7 +289,7 @@ int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const flo
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return -301;
   const int nch = (C / VEC + 63) / 64;
-  const int rpw = 8;  // 32 rows per block: enough waves in flight to hide the load -> shuffle-reduce -> store chain
+  const int rpw = 16;  // 64 rows per block: enough waves in flight to hide the load -> shuffle-reduce -> store chain
   const int waves = (M + rpw - 1) / rpw;
   dim3 grid((waves + 3) / 4), block(256);
   const size_t smem = (size_t)8 * C * sizeof(float);
