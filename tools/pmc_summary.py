@@ -5,19 +5,19 @@ import collections, csv, glob, json, os, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fetch_dir, write_dir, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
-VAR = {"Li0ELi0E": "bf16,R_CONTIG,R_CONTIG", "Li0ELi1E": "bf16,R_CONTIG,R_STRIDED", "Li1ELi0E": "bf16,R_STRIDED,R_CONTIG",
-       "Li1ELi1E": "bf16,R_STRIDED,R_STRIDED", "<0, 0>": "bf16,R_CONTIG,R_CONTIG", "<0, 1>": "bf16,R_CONTIG,R_STRIDED",
-       "<1, 0>": "bf16,R_STRIDED,R_CONTIG", "<1, 1>": "bf16,R_STRIDED,R_STRIDED"}
+import re
+NAME = re.compile(r"(gemm\w*_kernel<[^>]*>)")
 
 def load(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
     agg = collections.Counter(); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter or "gemm32_kernel" not in r["Kernel_Name"]:
+        if r["Counter_Name"] != counter:
             continue
-        key = next((v for k, v in VAR.items() if k in r["Kernel_Name"]), None)
-        if key is None:
+        m = NAME.search(r["Kernel_Name"])
+        if not m:
             continue
+        key = m.group(1)   # as bench.py's kernel_name(): e.g. gemm_ring_kernel<0, 1, 256, 256, 2, 4, 32, 4>
         agg[key] += float(r["Counter_Value"]) * 1024.0
         n[key] += 1
     return agg, n
@@ -28,7 +28,7 @@ out = {"batch": batch, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (s
        "variants": {}}
 for k in fe:
     rd = 2.0 * fe[k] / max(1, nf[k]); w = wr[k] / max(1, nw[k])
-    out["variants"][f"gemm32_kernel<{k}>"] = {"launches": nf[k], "read_bytes_per_launch": rd, "write_bytes_per_launch": w,
+    out["variants"][k] = {"launches": nf[k], "read_bytes_per_launch": rd, "write_bytes_per_launch": w,
                                              "bytes_per_launch": rd + w}
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
