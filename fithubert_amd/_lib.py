@@ -108,6 +108,8 @@ SIGNATURES = {
     "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
     "fh_gemm_set_path": (_I, [_I]),
     "fh_gemm_tune": (_I, [_I]),
+    "fh_gemm_tune_export": (_I, [_P, _P, _P, _I]),
+    "fh_gemm_tune_import": (_I, [_P, _P, _P, _I]),
     "fh_prof_enable": (_I, [_I]),
     "fh_prof_collect": (_I, [_P, _P, _P]),
     "fh_conv0_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
@@ -189,3 +191,29 @@ def epilogue(**kw):
         else:
             setattr(e, k, v)
     return e
+
+
+def save_gemm_table(path: str) -> int:
+    """Write the per-shape main-loop table (fh_gemm_tune) to ``path`` (JSON); returns the number of entries."""
+    import json
+    n = lib().fh_gemm_tune_export(None, None, None, 0)
+    keys, paths, sks = (C.c_ulonglong * n)(), (C.c_int * n)(), (C.c_int * n)()
+    lib().fh_gemm_tune_export(keys, paths, sks, n)
+    with open(path, "w") as f:
+        json.dump({"entries": [[int(keys[i]), int(paths[i]), int(sks[i])] for i in range(n)]}, f)
+    return n
+
+
+def load_gemm_table(path: str) -> int:
+    """Merge a table written by save_gemm_table; returns the table size (0 if the file does not exist)."""
+    import json
+    import os
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        ent = json.load(f)["entries"]
+    n = len(ent)
+    if n == 0:
+        return 0
+    keys, paths, sks = (C.c_ulonglong * n)(*[e[0] for e in ent]), (C.c_int * n)(*[e[1] for e in ent]), (C.c_int * n)(*[e[2] for e in ent])
+    return lib().fh_gemm_tune_import(keys, paths, sks, n)

@@ -1835,6 +1835,23 @@ extern "C" int fh_gemm_tune(int mode) {
   g_tune_mode = mode > 0;
   return (int)g_tune.size();
 }
+// table exchange (so that a profiled run can reuse the choices of an earlier run instead of re-measuring)
+extern "C" int fh_gemm_tune_export(unsigned long long* keys, int* paths, int* splitks, int cap) {
+  int n = 0;
+  for (auto& kv : g_tune) {
+    if (n < cap && keys && paths && splitks) {
+      keys[n] = kv.first;
+      paths[n] = kv.second.path;
+      splitks[n] = kv.second.splitk;
+    }
+    ++n;
+  }
+  return n;
+}
+extern "C" int fh_gemm_tune_import(const unsigned long long* keys, const int* paths, const int* splitks, int n) {
+  for (int i = 0; i < n; ++i) g_tune[keys[i]] = TuneChoice{paths[i], splitks[i]};
+  return (int)g_tune.size();
+}
 extern "C" int fh_prof_enable(int on) {
   g_prof_on = on != 0;
   return 0;

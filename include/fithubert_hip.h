@@ -92,6 +92,9 @@ int fh_gemm_set_path(int path);
  * output several times -- only for throw-away passes (StudentEngine.autotune).  mode 0: stop measuring; unmeasured shapes
  * run path 2.  mode -1: forget the table.  Returns the number of measured shape classes. */
 int fh_gemm_tune(int mode);
+/* copy the table out (returns the number of entries; fills up to cap) / merge entries in (returns the table size) */
+int fh_gemm_tune_export(unsigned long long* keys, int* paths, int* splitks, int cap);
+int fh_gemm_tune_import(const unsigned long long* keys, const int* paths, const int* splitks, int n);
 int fh_prof_enable(int on);
 int fh_prof_collect(double* ms /*[64]*/, double* flops /*[64]*/, long* launches /*[64]*/);
 

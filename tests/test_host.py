@@ -96,3 +96,25 @@ def test_ex_yaml_param_table_equals_reference_state_dict():
     assert ours["proj_head.2.weight"] == (3, 768, 768) and ours["proj_head.2.bias"] == (1, 1, 3, 768)
     d = dict(y["distiller"], pred_layer_id="[11]")
     assert unsupported(CustomStudentModelConfig(**d))  # single-task nn.Linear head: not built, fails loudly
+
+
+def test_gemm_table_roundtrip(tmp_path):
+    """Per-shape main-loop table: import / export / file round trip (host-side map, no GPU needed)."""
+    from fithubert_amd import _lib as L
+    import ctypes as C
+    lib = L.lib()
+    lib.fh_gemm_tune(-1)
+    keys = (C.c_ulonglong * 2)(0x1234567890ABCDEF, 42)
+    paths = (C.c_int * 2)(7, 3)
+    sks = (C.c_int * 2)(1, 43)
+    assert lib.fh_gemm_tune_import(keys, paths, sks, 2) == 2
+    f = str(tmp_path / "table.json")
+    assert L.save_gemm_table(f) == 2
+    lib.fh_gemm_tune(-1)
+    assert lib.fh_gemm_tune(0) == 0
+    assert L.load_gemm_table(f) == 2
+    k2, p2, s2 = (C.c_ulonglong * 2)(), (C.c_int * 2)(), (C.c_int * 2)()
+    assert lib.fh_gemm_tune_export(k2, p2, s2, 2) == 2
+    assert sorted(zip(k2, p2, s2)) == sorted(zip(keys, paths, sks))
+    lib.fh_gemm_tune(-1)
+    assert L.load_gemm_table(str(tmp_path / "missing.json")) == 0
