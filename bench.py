@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--gemm-table", default=os.environ.get("FH_GEMM_TABLE", ""),
                     help="JSON file with the per-shape GEMM main-loop table: loaded if present (then nothing is re-measured, so a "
                          "profiler sees only the steps), written after the run otherwise")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the 2 extra un-overlapped steps behind the timed region "
+                    "(so that a rocprofv3 --stats average of the same command is directly comparable with roofline.avg_launch_us)")
     ap.add_argument("--prof-steps", type=int, default=3, help="timed steps (the last ones) with per-launch HIP-event GEMM timing")
     args = ap.parse_args()
 
@@ -166,7 +168,7 @@ def main():
     # ---- the same measurement with nothing else on the device: 2 extra steps AFTER the timed region with the teacher on
     # the main stream (no concurrent kernels), so the per-launch durations are the GEMM's own rather than its share of
     # a GPU it splits with the teacher's rocBLAS kernels.  Reported beside the live figure, never instead of it.
-    if roof is not None and args.prof_steps > 0:
+    if roof is not None and args.prof_steps > 0 and not args.no_isolated:
         side = task.teacher_stream
         task.teacher_stream, task._next_teacher = None, None
         torch.cuda.synchronize()
