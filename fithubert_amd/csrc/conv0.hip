@@ -32,7 +32,7 @@ __device__ __forceinline__ int stage_wave(const Conv0Args& a, int b, int chunk, 
   const int nt = min(TCH, a.T0 - t0);
   const int nsamp = (nt - 1) * a.stride + a.K;
   const float* src = a.wave + (long)b * a.S + (long)t0 * a.stride;
-  for (int i = threadIdx.x; i < nsamp; i += blockDim.x) sw[i] = src[i];
+  for (int i = threadIdx.x; i < nsamp + MAXK; i += blockDim.x) sw[i] = i < nsamp ? src[i] : 0.f;  // zero tail: KT > K reads it
   __syncthreads();
   return nt;
 }
@@ -121,35 +121,39 @@ struct ChanMap {
   }
 };
 
-__device__ __forceinline__ void load_w4(const Conv0Args& a, int c0, float (&w)[CV][MAXK]) {
+// KT = compile-time tap count (10 for every shipped frontend; MAXK with zero weights past K otherwise): with a run-time
+// bound hipcc kept the tap loop rolled, one LDS round trip + branch per tap
+template <int KT>
+__device__ __forceinline__ void load_w4(const Conv0Args& a, int c0, float (&w)[CV][KT]) {
 #pragma unroll
   for (int e = 0; e < CV; ++e)
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j) w[e][j] = j < a.K ? a.w[(c0 + e) * a.K + j] : 0.f;
+    for (int j = 0; j < KT; ++j) w[e][j] = j < a.K ? a.w[(c0 + e) * a.K + j] : 0.f;
 }
-__device__ __forceinline__ void conv4_at(const float* sw, const float (&w)[CV][MAXK], int t, int K, int stride, float* v) {
+template <int KT>
+__device__ __forceinline__ void conv4_at(const float* sw, const float (&w)[CV][KT], int t, int stride, float* v) {
   const float* x = sw + t * stride;
+  float xs[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) xs[j] = x[j];
 #pragma unroll
   for (int e = 0; e < CV; ++e) v[e] = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXK; ++j)
-    if (j < K) {
-      const float xj = x[j];
+  for (int j = 0; j < KT; ++j)
 #pragma unroll
-      for (int e = 0; e < CV; ++e) v[e] = fmaf(w[e][j], xj, v[e]);
-    }
+    for (int e = 0; e < CV; ++e) v[e] = fmaf(w[e][j], xs[j], v[e]);
 }
 
 // ---------------------------------------------------------------- forward pass 2: conv + GN + GELU -> y
-template <typename T>
+template <typename T, int KT>
 __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const float* mean, const float* rstd, T* y) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int nt = stage_wave(a, b, chunk, sw);
   const ChanMap m(a.C0);
-  float w[CV][MAXK];
-  load_w4(a, m.c0, w);
+  float w[CV][KT];
+  load_w4<KT>(a, m.c0, w);
   float sc[CV], sh[CV];
 #pragma unroll
   for (int e = 0; e < CV; ++e) {
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
 #pragma unroll 2
   for (int t = m.tl; t < nt; t += m.nlan) {
     float v[CV];
-    conv4_at(sw, w, t, a.K, a.stride, v);
+    conv4_at<KT>(sw, w, t, a.stride, v);
 #pragma unroll
     for (int e = 0; e < CV; ++e) v[e] = gelu_f(fmaf(v[e], sc[e], sh[e]));
     st4(yp + (long)t * a.C0, v);
@@ -170,17 +174,17 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
 }
 
 // ---------------------------------------------------------------- backward pass 1: per-(b,c) sums of g and g*xhat
-template <typename T>
+template <typename T, int KT>
 __global__ void __launch_bounds__(256) conv0_bwd_reduce_kernel(Conv0Args a, const float* mean, const float* rstd,
                                                                const T* dy, float2* part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
-  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [2][256][CV]
+  float* red = smem + ((TCH - 1) * a.stride + a.K + MAXK + 3) / 4 * 4;  // [2][256][CV]
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int nt = stage_wave(a, b, chunk, sw);
   const ChanMap m(a.C0);
-  float w[CV][MAXK];
-  load_w4(a, m.c0, w);
+  float w[CV][KT];
+  load_w4<KT>(a, m.c0, w);
   float mu[CV], rs[CV], ga[CV], be[CV], s1[CV], s2[CV];
 #pragma unroll
   for (int e = 0; e < CV; ++e) {
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_reduce_kernel(Conv0Args a, cons
   for (int t = m.tl; t < nt; t += m.nlan) {
     float v[CV], d[CV];
     ld4(dyp + (long)t * a.C0, d);
-    conv4_at(sw, w, t, a.K, a.stride, v);
+    conv4_at<KT>(sw, w, t, a.stride, v);
 #pragma unroll
     for (int e = 0; e < CV; ++e) {
       const float xh = (v[e] - mu[e]) * rs[e];
@@ -240,16 +244,16 @@ __global__ void conv0_bwd_final_kernel(const float2* part, const float* gamma, f
 }
 
 // ---------------------------------------------------------------- backward pass 2: dW[c][j] += sum_t dv[t] * wave[stride*t + j]
-template <typename T>
+template <typename T, int KT>
 __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, const float* mean, const float* rstd,
                                                                const float2* ab, const T* dy, float scale, float* dw) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
-  float* red = smem + ((TCH - 1) * a.stride + a.K + 3) / 4 * 4;  // [256][CV]
+  float* red = smem + ((TCH - 1) * a.stride + a.K + MAXK + 3) / 4 * 4;  // [256][CV]
   const int b = blockIdx.y;
   const ChanMap m(a.C0);
-  float w[CV][MAXK], acc[CV][MAXK];
-  load_w4(a, m.c0, w);
+  float w[CV][KT], acc[CV][KT];
+  load_w4<KT>(a, m.c0, w);
   float mu[CV], rs[CV], ga[CV], be[CV], aa[CV], bb[CV];
 #pragma unroll
   for (int e = 0; e < CV; ++e) {
@@ -258,7 +262,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
     const float2 abv = ab[b * a.C0 + c];
     aa[e] = abv.x; bb[e] = abv.y;
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j) acc[e][j] = 0.f;
+    for (int j = 0; j < KT; ++j) acc[e][j] = 0.f;
   }
   // the block walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... keeping its dW partial in registers
   for (int chunk = blockIdx.x; chunk < a.nchunk; chunk += gridDim.x) {
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
     for (int t = m.tl; t < nt; t += m.nlan) {
       float v[CV], d[CV];
       ld4(dyp + (long)t * a.C0, d);
-      conv4_at(sw, w, t, a.K, a.stride, v);
+      conv4_at<KT>(sw, w, t, a.stride, v);
       const float* x = sw + t * a.stride;
 #pragma unroll
       for (int e = 0; e < CV; ++e) {
@@ -278,16 +282,15 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
         v[e] = rs[e] * (g * ga[e] - aa[e] - xh * bb[e]);  // dv
       }
 #pragma unroll
-      for (int j = 0; j < MAXK; ++j)
-        if (j < a.K) {
-          const float xj = x[j];
+      for (int j = 0; j < KT; ++j) {
+        const float xj = x[j];
 #pragma unroll
-          for (int e = 0; e < CV; ++e) acc[e][j] = fmaf(v[e], xj, acc[e][j]);
-        }
+        for (int e = 0; e < CV; ++e) acc[e][j] = fmaf(v[e], xj, acc[e][j]);
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < MAXK; ++j) {
+  for (int j = 0; j < KT; ++j) {
     if (j < a.K) {
       __syncthreads();
 #pragma unroll
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
 }
 
 size_t smem_bytes(int stride, int K, bool red2) {
-  size_t sw = ((size_t)((TCH - 1) * stride + K) + 3) / 4 * 4;
+  size_t sw = ((size_t)((TCH - 1) * stride + K + MAXK) + 3) / 4 * 4;  // staged samples + the zero tail
   return (sw + (red2 ? 2 : 1) * 256 * CV) * sizeof(float);
 }
 
@@ -330,10 +333,11 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
   hipLaunchKernelGGL(conv0_stats_final_kernel, dim3(B), dim3(256), 0, st, (const float*)part, w, mean, rstd, B, a.nchunk, C0, K,
                      a.T0, eps);
   FH_CHECK_LAUNCH();
-  if (dtype == 0)
-    hipLaunchKernelGGL(conv0_apply_kernel<float>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (float*)y);
-  else
-    hipLaunchKernelGGL(conv0_apply_kernel<bf16>, grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (bf16*)y);
+#define FH_C0_APPLY(T, KT) \
+  hipLaunchKernelGGL((conv0_apply_kernel<T, KT>), grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (T*)y)
+  if (dtype == 0) { if (K == 10) FH_C0_APPLY(float, 10); else FH_C0_APPLY(float, MAXK); }
+  else { if (K == 10) FH_C0_APPLY(bf16, 10); else FH_C0_APPLY(bf16, MAXK); }
+#undef FH_C0_APPLY
   FH_CHECK_LAUNCH();
   return 0;
 }
@@ -349,24 +353,22 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
   a.T0 = (S - K) / stride + 1;
   a.nchunk = fh_conv0_nchunk(a.T0);
   dim3 grid(a.nchunk, B), block(256);
-  if (dtype == 0)
-    hipLaunchKernelGGL(conv0_bwd_reduce_kernel<float>, grid, block, smem_bytes(stride, K, true), st, a, mean, rstd,
-                       (const float*)dy, part);
-  else
-    hipLaunchKernelGGL(conv0_bwd_reduce_kernel<bf16>, grid, block, smem_bytes(stride, K, true), st, a, mean, rstd,
-                       (const bf16*)dy, part);
+#define FH_C0_RED(T, KT) \
+  hipLaunchKernelGGL((conv0_bwd_reduce_kernel<T, KT>), grid, block, smem_bytes(stride, K, true), st, a, mean, rstd, (const T*)dy, part)
+  if (dtype == 0) { if (K == 10) FH_C0_RED(float, 10); else FH_C0_RED(float, MAXK); }
+  else { if (K == 10) FH_C0_RED(bf16, 10); else FH_C0_RED(bf16, MAXK); }
+#undef FH_C0_RED
   FH_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3(B), dim3(256), 0, st, part, gamma, ab, dgamma, dbeta, B, a.nchunk, C0,
                      a.T0);
   FH_CHECK_LAUNCH();
   const int per_b = (1024 + B - 1) / B;  // ~1024 blocks in total; each flushes its dW partial once
   dim3 wgrid(min(a.nchunk, max(1, per_b)), B);
-  if (dtype == 0)
-    hipLaunchKernelGGL(conv0_bwd_weight_kernel<float>, wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
-                       (const float*)dy, grad_scale, dw);
-  else
-    hipLaunchKernelGGL(conv0_bwd_weight_kernel<bf16>, wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab,
-                       (const bf16*)dy, grad_scale, dw);
+#define FH_C0_WG(T, KT) \
+  hipLaunchKernelGGL((conv0_bwd_weight_kernel<T, KT>), wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab, (const T*)dy, grad_scale, dw)
+  if (dtype == 0) { if (K == 10) FH_C0_WG(float, 10); else FH_C0_WG(float, MAXK); }
+  else { if (K == 10) FH_C0_WG(bf16, 10); else FH_C0_WG(bf16, MAXK); }
+#undef FH_C0_WG
   FH_CHECK_LAUNCH();
   return 0;
 }

@@ -38,10 +38,10 @@ def _p(t):
 
 # ------------------------------------------------------------------------------------------ conv0 + GroupNorm + GELU
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
-@pytest.mark.parametrize("C0,S", [(128, 6400), (128, 32000), (512, 4000)])
-def test_conv0_groupnorm_gelu_fwd_bwd(dt, C0, S):
+@pytest.mark.parametrize("C0,S,K,stride", [(128, 6400, 10, 5), (128, 32000, 10, 5), (512, 4000, 10, 5), (128, 5000, 8, 4), (128, 3000, 12, 5)])
+def test_conv0_groupnorm_gelu_fwd_bwd(dt, C0, S, K, stride):
     torch.manual_seed(C0 + S)
-    B, K, stride = 2, 10, 5
+    B = 2
     T0 = (S - K) // stride + 1
     wave = (0.5 * torch.randn(B, S, device=DEV)) + 0.05
     w = torch.randn(C0, K, device=DEV) * (2.0 / K) ** 0.5
