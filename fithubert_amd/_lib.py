@@ -81,7 +81,7 @@ class StudentConfigC(C.Structure):
         ("layers", C.c_int), ("conv_pos", C.c_int), ("conv_pos_groups", C.c_int), ("tr_factor", C.c_int),
         ("pred_dim", C.c_int), ("dropout", C.c_float), ("attention_dropout", C.c_float),
         ("activation_dropout", C.c_float), ("dropout_input", C.c_float), ("feature_grad_mult", C.c_float),
-        ("n_tasks", C.c_int), ("inter_dim", C.c_int),
+        ("n_tasks", C.c_int), ("inter_dim", C.c_int), ("cnn_head", C.c_int),
     ]
 
 
@@ -100,6 +100,7 @@ _ENGINE_SIGS = {
     "fh_student_prepare": (_I, [C.POINTER(StudentConfigC), _P, _P, _P]),
     "fh_student_forward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P]),
     "fh_student_backward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fh_student_backward_cnn": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -83,6 +83,26 @@ __global__ void mul_gelu_grad_kernel(const T* __restrict__ src, const T* __restr
   }
 }
 
+// mode 0: dst = gelu(src);  mode 1: dst += src
+template <typename T>
+__global__ void unary_kernel(const T* __restrict__ src, T* __restrict__ dst, long nvec, int mode) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float a[VEC];
+    unpack16<T>(ld16(src + i * VEC), a);
+    if (mode == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] = gelu_f(a[e]);
+    } else {
+      float d[VEC];
+      unpack16<T>(ld16(dst + i * VEC), d);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] += d[e];
+    }
+    st16(dst + i * VEC, pack16<T>(a));
+  }
+}
+
 // dst[row][c] = src[row][c] * dropmask(row*C + c) * (t(row) < row_len[b(row)])
 template <typename T>
 __global__ void mask_drop_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int C, int rpb,
@@ -111,6 +131,20 @@ __global__ void mask_drop_kernel(const T* __restrict__ src, T* __restrict__ dst,
 }
 
 }  // namespace
+
+int fh_unary_launch(int dtype, const void* src, void* dst, long n, int mode, hipStream_t st) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if (n <= 0) return 0;
+  if (n % vec) return -701;
+  const long nvec = n / vec;
+  dim3 grid((unsigned)min((long)4096, (nvec + 255) / 256)), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(unary_kernel<float>, grid, block, 0, st, (const float*)src, (float*)dst, nvec, mode);
+  else
+    hipLaunchKernelGGL(unary_kernel<bf16>, grid, block, 0, st, (const bf16*)src, (bf16*)dst, nvec, mode);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
 
 int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* dst, long n, float scale, hipStream_t st) {
   const int vec = dtype == 0 ? 4 : 8;

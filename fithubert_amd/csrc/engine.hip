@@ -45,6 +45,7 @@ struct ParamLayout {
   long enc_ln_w, enc_ln_b, ups_w, ups_b;
   long head0, head_stride, h_up_w, h_up_b, h_lin_w, h_lin_b;
   long sp_w0 = -1, sp_b0 = -1, sp_w2 = -1, sp_b2 = -1;  // DistilHuBERT-style head (n_tasks >= 2)
+  long cnn_w = -1, cnn_b = -1;                           // cnn_proj_head.1 (model.py:305-310)
 
   long add(const std::string& name, std::initializer_list<long> dims) {
     PEntry e;
@@ -110,6 +111,10 @@ struct ParamLayout {
     if (c.tr_factor > 0) {
       ups_w = add("upsampler.weight", {D, D, f});  // present in the reference state dict, never used (model.py:342-348)
       ups_b = add("upsampler.bias", {D});
+    }
+    if (c.cnn_head) {
+      cnn_w = add("cnn_proj_head.1.weight", {P, D});
+      cnn_b = add("cnn_proj_head.1.bias", {P});
     }
     head0 = total;
     if (c.n_tasks > 0) {
@@ -234,7 +239,7 @@ struct Plan {
   long c0_mean, c0_rstd, c0_scratch;
   long ln0, ln0_mean, ln0_rstd, features, x0, zc, psum, ln1_mean, ln1_rstd, x1;
   long xo, qkv, attn, lse, s1, st1_mean, st1_rstd, xa, z1, hbuf, f2, s2, st2_mean, st2_rstd;
-  long u, pred, hz = -1, hh = -1, dhz = -1;
+  long u, pred, hz = -1, hh = -1, dhz = -1, gfeat = -1, cnn_pred = -1, dgf = -1;
   // backward
   long du, ghead, dxin, ds2, df2, dz1, dx1b, ds1, dao, da, dqkv, delta;
   long dx1tr, dpsum, dzc, dx0, dfeat, dln0, dylast, pos_dws;
@@ -294,6 +299,11 @@ struct Plan {
       u = ws.add("u", {Lh, B, sh.T2 * sh.f, D}, es);
     }
     pred = ws.add("pred", {Lh, B, sh.T2 * sh.f, P}, es);
+    if (c.cnn_head) {
+      gfeat = ws.add("gfeat", {B, sh.Tp, D}, es);
+      cnn_pred = ws.add("cnn_pred", {B, sh.Tp, P}, es);
+      if (tr) dgf = ws.add("dgf", {B, sh.Tp, D}, es);
+    }
     if (tr) {
       du = c.n_tasks > 0 ? -1 : ws.add("du", {Lh, B, sh.T2 * sh.f, D}, es);
       ghead = ws.add("ghead", {L, M2, D}, es);
@@ -469,6 +479,17 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
       RC(fh_gemm_launch(g, dt, x.st));
     }
   }
+  // ---- cnn_proj_head on the pre-dropout projection (model.py:482-487): GELU -> Linear(D, P)
+  if (c.cnn_head && p.k.heads_on) {
+    RC(fh_unary_launch(dt, x.W(p.features), x.W(p.gfeat), s.Mp * D, 0, x.st));
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(x.W(p.gfeat), FH_R_CONTIG, D);
+    g.Y = fh_operand(x.nat(p.pl.cnn_w), FH_R_CONTIG, D);
+    g.C = x.W(p.cnn_pred);
+    g.M = (int)s.Mp; g.N = P; g.Kseg = D; g.ldc = P;
+    g.ep.bias = prm + p.pl.cnn_b;
+    RC(fh_gemm_launch(g, dt, x.st));
+  }
   // ---- positional conv + residual, LayerNorm, dropout   module.py:276-294
   RC(fh_posconv_fwd_launch(dt, x.W(p.x0), x.rel(p.wl.pos_wf), prm + p.pl.pos_b, x.W(p.zc), x.W(p.psum), B, s.Tp, D,
                            c.conv_pos_groups, c.conv_pos, x.st));
@@ -615,7 +636,8 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
   return 0;
 }
 
-int backward(const Ctx& x, float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden) {
+int backward(const Ctx& x, float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden,
+             const void* d_cnn = nullptr) {
   const Plan& p = x.p;
   const fh_student_config& c = p.c;
   const Shapes& s = p.sh;
@@ -852,7 +874,29 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
                               x.W<float>(p.pos_dws), grads + p.pl.pos_g, grads + p.pl.pos_v, D, c.conv_pos_groups, c.conv_pos, x.st));
   // ---------------- post_extract_proj backward
   const int E = c.conv_dim[c.n_conv - 1];
+  // results["features"] without a cnn_proj_head is the projection itself.  When it aliases the encoder input (dropout_input == 0:
+  // F.dropout returns its argument and the encoder zeroes padded frames IN PLACE, see the oracle), its gradient shares that
+  // zeroing: add it before the row mask.  (With a head and dropout_input == 0 the reference cannot run a padded batch at all:
+  // the in-place zeroing invalidates the GELU's saved input.)
+  const bool cnn_direct = d_cnn && !(c.cnn_head && p.k.heads_on);
+  const bool cnn_aliased = cnn_direct && c.dropout_input == 0.f;
+  if (cnn_aliased) RC(fh_unary_launch(dt, d_cnn, x.W(p.dx0), s.Mp * D, 1, x.st));
   RC(fh_mask_drop_launch(dt, x.W(p.dx0), x.W(p.dfeat), s.Mp, D, s.Tp, len_p, x.drop(c.dropout_input, SITE_INPUT), x.st));
+  if (d_cnn && c.cnn_head && p.k.heads_on) {  // through cnn_proj_head: dfeat += (d_cnn . Wc) * gelu'(features); dWc, dbc
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(d_cnn, FH_R_CONTIG, P);
+    g.Y = fh_operand(x.nat(p.pl.cnn_w), FH_R_STRIDED, D);
+    g.C = x.W(p.dgf);
+    g.M = (int)s.Mp; g.N = D; g.Kseg = P; g.ldc = D;
+    g.ep.gelu_aux = x.W(p.features);
+    RC(fh_gemm_launch(g, dt, x.st));
+    RC(fh_unary_launch(dt, x.W(p.dgf), x.W(p.dfeat), s.Mp * D, 1, x.st));
+    GemmOperand A = fh_operand(x.W(p.gfeat), FH_R_STRIDED, D);
+    RC(wgrad(x, d_cnn, P, A, grads + p.pl.cnn_w, P, D, s.Mp, 1, 0, 0));
+    RC(fh_colsum_launch(dt, d_cnn, grads + p.pl.cnn_b, (int)s.Mp, P, P, 1, 0, 0, 0, 1.f, x.st));
+  } else if (cnn_direct && !cnn_aliased) {  // pre-dropout projection: its gradient joins dfeat behind the dropout / row mask
+    RC(fh_unary_launch(dt, d_cnn, x.W(p.dfeat), s.Mp * D, 1, x.st));
+  }
   {
     GemmParams g = fh_gemm_params();
     g.X = fh_operand(x.W(p.dfeat), FH_R_CONTIG, D);
@@ -1023,6 +1067,17 @@ int fh_student_backward(const fh_student_config* c, const fh_student_call* k, co
   if (p.ok != 0) return p.ok;
   Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
   return backward(x, grads, wave, lens, d_pred, d_hidden);
+}
+
+int fh_student_backward_cnn(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
+                            float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden,
+                            const void* d_cnn, fh_stream_t stream) {
+  if (!c || !k) return -1;
+  RC(validate(*c));
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
+  return backward(x, grads, wave, lens, d_pred, d_hidden, d_cnn);
 }
 
 }  // extern "C"

@@ -60,10 +60,10 @@ class W2V2Distil:
         self.attn_loss_type = t["attn_loss_type"]
         self.v_rel_loss_weight = t["v_rel_loss_weight"]
         self.random_layer_weight = t["random_layer_weight"]
-        for k in ("cnn_loss_weight", "attn_loss_weight", "v_rel_loss_weight"):
+        for k in ("attn_loss_weight", "v_rel_loss_weight"):
             if t[k] > 0:
-                raise NotImplementedError(f"train.{k} > 0 is a next-scope loss option (SURVEY 8f rank 2); the fused kernels cover "
-                                          "rec_loss (mse / l1) and the cosine sim_loss")
+                raise NotImplementedError(f"train.{k} > 0 (attention-logit / value-relation transfer, utils/utils.py:193-280) is not "
+                                          "built; the fused kernels cover rec_loss (mse / l1), the cosine sim_loss and the CNN l1 loss")
         if t["sim_loss_weight"] > 0 and t["distil_random_layer"] > 0:
             # the reference itself cannot run this: sim_loss is 3-D and train.py:305 takes mean((0, 2, 3))
             raise NotImplementedError("sim_loss_weight > 0 needs distil_random_layer == 0 (train.py:302-306 fails otherwise)")
@@ -86,6 +86,8 @@ class W2V2Distil:
         self.num_gpus = len(t["gpus"]) if isinstance(t["gpus"], list) else t["gpus"]
         self.accumulate = int(t.get("accumulate_grad_batches", 1))
         self._rows_loss = self.sim_loss_weight > 0   # row-wise kernel (rec + cosine); its out[-1] is the fully weighted total
+        self._one = torch.ones(1, device=self.device)
+        self._zero_i = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._set_loss_tables()
         # ---- optimizer state (configure_optimizers fills the schedule)
         self.opt_m = torch.zeros_like(self.engine.params)
@@ -146,7 +148,12 @@ class W2V2Distil:
         teacher = torch.stack([lr[0].transpose(0, 1) for lr in teacher_results["layer_results"]], dim=0).contiguous()
         out = _KDLossFn.apply(pred, teacher, self)
         total = out[-1] if self._rows_loss else self.rec_loss_weight * out[-1]
-        return total.float(), self._loss_dict(out)
+        losses = self._loss_dict(out)
+        if self.cnn_loss_weight > 0:  # train.py:241-246
+            cnn = _L1Fn.apply(student_results["features"], teacher_results["features"][0], self)
+            losses["cnn_loss"] = cnn
+            total = total + self.cnn_loss_weight * cnn
+        return total.float(), losses
 
     def _loss_dict(self, out) -> Dict[str, torch.Tensor]:
         losses = {}
@@ -192,6 +199,10 @@ class W2V2Distil:
         pm = batch.get("padding_mask")
         if pm is not None and not bool(batch.get("_any_pad", True)) and self.teacher_model.model.cfg.model_type != "hubert":
             pm = None
+        if self.cnn_loss_weight > 0:  # CNN loss target: the teacher's post_extract_proj output (utils/utils.py:71-73 hook)
+            hid, post, _ = self.teacher_model.model.run(batch["x"], pm)
+            hid._fh_post = post.contiguous()
+            return hid
         return self.teacher_model.hidden_stack(batch["x"], pm)
 
     def _teacher_async(self, batch):
@@ -236,7 +247,16 @@ class W2V2Distil:
         else:
             out, d_pred = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer,
                                               loss_type=0 if self.rec_loss_type == "mse" else 1, grad_scale=float(self.rec_loss_weight))
-        self.engine.backward(ws, d_pred=d_pred)
+        d_cnn = None
+        if self.cnn_loss_weight > 0:   # train.py:241-246: l1 between results["features"] and the teacher's projected CNN features
+            featd = self.engine.features_to_distill(ws)
+            cout, d_cnn = self.engine.kd_loss(ws, hid._fh_post.unsqueeze(0), self._one, self._zero_i, loss_type=1,
+                                              grad_scale=float(self.cnn_loss_weight), pred=featd.unsqueeze(0))
+            d_cnn = d_cnn[0]
+            self.last_cnn_loss = cout[0]           # device scalar, for logging (losses['cnn_loss'], train.py:244)
+            feat_total = out[-1] if self._rows_loss else float(self.rec_loss_weight) * out[-1]
+            out = torch.cat([out[:-1], (feat_total + float(self.cnn_loss_weight) * cout[0]).reshape(1)])  # [-1] = train.py:372-378
+        self.engine.backward(ws, d_pred=d_pred, d_cnn=d_cnn)
         self._micro += 1
         if self._micro >= self.accumulate:
             self.sync.launch()                      # async all-reduce of the flat gradients (RCCL / xGMI)
@@ -267,6 +287,33 @@ class W2V2Distil:
     def save_checkpoint(self, path: str, epoch: int = 0) -> None:
         torch.save({"state_dict": {k: v.cpu() for k, v in self.state_dict().items()}, "epoch": epoch,
                     "global_step": self.opt_step, "hyper_parameters": {"cfg": self.yaml_cfg}}, path)
+
+
+class _L1Fn(torch.autograd.Function):
+    """mean |a - b| with the fused loss kernel (one 'layer'); gradient w.r.t. a."""
+
+    @staticmethod
+    def forward(ctx, a, b, task):
+        eng = task.engine
+        a4 = a.contiguous().unsqueeze(0)
+        b4 = b.contiguous().unsqueeze(0)
+        _, B, Tp, P = a4.shape
+        lib = L.lib()
+        tdt = L.DT_F32 if b4.dtype == torch.float32 else L.DT_BF16
+        nblk = lib.fh_kd_loss_nblk(eng.c.dtype, B, Tp, P)
+        partials = torch.empty(nblk, device=a.device, dtype=torch.float32)
+        out = torch.empty(2, device=a.device, dtype=torch.float64)
+        d = torch.empty_like(a4)
+        L.check(lib.fh_kd_loss(eng.c.dtype, tdt, a4.data_ptr(), b4.data_ptr(), d.data_ptr(), task._one.data_ptr(), task._zero_i.data_ptr(),
+                               partials.data_ptr(), out.data_ptr(), 1, B, Tp, b4.shape[2], P, B * b4.shape[2] * P, 1, 1.0, eng.stream()),
+                "fh_kd_loss")
+        ctx.save_for_backward(d[0])
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * g.to(d.dtype), None, None
 
 
 class _KDLossFn(torch.autograd.Function):

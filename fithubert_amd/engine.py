@@ -51,8 +51,6 @@ def unsupported(cfg: CustomStudentModelConfig) -> Optional[str]:
             return "layerwise_proj=False together with enable_tr_layer (shared upsampler, model.py:504-505) is not built"
     elif cfg.pred_head_final_dim == cfg.encoder_embed_dim:
         return "pred_head_final_dim == encoder_embed_dim (no lin_proj) is not built"
-    if cfg._cnn_weight > 0:
-        return "cnn_proj_head / cnn_loss_weight > 0 is not built yet"
     return None
 
 
@@ -83,6 +81,7 @@ def make_config_c(cfg: CustomStudentModelConfig, dtype: str) -> StudentConfigC:
     c.feature_grad_mult = cfg.feature_grad_mult
     c.n_tasks = 0 if cfg.layerwise_proj else len(cfg.pred_layers())
     c.inter_dim = cfg.pred_head_inter_dim if cfg.pred_head_inter_dim > 0 else cfg.encoder_embed_dim  # model.py:334-335
+    c.cnn_head = int(cfg._cnn_weight > 0 and cfg.pred_head_final_dim != cfg.encoder_embed_dim)      # model.py:305-310
     return c
 
 
@@ -252,17 +251,21 @@ class StudentEngine:
             n = self.lib.fh_gemm_tune(0)
         return n
 
+    def features_to_distill(self, ws: Workspace) -> torch.Tensor:
+        """results["features"] as the CNN loss sees it (model.py:482-487): cnn_proj_head output when the head exists."""
+        return ws.view("cnn_pred") if (self.c.cnn_head and ws.call.heads_on) else ws.view("features")
+
     def backward(self, ws: Workspace, d_pred: Optional[torch.Tensor] = None, d_hidden: Optional[torch.Tensor] = None,
-                 grads: Optional[torch.Tensor] = None) -> None:
+                 grads: Optional[torch.Tensor] = None, d_cnn: Optional[torch.Tensor] = None) -> None:
         grads = self.grads if grads is None else grads
-        for t in (d_pred, d_hidden):
+        for t in (d_pred, d_hidden, d_cnn):
             if t is not None:
                 assert t.is_cuda and t.is_contiguous() and t.dtype == self.elem
-        L.check(self.lib.fh_student_backward(
+        L.check(self.lib.fh_student_backward_cnn(
             C.byref(self.c), C.byref(ws.call), self.params.data_ptr(), self.wc.data_ptr(), ws.buf.data_ptr(), grads.data_ptr(),
             ws.wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None,
             d_pred.data_ptr() if d_pred is not None else None, d_hidden.data_ptr() if d_hidden is not None else None,
-            self.stream()), "fh_student_backward")
+            d_cnn.data_ptr() if d_cnn is not None else None, self.stream()), "fh_student_backward")
 
     def kd_loss_rows(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
                      loss_type: int = 1, rec_weight: float = 1.0, sim_weight: float = 1.0, want_grad: bool = True):
@@ -284,10 +287,10 @@ class StudentEngine:
         return out, d_pred
 
     def kd_loss(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
-                loss_type: int = 0, grad_scale: float = 1.0, want_grad: bool = True):
+                loss_type: int = 0, grad_scale: float = 1.0, want_grad: bool = True, pred: Optional[torch.Tensor] = None):
         """Fused layer-wise KD loss (train.py:250-293).  teacher: [Lt][B][Tt][P] fp32 or bf16, contiguous.
         Returns (out_losses fp64 [L+1] on device, d_pred or None)."""
-        pred = ws.view("pred")
+        pred = ws.view("pred") if pred is None else pred
         Lh, B, Tp, P = pred.shape
         assert teacher.is_cuda and teacher.is_contiguous() and teacher.dim() == 4 and teacher.shape[1] == B and teacher.shape[3] == P
         tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16

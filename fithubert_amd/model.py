@@ -33,13 +33,14 @@ class _StudentFn(torch.autograd.Function):
         ws = eng.forward(source, lengths, training=training, heads_on=heads_on, seed=seed)
         ctx.ws, ctx.model = ws, model
         ctx.needs = training
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero tensors
         pred, xo = ws.view("pred"), ws.view("xo")
-        feats, f2 = ws.view("features"), ws.view("f2")
-        ctx.mark_non_differentiable(feats, f2)
+        feats, f2 = eng.features_to_distill(ws), ws.view("f2")   # model.py:482-487 (cnn_proj_head output when present)
+        ctx.mark_non_differentiable(f2)
         return pred, xo, feats, f2
 
     @staticmethod
-    def backward(ctx, d_pred, d_xo, _df, _df2):
+    def backward(ctx, d_pred, d_xo, d_feats, _df2):
         if not ctx.needs:
             raise RuntimeError("backward through CustomStudentModel requires model.train() (activations are not kept in eval mode)")
         eng = ctx.model.engine
@@ -49,7 +50,8 @@ class _StudentFn(torch.autograd.Function):
             if d_xo[0].abs().max().item() != 0:
                 raise NotImplementedError("gradient w.r.t. tr_layer_results is not built")
             d_hidden = d_xo[1:].contiguous()
-        eng.backward(ctx.ws, d_pred=d_pred.contiguous() if d_pred is not None else None, d_hidden=d_hidden, grads=g)
+        eng.backward(ctx.ws, d_pred=d_pred.contiguous() if d_pred is not None else None, d_hidden=d_hidden, grads=g,
+                     d_cnn=d_feats.contiguous() if d_feats is not None else None)
         return g, None, None, None, None, None, None
 
 

@@ -212,6 +212,9 @@ typedef struct {
    * n_tasks >= 2: DistilHuBERT-style head on the LAST layer only (modules/model.py:364-368,508-516): Linear(D, inter*n_tasks)
    * -> GELU -> SplitLinear(inter, n_tasks, pred_dim) (modules/module.py:585-619); "pred" is then [n_tasks][B][T][pred_dim]. */
   int n_tasks, inter_dim;
+  /* CNN distillation (train.py:241-246): 1 = cnn_proj_head GELU -> Linear(embed_dim, pred_dim) on the post_extract_proj output
+   * (model.py:305-310, present when pred_dim != embed_dim and cnn_loss_weight > 0); the workspace tensor "cnn_pred" holds it */
+  int cnn_head;
 } fh_student_config;
 
 /* per-call shape info */
@@ -244,6 +247,11 @@ int fh_student_forward(const fh_student_config* c, const fh_student_call* k, con
 int fh_student_backward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
                         void* ws, float* grads, const float* wave, const int* lens, const void* d_pred,
                         const void* d_hidden, fh_stream_t stream);
+/* same, plus d_cnn: gradient w.r.t. results["features"] as the loss sees it -- "cnn_pred" [B][T_conv][pred_dim] with a
+ * cnn_proj_head, the pre-dropout "features" [B][T_conv][embed_dim] without -- or NULL */
+int fh_student_backward_cnn(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
+                            void* ws, float* grads, const float* wave, const int* lens, const void* d_pred,
+                            const void* d_hidden, const void* d_cnn, fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frozen-teacher conv frontend on the student's kernels.  The teacher (fairseq HubertModel /

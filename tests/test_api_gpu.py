@@ -223,3 +223,63 @@ def test_ex_yaml_distilhubert_recipe_end_to_end():
         vals.append(task.training_step(bi, batch_idx=i, next_batch={k: v.to(DEV) for k, v in ds[(i + 1) % 2].items()})[-1].item())
     assert all(v == v and v < 1e3 for v in vals), vals
     assert min(vals[-2:]) < vals[0] + 1e-3, vals          # l1 + cosine goes down on a repeated pair of batches
+
+
+@pytest.mark.parametrize("recipe", ["fithubert", "ex"])
+def test_cnn_distillation_loss(recipe):
+    """train.py:241-246 with cnn_loss_weight > 0: l1 between results["features"] and the teacher's post_extract_proj output --
+    through cnn_proj_head (GELU -> Linear, model.py:305-310) when the student is narrower than the teacher (fithubert.yaml),
+    directly otherwise (ex.yaml).  Module-API loss and gradients against the oracle's autograd; fused hot path runs."""
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+    from oracle import loss_ref as LR
+
+    y = yaml.safe_load(open(os.path.join(ROOT, "conf", recipe + ".yaml")))
+    y["distiller"].update(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0, encoder_layers=2,
+                          init_conv_layers=False, init_encoder_layers=0)
+    y["train"].update(cnn_loss_weight=0.5, accumulate_grad_batches=1)
+    if recipe == "fithubert":
+        y["train"].update(distil_random_layer=1)
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 12 if recipe == "ex" else 2
+    task = W2V2Distil(y, dtype="float32", device=DEV, teacher_cfg=tc, seed=0, teacher_dtype=torch.float32)
+    sm = task.student_model
+    names = [k for k in sm.state_dict()]
+    assert ("cnn_proj_head.1.weight" in names) == (recipe == "fithubert")
+    # a padded pair for the head-less recipe (the projection aliases the encoder input, whose padded frames are zeroed in place);
+    # with a head and dropout_input == 0 the reference itself cannot back-propagate a padded batch (in-place zeroing of the GELU's
+    # saved input), so that recipe is checked on an unpadded pair
+    ds = SyntheticLibriDataset([12000, 10000] if recipe == "ex" else [12000, 12000], batch_size=2, seed=4)
+    b = {k: v.to(DEV) for k, v in ds[0].items()}
+    sm.train()
+    sres, tres = task(b["x"], b["padding_mask"])
+    assert sres["features"].shape[-1] == 768
+    total, losses = task.calculate_loss(sres, tres)
+    total.backward()
+    grads = sm.engine.param_views(sm.flat.grad)
+    # oracle on the same weights
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in sm.state_dict().items()}
+    ref = S.student_forward(sd, y["distiller"], b["x"].cpu(), b["padding_mask"].cpu(), training=True)
+    t_res = {"layer_results": [(lr[0].float().cpu(), (None, None)) for lr in tres["layer_results"]],
+             "features": [tres["features"][0].float().cpu()]}
+    if recipe == "ex":
+        lo, ld = LR.calculate_loss(ref, t_res, y["train"], pred_layer_id=[3, 7, 11], layerwise_proj=False)
+    else:
+        lo, ld = LR.calculate_loss(ref, t_res, y["train"], rand_l=list(task.rand_l), layerwise_proj=True)
+    lo.backward()
+    assert abs(total.item() - lo.item()) < 2e-4 * abs(lo.item()), (total.item(), lo.item())
+    assert abs(losses["cnn_loss"].item() - ld["cnn_loss"].item()) < 2e-4 * abs(ld["cnn_loss"].item())
+    bad = []
+    for k, gv in grads.items():
+        rg = sd[k].grad
+        if rg is None or rg.norm().item() < 1e-7:
+            continue
+        e = _rel_l2(gv.float(), rg)
+        if e > 3e-3:
+            bad.append((k, e))
+    assert not bad, bad
+    # fused hot path: same total on the first step, and it trains
+    task.configure_optimizers(num_training_steps=10)
+    out = task.training_step(b, batch_idx=0)
+    assert abs(out[-1].item() - lo.item()) < 2e-3 * abs(lo.item()), (out[-1].item(), lo.item())
