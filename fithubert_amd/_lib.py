@@ -85,6 +85,10 @@ class StudentConfigC(C.Structure):
     ]
 
 
+class StudentGradsC(C.Structure):
+    _fields_ = [("d_pred", C.c_void_p), ("d_hidden", C.c_void_p), ("d_cnn", C.c_void_p), ("d_qkv_last", C.c_void_p)]
+
+
 class StudentCallC(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("training", C.c_int), ("heads_on", C.c_int), ("seed", C.c_uint32)]
 
@@ -101,6 +105,7 @@ _ENGINE_SIGS = {
     "fh_student_forward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P]),
     "fh_student_backward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fh_student_backward_cnn": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fh_student_backward_ex": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, C.POINTER(StudentGradsC), _P]),
 }
 
 

@@ -637,7 +637,7 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
 }
 
 int backward(const Ctx& x, float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden,
-             const void* d_cnn = nullptr) {
+             const void* d_cnn = nullptr, const void* d_qkv_last = nullptr) {
   const Plan& p = x.p;
   const fh_student_config& c = p.c;
   const Shapes& s = p.sh;
@@ -807,6 +807,8 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
                                x.W<float>(p.lse) + (long)l * B * H * s.T2, x.W<float>(p.delta),
                                x.at(p.dqkv, (long)l * M2 * 3 * D), len_2, B, s.T2, H, D / H, scale,
                                x.drop(c.attention_dropout, site + 0), x.st));
+    if (l == L - 1 && d_qkv_last)  // attention-logit / value-relation transfer gradients enter at the last layer's q|k|v
+      RC(fh_unary_launch(dt, d_qkv_last, x.at(p.dqkv, (long)l * M2 * 3 * D), M2 * 3 * D, 1, x.st));
     {  // dxin = dqkv . Wqkv + ds1
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.at(p.dqkv, (long)l * M2 * 3 * D), FH_R_CONTIG, 3 * D);
@@ -1078,6 +1080,16 @@ int fh_student_backward_cnn(const fh_student_config* c, const fh_student_call* k
   if (p.ok != 0) return p.ok;
   Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
   return backward(x, grads, wave, lens, d_pred, d_hidden, d_cnn);
+}
+
+int fh_student_backward_ex(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
+                           float* grads, const float* wave, const int* lens, const fh_student_grads* g, fh_stream_t stream) {
+  if (!c || !k || !g) return -1;
+  RC(validate(*c));
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
+  return backward(x, grads, wave, lens, g->d_pred, g->d_hidden, g->d_cnn, g->d_qkv_last);
 }
 
 }  // extern "C"

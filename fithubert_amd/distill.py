@@ -60,10 +60,13 @@ class W2V2Distil:
         self.attn_loss_type = t["attn_loss_type"]
         self.v_rel_loss_weight = t["v_rel_loss_weight"]
         self.random_layer_weight = t["random_layer_weight"]
-        for k in ("attn_loss_weight", "v_rel_loss_weight"):
-            if t[k] > 0:
-                raise NotImplementedError(f"train.{k} > 0 (attention-logit / value-relation transfer, utils/utils.py:193-280) is not "
-                                          "built; the fused kernels cover rec_loss (mse / l1), the cosine sim_loss and the CNN l1 loss")
+        self._attn_transfer = t["attn_loss_weight"] > 0 or t["v_rel_loss_weight"] > 0
+        if self._attn_transfer:   # train.py:64-78: both models return the last layer's (attn_logits, v_rel)
+            if self.model_cfg.get("enable_tr_layer"):
+                raise NotImplementedError("attention / value-relation transfer needs equal frame counts in student and teacher: "
+                                          "enable_tr_layer must be False (the reference's shapes disagree otherwise)")
+            self.student_model.return_attn = True
+            self.teacher_model.model.return_attn = True
         if t["sim_loss_weight"] > 0 and t["distil_random_layer"] > 0:
             # the reference itself cannot run this: sim_loss is 3-D and train.py:305 takes mean((0, 2, 3))
             raise NotImplementedError("sim_loss_weight > 0 needs distil_random_layer == 0 (train.py:302-306 fails otherwise)")
@@ -153,6 +156,15 @@ class W2V2Distil:
             cnn = _L1Fn.apply(student_results["features"], teacher_results["features"][0], self)
             losses["cnn_loss"] = cnn
             total = total + self.cnn_loss_weight * cnn
+        if self._attn_transfer:       # train.py:327-370 (plain torch ops on the last layers' logits; autograd reaches the engine
+            from .attn_transfer import attn_loss, v_rel_loss   # through the differentiable q|k|v output of the student node)
+            s_ex, t_ex = student_results["layer_results"][-1][1], teacher_results["layer_results"][-1][1][0]
+            if self.attn_loss_weight > 0:
+                losses["attn_loss"] = attn_loss(s_ex[0], t_ex[0], self.attn_loss_type)
+                total = total + self.attn_loss_weight * losses["attn_loss"]
+            if self.v_rel_loss_weight > 0:
+                losses["v_rel_loss"] = v_rel_loss(s_ex[1], t_ex[1])
+                total = total + self.v_rel_loss_weight * losses["v_rel_loss"]
         return total.float(), losses
 
     def _loss_dict(self, out) -> Dict[str, torch.Tensor]:
@@ -199,9 +211,10 @@ class W2V2Distil:
         pm = batch.get("padding_mask")
         if pm is not None and not bool(batch.get("_any_pad", True)) and self.teacher_model.model.cfg.model_type != "hubert":
             pm = None
-        if self.cnn_loss_weight > 0:  # CNN loss target: the teacher's post_extract_proj output (utils/utils.py:71-73 hook)
+        if self.cnn_loss_weight > 0 or self._attn_transfer:
             hid, post, _ = self.teacher_model.model.run(batch["x"], pm)
-            hid._fh_post = post.contiguous()
+            hid._fh_post = post.contiguous()   # CNN loss target: the teacher's post_extract_proj output (utils/utils.py:71-73 hook)
+            hid._fh_qkv = self.teacher_model.model.last_qkv   # attention transfer: the last layer's q|k|v projection
             return hid
         return self.teacher_model.hidden_stack(batch["x"], pm)
 
@@ -216,6 +229,10 @@ class W2V2Distil:
             ev = torch.cuda.Event()
             ev.record(self.teacher_stream)
         hid.record_stream(main)  # consumed by the loss kernel on the main stream
+        for extra in ("_fh_post", "_fh_qkv"):
+            t = getattr(hid, extra, None)
+            if t is not None:
+                t.record_stream(main)
         return hid, ev
 
     @torch.no_grad()
@@ -256,7 +273,20 @@ class W2V2Distil:
             self.last_cnn_loss = cout[0]           # device scalar, for logging (losses['cnn_loss'], train.py:244)
             feat_total = out[-1] if self._rows_loss else float(self.rec_loss_weight) * out[-1]
             out = torch.cat([out[:-1], (feat_total + float(self.cnn_loss_weight) * cout[0]).reshape(1)])  # [-1] = train.py:372-378
-        self.engine.backward(ws, d_pred=d_pred, d_cnn=d_cnn)
+        d_qkv = None
+        if self._attn_transfer:   # train.py:327-370 on the last layers' q|k|v projections (fithubert_amd/attn_transfer.py)
+            from .attn_transfer import transfer
+            D3 = 3 * self.engine.c.embed_dim
+            s_qkv = ws.view("qkv")[-1].view(x.shape[0], -1, D3)
+            key_len = ws.lens[1] if ws.lens is not None else None
+            with torch.enable_grad():
+                tot, parts, d_qkv = transfer(s_qkv, hid._fh_qkv, self.engine.c.heads, self.teacher_model.model.cfg.encoder_attention_heads,
+                                             key_len, float(self.attn_loss_weight), self.attn_loss_type, float(self.v_rel_loss_weight))
+            d_qkv = d_qkv.view(-1, D3)
+            self.last_transfer_losses = parts
+            feat_total = out[-1] if (self._rows_loss or self.cnn_loss_weight > 0) else float(self.rec_loss_weight) * out[-1]
+            out = torch.cat([out[:-1], (feat_total + tot.double()).reshape(1)])
+        self.engine.backward(ws, d_pred=d_pred, d_cnn=d_cnn, d_qkv_last=d_qkv)
         self._micro += 1
         if self._micro >= self.accumulate:
             self.sync.launch()                      # async all-reduce of the flat gradients (RCCL / xGMI)

@@ -256,16 +256,18 @@ class StudentEngine:
         return ws.view("cnn_pred") if (self.c.cnn_head and ws.call.heads_on) else ws.view("features")
 
     def backward(self, ws: Workspace, d_pred: Optional[torch.Tensor] = None, d_hidden: Optional[torch.Tensor] = None,
-                 grads: Optional[torch.Tensor] = None, d_cnn: Optional[torch.Tensor] = None) -> None:
+                 grads: Optional[torch.Tensor] = None, d_cnn: Optional[torch.Tensor] = None,
+                 d_qkv_last: Optional[torch.Tensor] = None) -> None:
         grads = self.grads if grads is None else grads
-        for t in (d_pred, d_hidden, d_cnn):
+        for t in (d_pred, d_hidden, d_cnn, d_qkv_last):
             if t is not None:
                 assert t.is_cuda and t.is_contiguous() and t.dtype == self.elem
-        L.check(self.lib.fh_student_backward_cnn(
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        g = L.StudentGradsC(ptr(d_pred), ptr(d_hidden), ptr(d_cnn), ptr(d_qkv_last))
+        L.check(self.lib.fh_student_backward_ex(
             C.byref(self.c), C.byref(ws.call), self.params.data_ptr(), self.wc.data_ptr(), ws.buf.data_ptr(), grads.data_ptr(),
-            ws.wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None,
-            d_pred.data_ptr() if d_pred is not None else None, d_hidden.data_ptr() if d_hidden is not None else None,
-            d_cnn.data_ptr() if d_cnn is not None else None, self.stream()), "fh_student_backward")
+            ws.wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None, C.byref(g), self.stream()),
+            "fh_student_backward")
 
     def kd_loss_rows(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
                      loss_type: int = 1, rec_weight: float = 1.0, sim_weight: float = 1.0, want_grad: bool = True):

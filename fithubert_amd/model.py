@@ -36,11 +36,12 @@ class _StudentFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero tensors
         pred, xo = ws.view("pred"), ws.view("xo")
         feats, f2 = eng.features_to_distill(ws), ws.view("f2")   # model.py:482-487 (cnn_proj_head output when present)
+        qkv_last = ws.view("qkv")[-1].view(source.shape[0], -1, 3 * eng.c.embed_dim)   # last layer's packed q|k|v projection
         ctx.mark_non_differentiable(f2)
-        return pred, xo, feats, f2
+        return pred, xo, feats, f2, qkv_last
 
     @staticmethod
-    def backward(ctx, d_pred, d_xo, d_feats, _df2):
+    def backward(ctx, d_pred, d_xo, d_feats, _df2, d_qkv):
         if not ctx.needs:
             raise RuntimeError("backward through CustomStudentModel requires model.train() (activations are not kept in eval mode)")
         eng = ctx.model.engine
@@ -51,7 +52,8 @@ class _StudentFn(torch.autograd.Function):
                 raise NotImplementedError("gradient w.r.t. tr_layer_results is not built")
             d_hidden = d_xo[1:].contiguous()
         eng.backward(ctx.ws, d_pred=d_pred.contiguous() if d_pred is not None else None, d_hidden=d_hidden, grads=g,
-                     d_cnn=d_feats.contiguous() if d_feats is not None else None)
+                     d_cnn=d_feats.contiguous() if d_feats is not None else None,
+                     d_qkv_last=d_qkv.contiguous().view(-1, d_qkv.shape[-1]) if d_qkv is not None else None)
         return g, None, None, None, None, None, None
 
 
@@ -80,6 +82,7 @@ class CustomStudentModel(nn.Module):
         self.feature_grad_mult = cfg.feature_grad_mult
         self.encoder = _EncoderNS(cfg.encoder_layers + (1 if cfg.enable_tr_layer else 0))
         self._heads_on = True
+        self.return_attn = False   # set by the task when attention / value-relation transfer is on (train.py:64-78)
         self.specaug = None
         self._step_seed = 0
         self.reset_parameters(init_seed)
@@ -231,9 +234,16 @@ class CustomStudentModel(nn.Module):
             Tp = self.engine.frames(S)[0]
             pm_out = (torch.arange(Tp)[None, :] >= torch.tensor(tp)[:, None]).to(source.device)
         self._step_seed = (self._step_seed + 1) & 0x7FFFFFFF
-        pred, xo, feats, f2 = _StudentFn.apply(self.flat, self, source, lengths, self.training, self._heads_on, self._step_seed)
+        pred, xo, feats, f2, qkv_last = _StudentFn.apply(self.flat, self, source, lengths, self.training, self._heads_on, self._step_seed)
         L = self.cfg.encoder_layers
         layer_results = [(xo[i + 1].transpose(0, 1), None, f2[i].transpose(0, 1)) for i in range(L)]
+        if self.return_attn:  # utils/utils.py:193-280 patched in by train.py:64-78: (attn_logits, v_rel) of the LAST layer
+            from .attn_transfer import attention_extras
+            key_len = None
+            if lengths is not None:
+                key_len = torch.tensor(self.engine.frame_lengths(lengths)[1], dtype=torch.int32, device=source.device)
+            extras = attention_extras(qkv_last, self.cfg.encoder_attention_heads, key_len)
+            layer_results[-1] = (layer_results[-1][0], extras, layer_results[-1][2])
         tr_layer_results = [xo[0].transpose(0, 1)] if self.cfg.enable_tr_layer else []
         if not self.layerwise_proj:  # model.py:503-516: x is the encoder output, projections B x N x T x D
             x = xo[L]

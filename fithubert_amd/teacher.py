@@ -304,6 +304,9 @@ class TeacherModel(nn.Module):
         self.encoder = _Encoder(cfg)
         self.native_frontend = False   # True: conv frontend + positional conv on the HIP kernels (GPU only)
         self._native = None
+        self.return_attn = False       # True: keep the LAST layer's q|k|v projection (attention / value-relation transfer)
+        self.last_qkv = None
+        self.last_key_len = None
 
     def enable_native_frontend(self, on: bool = True):
         self.native_frontend = on
@@ -369,16 +372,27 @@ class TeacherModel(nn.Module):
         L = len(self.encoder.layers)
         hidden = torch.empty(L, B, T, x.shape[-1], device=x.device, dtype=dt)
         fc2 = [] if want_fc2 else None
+        self.last_key_len = None if fm is None else (~fm).sum(-1).to(torch.int32)
+
+        def stash_qkv(layer, xin):  # the reference's rtrn_attn_forward (utils/utils.py:244-263) sees exactly these projections
+            a = layer.self_attn
+            h = layer.self_attn_layer_norm(xin) if layer.pre_ln else xin
+            self.last_qkv = torch.cat([a.q_proj(h), a.k_proj(h), a.v_proj(h)], dim=-1)
+
         if native is not None and native.layers_native:
             # right-padded batches (what dataset.collate produces): the key mask is a per-utterance valid-frame count
             key_len = None if fm is None else (~fm).sum(-1).to(torch.int32)
             x = x.contiguous()
             for i in range(L):
+                if self.return_attn and i == L - 1:
+                    stash_qkv(self.encoder.layers[i], x)
                 x, lr = native.layer(i, x, key_len, hidden[i])
                 if want_fc2:
                     fc2.append(lr)
             return hidden, post, fc2
         for i, layer in enumerate(self.encoder.layers):
+            if self.return_attn and i == L - 1:
+                stash_qkv(layer, x)
             x, lr = layer(x, key_mask)
             hidden[i].copy_(x)
             if want_fc2:
@@ -396,6 +410,10 @@ class TeacherWrapper(nn.Module):
     def extract_features(self, source, padding_mask):
         hidden, post, fc2 = self.model.run(source, padding_mask, want_fc2=True)
         layer_results = [(hidden[i].transpose(0, 1), (None, fc2[i].transpose(0, 1))) for i in range(hidden.shape[0])]
+        if self.model.return_attn:  # utils/utils.py:278: the patched layer returns ((attn_logits, v_rel), fc2_out)
+            from .attn_transfer import attention_extras
+            extras = attention_extras(self.model.last_qkv, self.model.cfg.encoder_attention_heads, self.model.last_key_len)
+            layer_results[-1] = (layer_results[-1][0], (extras, layer_results[-1][1][1]))
         return {"layer_results": layer_results, "x": hidden[-1], "features": [post]}
 
     def hidden_stack(self, source, padding_mask=None):

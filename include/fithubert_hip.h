@@ -252,6 +252,18 @@ int fh_student_backward(const fh_student_config* c, const fh_student_call* k, co
 int fh_student_backward_cnn(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
                             void* ws, float* grads, const float* wave, const int* lens, const void* d_pred,
                             const void* d_hidden, const void* d_cnn, fh_stream_t stream);
+/* all upstream gradients in one struct; d_qkv_last: gradient w.r.t. the LAST layer's packed q|k|v projection (workspace "qkv"
+ * slot L-1, [B*T_enc][3*embed_dim]) -- the entry point of the attention-logit / value-relation transfer losses
+ * (utils/utils.py:244-278, train.py:327-370), whose logits are functions of that projection only */
+typedef struct {
+  const void* d_pred;
+  const void* d_hidden;
+  const void* d_cnn;
+  const void* d_qkv_last;
+} fh_student_grads;
+int fh_student_backward_ex(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
+                           void* ws, float* grads, const float* wave, const int* lens, const fh_student_grads* g,
+                           fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frozen-teacher conv frontend on the student's kernels.  The teacher (fairseq HubertModel /
