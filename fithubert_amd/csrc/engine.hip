@@ -122,8 +122,13 @@ struct ParamLayout {
       const long I = c.inter_dim, Nt = c.n_tasks;
       sp_w0 = add("proj_head.0.weight", {I * Nt, D});
       sp_b0 = add("proj_head.0.bias", {I * Nt});
-      sp_w2 = add("proj_head.2.weight", {Nt, I, P});   // SplitLinear: [task][Din][Dout]
-      sp_b2 = add("proj_head.2.bias", {1, 1, Nt, P});
+      if (Nt > 1) {
+        sp_w2 = add("proj_head.2.weight", {Nt, I, P});   // SplitLinear: [task][Din][Dout]
+        sp_b2 = add("proj_head.2.bias", {1, 1, Nt, P});
+      } else {                                          // in_split == 1: a plain nn.Linear (module.py:604-605)
+        sp_w2 = add("proj_head.2.layer.weight", {P, I});
+        sp_b2 = add("proj_head.2.layer.bias", {P});
+      }
       return;
     }
     for (int l = 0; l < c.layers; ++l) {
@@ -342,7 +347,7 @@ inline int validate(const fh_student_config& c) {
     return -814;
   if (c.tr_factor != 0 && c.tr_factor != 2) return -815;  // shipped configs: conv1d TR with factor 2 at index 0
   if (!fh_posconv_cp(c.embed_dim / c.conv_pos_groups) || (c.embed_dim / c.conv_pos_groups) % 2) return -818;
-  if (c.n_tasks < 0 || c.n_tasks == 1 || (c.n_tasks > 0 && (c.inter_dim <= 0 || c.inter_dim % vec || c.tr_factor != 0))) return -817;
+  if (c.n_tasks < 0 || (c.n_tasks > 0 && (c.inter_dim <= 0 || c.inter_dim % vec || c.tr_factor != 0))) return -817;
   for (int i = 1; i < c.n_conv; ++i) {
     const int kk = c.conv_k[i], s = c.conv_stride[i];
     if (!((kk == s) || (kk == 1 && s == 1) || (kk == 3 && s == 2))) return -816;
@@ -585,8 +590,12 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
     GemmParams g2 = fh_gemm_params();  // pred[n] = hh[:, n*I:(n+1)*I] . W2[n]  (+ b2[n])
     g2.X = fh_operand(x.W(p.hh), FH_R_CONTIG, (long)I * Nt);
     g2.X.gstride = I;
-    g2.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_STRIDED, P);
-    g2.Y.gstride = (long)I * P;
+    if (Nt > 1) {
+      g2.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_STRIDED, P);
+      g2.Y.gstride = (long)I * P;
+    } else {
+      g2.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_CONTIG, I);  // nn.Linear weight [P][I]
+    }
     g2.C = x.W(p.pred);
     g2.M = (int)M2; g2.N = P; g2.Kseg = I; g2.ldc = P;
     g2.c_gstride = M2 * P;
@@ -661,8 +670,12 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(d_pred, FH_R_CONTIG, P);
       g.X.gstride = M2 * P;
-      g.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_CONTIG, P);
-      g.Y.gstride = (long)I * P;
+      if (Nt > 1) {
+        g.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_CONTIG, P);
+        g.Y.gstride = (long)I * P;
+      } else {
+        g.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_STRIDED, I);
+      }
       g.C = x.W(p.dhz);
       g.M = (int)M2; g.N = I; g.Kseg = P; g.ldc = IN;
       g.c_gstride = I;
@@ -671,9 +684,14 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
       RC(fh_gemm_launch(g, dt, x.st));
     }
     {  // dW2[n][r][j] += sum_m hh[m][n*I + r] * d_pred[n][m][j] ; db2[n] = colsum(d_pred[n])
-      GemmOperand A = fh_operand(d_pred, FH_R_STRIDED, P);
-      A.gstride = M2 * P;
-      RC(wgrad(x, x.W(p.hh), IN, A, grads + p.pl.sp_w2, I, P, M2, Nt, I, (long)I * P));
+      if (Nt > 1) {
+        GemmOperand A = fh_operand(d_pred, FH_R_STRIDED, P);
+        A.gstride = M2 * P;
+        RC(wgrad(x, x.W(p.hh), IN, A, grads + p.pl.sp_w2, I, P, M2, Nt, I, (long)I * P));
+      } else {  // dW[j][r] += sum_m d_pred[m][j] * hh[m][r]
+        GemmOperand A = fh_operand(x.W(p.hh), FH_R_STRIDED, I);
+        RC(wgrad(x, d_pred, P, A, grads + p.pl.sp_w2, P, I, M2, 1, 0, 0));
+      }
       RC(fh_colsum_launch(dt, d_pred, grads + p.pl.sp_b2, (int)M2, P, P, Nt, M2 * P, P, 0, 1.f, x.st));
     }
     {  // ghead[L-1] = dhz . W0 (+ d_hidden[L-1])

@@ -45,8 +45,8 @@ def unsupported(cfg: CustomStudentModelConfig) -> Optional[str]:
         return "time reduction is built for tr_layer_type='conv1d', tr_layer_index=0, tr_reduce_factor=2 (fithubert.yaml)"
     if not cfg.layerwise_proj:
         # DistilHuBERT-style head (model.py:364-368): Linear -> GELU -> SplitLinear over len(pred_layer_id) tasks
-        if len(cfg.pred_layers()) < 2:
-            return "layerwise_proj=False needs at least two pred_layer_id tasks (SplitLinear); the single-task nn.Linear form is not built"
+        if len(cfg.pred_layers()) < 1:
+            return "layerwise_proj=False without any pred_layer_id task has no head to train"
         if cfg.enable_tr_layer:
             return "layerwise_proj=False together with enable_tr_layer (shared upsampler, model.py:504-505) is not built"
     elif cfg.pred_head_final_dim == cfg.encoder_embed_dim:

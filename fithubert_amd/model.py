@@ -119,7 +119,7 @@ class CustomStudentModel(nn.Module):
                 t = torch.randn(shape, generator=g) * math.sqrt(4.0 / (k * e))
             elif name.endswith("weight_g"):
                 t = None  # set from weight_v below (weight_norm initialises g = ||v||)
-            elif name in ("proj_head.2.weight", "proj_head.2.bias"):  # SplitLinear, module.py:596-603
+            elif name in ("proj_head.2.weight", "proj_head.2.bias", "proj_head.2.layer.weight", "proj_head.2.layer.bias"):  # module.py:596-605
                 bound = float(self.engine.c.inter_dim) ** -0.5
                 t = (torch.rand(shape, generator=g) * 2 - 1) * bound
             elif "layer_norm.weight" in name or name.endswith(".2.weight"):

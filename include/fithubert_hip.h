@@ -209,8 +209,9 @@ typedef struct {
   float dropout, attention_dropout, activation_dropout, dropout_input;
   float feature_grad_mult;
   /* heads: n_tasks == 0: one LayerWiseProjHead per layer (layerwise_proj, modules/module.py:625-661).
-   * n_tasks >= 2: DistilHuBERT-style head on the LAST layer only (modules/model.py:364-368,508-516): Linear(D, inter*n_tasks)
-   * -> GELU -> SplitLinear(inter, n_tasks, pred_dim) (modules/module.py:585-619); "pred" is then [n_tasks][B][T][pred_dim]. */
+   * n_tasks >= 1: DistilHuBERT-style head on the LAST layer only (modules/model.py:364-368,508-516): Linear(D, inter*n_tasks)
+   * -> GELU -> SplitLinear(inter, n_tasks, pred_dim) (modules/module.py:585-619; a plain Linear when n_tasks == 1); "pred" is then
+   * [n_tasks][B][T][pred_dim]. */
   int n_tasks, inter_dim;
   /* CNN distillation (train.py:241-246): 1 = cnn_proj_head GELU -> Linear(embed_dim, pred_dim) on the post_extract_proj output
    * (model.py:305-310, present when pred_dim != embed_dim and cnn_loss_weight > 0); the workspace tensor "cnn_pred" holds it */

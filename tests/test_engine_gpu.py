@@ -303,3 +303,34 @@ def test_ex_config_split_linear_heads_l1_cosine(dtype, tol_l2, golden_dir):
         if e > tol:
             bad.append((k, e, n))
     assert not bad, bad
+
+
+def test_single_task_head_is_a_plain_linear(golden_dir):
+    """layerwise_proj=False with one pred_layer_id: SplitLinear degenerates to nn.Linear (module.py:604-605; parameter
+    names proj_head.2.layer.*).  Forward, l1 + cosine loss and gradients against the oracle, fp32."""
+    fx = np.load(os.path.join(golden_dir, "student_ex.npz"))
+    cfg = yaml.safe_load(str(fx["cfg_yaml"]))
+    cfg = dict(cfg, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0, pred_layer_id="[7]")
+    eng, sd = _engine(cfg, 21, "float32")
+    assert eng.c.n_tasks == 1 and "proj_head.2.layer.weight" in sd
+    wav = torch.from_numpy(fx["wav"])
+    ws = eng.forward(wav.to(DEV), None, training=True, seed=1)
+    Te = ws.view("pred").shape[2]
+    tg = torch.Generator().manual_seed(3)
+    t_layers = [torch.randn(Te, 2, 768, generator=tg) for _ in range(12)]
+    teacher = torch.stack([t.transpose(0, 1) for t in t_layers]).contiguous()
+    out, d_pred = eng.kd_loss_rows(ws, teacher.to(DEV), torch.ones(1, device=DEV), torch.tensor([7], dtype=torch.int32, device=DEV),
+                                   loss_type=1, rec_weight=1.0, sim_weight=1.0)
+    eng.grads.zero_()
+    eng.backward(ws, d_pred=d_pred)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = S.student_forward(sdg, cfg, wav.clone(), None, training=True)
+    assert _rel_l2(ws.view("pred").float().permute(1, 0, 2, 3), ref["projections"]) < 2e-4
+    tc = dict(rec_loss_weight=1.0, rec_loss_type="l1", sim_loss_weight=1.0, distil_random_layer=0, random_layer_weight=0)
+    loss, _ = LR.calculate_loss(ref, {"layer_results": [(t, (None, None)) for t in t_layers]}, tc, pred_layer_id=[7], layerwise_proj=False)
+    loss.backward()
+    assert abs(out[1].item() - loss.item()) < 1e-4
+    for k, gv in eng.param_views(eng.grads).items():
+        rg = sdg[k].grad
+        if rg is not None and rg.norm().item() > 1e-6:
+            assert _rel_l2(gv.float(), rg) < 2e-3, k

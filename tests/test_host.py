@@ -94,8 +94,11 @@ def test_ex_yaml_param_table_equals_reference_state_dict():
     for k in ref:
         assert tuple(ours[k]) == tuple(ref[k]), k
     assert ours["proj_head.2.weight"] == (3, 768, 768) and ours["proj_head.2.bias"] == (1, 1, 3, 768)
-    d = dict(y["distiller"], pred_layer_id="[11]")
-    assert unsupported(CustomStudentModelConfig(**d))  # single-task nn.Linear head: not built, fails loudly
+    d = dict(y["distiller"], pred_layer_id="[11]")      # single task: SplitLinear degenerates to nn.Linear (module.py:604-605)
+    cfg1 = CustomStudentModelConfig(**d)
+    assert unsupported(cfg1) is None
+    ours1 = {n: s for n, _, s in param_table(cfg1, "bf16")[0]}
+    assert ours1 == {k: tuple(v) for k, v in S.param_shapes(d).items()}
 
 
 def test_gemm_table_roundtrip(tmp_path):
