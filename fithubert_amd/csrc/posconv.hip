@@ -15,7 +15,8 @@
 
 namespace {
 
-constexpr int TT = 128;   // output frames per block (fwd / dgrad)
+constexpr int TT = 256;   // output frames per block (fwd / dgrad): 4 waves x 64 frames
+constexpr int NTT = TT / 64;  // 16-frame tiles per wave: each tap's weight fragments (streamed from L2) serve all of them
 
 template <typename T, int CP> struct PC {
   static constexpr int RS = CP * (int)sizeof(T) + 16;  // LDS row stride in bytes
@@ -155,11 +156,11 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
   stage_rows<T, CP, BWD>(lds, in, zc_in, out1, b, Tn, D, cg, g, t0 - pad_left, nrows, pad_left, pad_left + TT);
   __syncthreads();
 
-  f32x4 acc[CB][2];
+  f32x4 acc[CB][NTT];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * K * CP * CP;
   const int r = lane & 15;
   // weights stream from L2 (identical for every workgroup of the group): keep the NEXT tap's fragments in flight
@@ -182,20 +183,20 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
       for (int cb = 0; cb < CB; ++cb) wn[kr][cb] = F::gmem_row(wg + (long)jn * CP * CP, cb * 16 + r, lane, kr);
 #pragma unroll
     for (int kr = 0; kr < F::NK; ++kr) {
-      typename F::type xf[2];
+      typename F::type xf[NTT];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) xf[tt] = F::lds_row(lds, wave * 32 + tt * 16 + r + j, lane, kr);
+      for (int tt = 0; tt < NTT; ++tt) xf[tt] = F::lds_row(lds, wave * (16 * NTT) + tt * 16 + r + j, lane, kr);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) acc[cb][tt] = F::mma(wf[kr][cb], xf[tt], acc[cb][tt]);
+        for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = F::mma(wf[kr][cb], xf[tt], acc[cb][tt]);
     }
   }
 
   const int q = lane >> 4;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int tl = wave * 32 + tt * 16 + r;
+  for (int tt = 0; tt < NTT; ++tt) {
+    const int tl = wave * (16 * NTT) + tt * 16 + r;
     const int t = t0 + tl;
     if (t >= Tn) continue;
 #pragma unroll

@@ -8,7 +8,8 @@
 namespace {
 
 constexpr int CPW = 64;
-constexpr int TTW = 128;
+constexpr int TTW = 256;   // frames per workgroup: 4 waves x 64 frames (each tap's weight fragments serve 4 frame tiles)
+constexpr int NTT = TTW / 64;  // 16-frame tiles per wave
 
 template <typename T> struct PW { static constexpr int RS = CPW * (int)sizeof(T) + 16; };
 
@@ -76,9 +77,11 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
   }
   __syncthreads();
   const int ncb = (cg + 15) / 16;  // output-channel blocks that hold real channels
-  f32x4 acc[4][2];
+  f32x4 acc[4][NTT];
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) acc[cb][0] = acc[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * K * CPW * CPW;
   if constexpr (IS_BF) {
     // next tap's weight fragments are loaded (from L2) while this tap's MFMAs run
@@ -102,15 +105,15 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
           if (cb < ncb) wn[ks][cb] = *reinterpret_cast<const bf16x8*>(wj + (long)(cb * 16 + r) * CPW + ks * 32 + q * 8);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 xf[2];
+        bf16x8 xf[NTT];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-          xf[tt] = *reinterpret_cast<const bf16x8*>(lds + (wave * 32 + tt * 16 + r + j) * RS + ks * 64 + q * 16);
+        for (int tt = 0; tt < NTT; ++tt)
+          xf[tt] = *reinterpret_cast<const bf16x8*>(lds + (wave * (16 * NTT) + tt * 16 + r + j) * RS + ks * 64 + q * 16);
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           if (cb < ncb) {
-            acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cb], xf[0], acc[cb][0], 0, 0, 0);
-            acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cb], xf[1], acc[cb][1], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cb], xf[tt], acc[cb][tt], 0, 0, 0);
           }
         }
       }
@@ -120,27 +123,26 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
       const T* wj = wg + (long)j * CPW * CPW;
 #pragma unroll
       for (int kr = 0; kr < 4; ++kr) {
-        f32x4 xf[2];
+        f32x4 xf[NTT];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-          xf[tt] = *reinterpret_cast<const f32x4*>(lds + (wave * 32 + tt * 16 + r + j) * RS + kr * 64 + q * 16);
+        for (int tt = 0; tt < NTT; ++tt)
+          xf[tt] = *reinterpret_cast<const f32x4*>(lds + (wave * (16 * NTT) + tt * 16 + r + j) * RS + kr * 64 + q * 16);
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           if (cb < ncb) {
             const f32x4 wf = *reinterpret_cast<const f32x4*>(wj + (long)(cb * 16 + r) * CPW + kr * 16 + q * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xf[0][e], acc[cb][0], 0, 0, 0);
-              acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xf[1][e], acc[cb][1], 0, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xf[tt][e], acc[cb][tt], 0, 0, 0);
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int tl = wave * 32 + tt * 16 + r;
+  for (int tt = 0; tt < NTT; ++tt) {
+    const int tl = wave * (16 * NTT) + tt * 16 + r;
     const int t = t0 + tl;
     if (t >= Tn) continue;
 #pragma unroll
@@ -194,6 +196,7 @@ extern "C" int fh_posconv_wide_forward(int dtype, const void* x, const void* w_f
                        T, D, cg, K, K / 2);
   } else {
     const size_t smem = (size_t)(TTW + K - 1) * PW<bf16>::RS;
+    hipFuncSetAttribute((const void*)posconv_wide_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(posconv_wide_kernel<bf16>, grid, block, smem, st, (const bf16*)x, (const bf16*)w_fwd, bias, (bf16*)y, B, T, D,
                        cg, K, K / 2);
   }
