@@ -15,6 +15,7 @@ train.py:166-168, forces a host sync per term per step).
 from __future__ import annotations
 
 import math
+import os
 import random
 from typing import Dict, Optional
 
@@ -105,6 +106,8 @@ class W2V2Distil:
         # the frozen teacher runs on its own HIP stream: its forward for batch i+1 overlaps the student's forward /
         # backward of batch i (and the gradient all-reduce), filling CUs the student's short kernels leave idle
         self.teacher_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        if os.environ.get("FH_TEACHER_STREAM", "1") == "0":   # A/B: teacher serialised on the main stream
+            self.teacher_stream = None
 
     # ------------------------------------------------------------------ loss tables
     def _set_loss_tables(self):
