@@ -1568,10 +1568,13 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   __builtin_amdgcn_sched_barrier(0);
 
   bf16x8 fa[2][4], fb[2][2];  // [ks][m-tile of the half], [ks][n-tile of the half]
+  // the DMA wait (this wave's own loads, RAW) goes BEFORE the barrier; the fragment reads are only waited for behind it, so
+  // their latency overlaps the wait for the other wave group (the buffers they read are rewritten a whole K-tile later)
 #define FH_PHASE_TAIL(WAITSTR)                                   \
   asm volatile(WAITSTR ::: "memory");                            \
   __builtin_amdgcn_sched_barrier(0);                             \
   __builtin_amdgcn_s_barrier();                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
   __builtin_amdgcn_sched_barrier(0);                             \
   __builtin_amdgcn_s_setprio(1);
 #define FH_PHASE_MMA(MH, NH)                                                                                          \
@@ -1599,22 +1602,22 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
     FH_READ_A(0)
     advance();
     lx.issue_half(wx, 0);
-    FH_PHASE_TAIL("s_waitcnt lgkmcnt(0)")
+    FH_PHASE_TAIL("")
     FH_PHASE_MMA(0, 0)
     // phase 2: (mh0, nh1); next tile's B(nh0); this tile's A(mh1) must have landed for phase 3
     FH_READ_B(1)
     ly.issue_half(wy, 0);
-    FH_PHASE_TAIL("s_waitcnt vmcnt(4) lgkmcnt(0)")
+    FH_PHASE_TAIL("s_waitcnt vmcnt(4)")
     FH_PHASE_MMA(0, 1)
     // phase 3: (mh1, nh1); next tile's B(nh1)
     FH_READ_A(1)
     ly.issue_half(wy, 1);
-    FH_PHASE_TAIL("s_waitcnt lgkmcnt(0)")
+    FH_PHASE_TAIL("")
     FH_PHASE_MMA(1, 1)
     // phase 4: (mh1, nh0); next tile's A(mh1); the next tile's first three quarters must have landed
     FH_READ_B(0)
     lx.issue_half(wx, 1);
-    FH_PHASE_TAIL("s_waitcnt vmcnt(2) lgkmcnt(0)")
+    FH_PHASE_TAIL("s_waitcnt vmcnt(2)")
     FH_PHASE_MMA(1, 0)
   }
 #undef FH_PHASE_TAIL
