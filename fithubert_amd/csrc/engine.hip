@@ -23,6 +23,42 @@ namespace {
 
 inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 
+// ---- merged projection heads (LayerWiseProjHead = ConvTranspose1d(k = s = f) then Linear, module.py:649-661): the two affine
+// maps compose, pred[(t, j)] = (Wlin Wup_j) x_t + (Wlin b_up + b_lin), so the engine runs ONE GEMM per head against weights merged
+// once per optimizer step -- 38 % fewer head FLOPs, no upsampled intermediate -- and maps the merged weights' gradient back onto
+// the reference's parameters with small fp32 GEMMs (chain rule).
+// bm[l][p] = b_lin[l][p] + sum_co Wlin[l][p][co] * b_up[l][co]
+__global__ void head_bias_merge_kernel(const float* __restrict__ params, long head0, long head_stride, long o_lin_w, long o_lin_b,
+                                       long o_up_b, float* __restrict__ bm, int L, int P, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * P) return;
+  const int l = i / P, pp = i - l * P;
+  const float* hp = params + head0 + (long)l * head_stride;
+  float s = hp[o_lin_b + pp];
+  const float* w = hp + o_lin_w + (long)pp * D;
+  for (int co = 0; co < D; ++co) s = fmaf(w[co], hp[o_up_b + co], s);
+  bm[i] = s;
+}
+// dbl[l][p] = this pass's column sums of d_pred.  db_lin += dbl;  db_up[co] += sum_p Wlin[p][co] dbl[p];
+// dWlin[p][co] += dbl[p] * b_up[co]   (the merged bias depends on Wlin too)
+__global__ void head_bias_bwd_kernel(const float* __restrict__ params, float* __restrict__ grads, long head_base, long head_stride,
+                                     long o_lin_w, long o_lin_b, long o_up_b, const float* __restrict__ dbl, int P, int D) {
+  const int l = blockIdx.x;
+  const float* hp = params + head_base + (long)l * head_stride;
+  float* hg = grads + head_base + (long)l * head_stride;
+  const float* d = dbl + (long)l * P;
+  for (int pp = threadIdx.x; pp < P; pp += blockDim.x) hg[o_lin_b + pp] += d[pp];
+  for (int co = threadIdx.x; co < D; co += blockDim.x) {
+    float s = 0.f;
+    for (int pp = 0; pp < P; ++pp) s = fmaf(hp[o_lin_w + (long)pp * D + co], d[pp], s);
+    hg[o_up_b + co] += s;
+  }
+  for (long i = threadIdx.x; i < (long)P * D; i += blockDim.x) {
+    const int pp = (int)(i / D), co = (int)(i - (long)pp * D);
+    hg[o_lin_w + i] += d[pp] * hp[o_up_b + co];
+  }
+}
+
 struct PEntry {
   std::string name;
   long off;
@@ -185,6 +221,8 @@ struct WcLayout {
   long cast_off = 0;      // bf16 copy of the whole flat parameter buffer (bf16 mode only)
   long conv_wf[FH_MAX_CONV];
   long tr_wf = -1, head_wup = -1, head_wup_stride = 0, pos_wf, pos_wb, pos_norm;
+  long head_wm = -1, head_bm = -1, head_wupf = -1;  // merged head weights [L][f*P][D] (compute dtype), merged bias [L][P] fp32,
+                                                    // fp32 copy of the permuted upsampler weights [L][f][D][D]
   long total = 0;
   WcLayout(const fh_student_config& c, const ParamLayout& pl) {
     const int es = c.dtype == 0 ? 4 : 2;
@@ -201,6 +239,12 @@ struct WcLayout {
       tr_wf = o; o += rup(D * D * c.tr_factor * es, 256);
       head_wup = o; head_wup_stride = D * D * c.tr_factor;  // elements
       o += rup(head_wup_stride * c.layers * es, 256);
+      if (c.n_tasks == 0) {
+        head_wm = o; o += rup((long)c.layers * c.tr_factor * c.pred_dim * D * es, 256);
+        head_bm = o; o += rup((long)c.layers * c.pred_dim * 4, 256);
+        if (c.dtype != 0) { head_wupf = o; o += rup(head_wup_stride * c.layers * 4, 256); }
+        else head_wupf = head_wup;
+      }
     }
     const long cp = fh_posconv_cp(c.embed_dim / c.conv_pos_groups);
     const long pw = (long)c.conv_pos_groups * c.conv_pos * cp * cp;
@@ -244,7 +288,7 @@ struct Plan {
   long c0_mean, c0_rstd, c0_scratch;
   long ln0, ln0_mean, ln0_rstd, features, x0, zc, psum, ln1_mean, ln1_rstd, x1;
   long xo, qkv, attn, lse, s1, st1_mean, st1_rstd, xa, z1, hbuf, f2, s2, st2_mean, st2_rstd;
-  long u, pred, hz = -1, hh = -1, dhz = -1, gfeat = -1, cnn_pred = -1, dgf = -1;
+  long u = -1, pred, hz = -1, hh = -1, dhz = -1, gfeat = -1, cnn_pred = -1, dgf = -1, dwm = -1, dbl = -1;
   // backward
   long du, ghead, dxin, ds2, df2, dz1, dx1b, ds1, dao, da, dqkv, delta;
   long dx1tr, dpsum, dzc, dx0, dfeat, dln0, dylast, pos_dws;
@@ -300,8 +344,8 @@ struct Plan {
       if (tr) hz = ws.add("hz", {M2, IN}, es);
       hh = ws.add("hh", {M2, IN}, es);
       if (tr) dhz = ws.add("dhz", {M2, IN}, es);
-    } else {
-      u = ws.add("u", {Lh, B, sh.T2 * sh.f, D}, es);
+    } else if (c.tr_factor == 0) {
+      u = -1;
     }
     pred = ws.add("pred", {Lh, B, sh.T2 * sh.f, P}, es);
     if (c.cnn_head) {
@@ -310,7 +354,11 @@ struct Plan {
       if (tr) dgf = ws.add("dgf", {B, sh.Tp, D}, es);
     }
     if (tr) {
-      du = c.n_tasks > 0 ? -1 : ws.add("du", {Lh, B, sh.T2 * sh.f, D}, es);
+      du = -1;
+      if (c.n_tasks == 0 && c.tr_factor > 0) {  // gradient of the merged head weights / this pass's d_pred column sums
+        dwm = ws.add("dwm", {Lh, (long)sh.f * P, D}, 4);
+        dbl = ws.add("dbl", {Lh, P}, 4);
+      }
       ghead = ws.add("ghead", {L, M2, D}, es);
       dxin = ws.add("dxin", {2, M2, D}, es);
       ds2 = ws.add("ds2", {M2, D}, es);
@@ -424,10 +472,34 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
   if (c.tr_factor > 0) {
     RC(fh_permute3_cast_launch(dt, params + p.pl.tr_w, wc + p.wl.tr_wf, D, D, c.tr_factor, 0, 2, 1, st));
     const int es = dt == 0 ? 4 : 2;
-    for (int l = 0; l < c.layers; ++l)
-      // ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin]
-      RC(fh_permute3_cast_launch(dt, params + p.pl.head0 + l * p.pl.head_stride + p.pl.h_up_w,
-                                 wc + p.wl.head_wup + (long)l * p.wl.head_wup_stride * es, D, D, c.tr_factor, 2, 1, 0, st));
+    if (c.n_tasks == 0) {
+      for (int l = 0; l < c.layers; ++l) {
+        // ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin]
+        RC(fh_permute3_cast_launch(dt, params + p.pl.head0 + l * p.pl.head_stride + p.pl.h_up_w,
+                                   wc + p.wl.head_wup + (long)l * p.wl.head_wup_stride * es, D, D, c.tr_factor, 2, 1, 0, st));
+        if (dt != 0)
+          RC(fh_permute3_cast_launch(0, params + p.pl.head0 + l * p.pl.head_stride + p.pl.h_up_w,
+                                     wc + p.wl.head_wupf + (long)l * p.wl.head_wup_stride * 4, D, D, c.tr_factor, 2, 1, 0, st));
+      }
+      // merged weights Wm[l][j][p][ci] = sum_co Wlin[l][p][co] * Wup[l][ci][co][j]
+      const int P = c.pred_dim, f = c.tr_factor;
+      const unsigned char* nat = dt == 0 ? (const unsigned char*)params : wc + p.wl.cast_off;
+      for (int j = 0; j < f; ++j) {
+        GemmParams g = fh_gemm_params();
+        g.X = fh_operand(nat + (p.pl.head0 + p.pl.h_lin_w) * es, FH_R_CONTIG, D);
+        g.X.gstride = p.pl.head_stride;
+        g.Y = fh_operand(wc + p.wl.head_wup + (long)j * D * D * es, FH_R_STRIDED, D);
+        g.Y.gstride = p.wl.head_wup_stride;
+        g.C = wc + p.wl.head_wm + (long)j * P * D * es;
+        g.M = P; g.N = D; g.Kseg = D; g.ldc = D;
+        g.c_gstride = (long)f * P * D;
+        g.groups = c.layers;
+        RC(fh_gemm_launch(g, dt, st));
+      }
+      hipLaunchKernelGGL(head_bias_merge_kernel, dim3((c.layers * P + 255) / 256), dim3(256), 0, st, params, p.pl.head0,
+                         p.pl.head_stride, p.pl.h_lin_w, p.pl.h_lin_b, p.pl.h_up_b, (float*)(wc + p.wl.head_bm), c.layers, P, D);
+      FH_CHECK_LAUNCH();
+    }
   }
   RC(fh_posconv_prep_launch(dt, params + p.pl.pos_g, params + p.pl.pos_v, wc + p.wl.pos_wf, wc + p.wl.pos_wb,
                             (float*)(wc + p.wl.pos_norm), D, c.conv_pos_groups, c.conv_pos, st));
@@ -613,21 +685,21 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
     const void* lin_in = x.at(p.xo, (long)(l0 + 1) * M2 * D);
     long lin_in_g = M2 * D;
     if (c.tr_factor > 0) {
+      // merged head: pred[l][m][(j, p)] = x[l][m] . Wm[l][(j, p)] + bm[l][p]  -- row m of C holds the f up-sampled frames
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(lin_in, FH_R_CONTIG, D);
       g.X.gstride = M2 * D;
-      g.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wup) + (long)l0 * p.wl.head_wup_stride * p.es, FH_R_CONTIG, D);
-      g.Y.gstride = p.wl.head_wup_stride;
-      g.C = x.W(p.u);
-      g.M = (int)M2; g.N = s.f * D; g.Kseg = D; g.ldc = (long)s.f * D;
-      g.c_gstride = M2 * s.f * D;
+      g.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wm) + (long)l0 * s.f * P * D * p.es, FH_R_CONTIG, D);
+      g.Y.gstride = (long)s.f * P * D;
+      g.C = x.W(p.pred);
+      g.M = (int)M2; g.N = s.f * P; g.Kseg = D; g.ldc = (long)s.f * P;
+      g.c_gstride = M2 * s.f * P;
       g.groups = Lh;
-      g.ep.bias = prm + hp0 + p.pl.h_up_b;
-      g.ep.bias_gstride = p.pl.head_stride;
-      g.ep.bias_mod = D;
+      g.ep.bias = (const float*)x.rel(p.wl.head_bm) + (long)l0 * P;
+      g.ep.bias_gstride = P;
+      g.ep.bias_mod = P;
       RC(fh_gemm_launch(g, dt, x.st));
-      lin_in = x.W(p.u);
-      lin_in_g = M2 * s.f * D;
+      return 0;
     }
     GemmParams g = fh_gemm_params();
     g.X = fh_operand(lin_in, FH_R_CONTIG, D);
@@ -710,31 +782,66 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
   } else if (d_pred) {
     const void* dlin_in;  // gradient w.r.t. the Linear's input
     if (c.tr_factor > 0) {
-      GemmParams g = fh_gemm_params();
-      g.X = fh_operand(d_pred, FH_R_CONTIG, P);
-      g.X.gstride = M2 * s.f * P;
-      g.Y = fh_operand(x.nat(hp0 + p.pl.h_lin_w), FH_R_STRIDED, D);
-      g.Y.gstride = p.pl.head_stride;
-      g.C = x.W(p.du);
-      g.M = (int)(M2 * s.f); g.N = D; g.Kseg = P; g.ldc = D;
-      g.c_gstride = M2 * s.f * D;
-      g.groups = Lh;
-      RC(fh_gemm_launch(g, dt, x.st));
-      dlin_in = x.W(p.du);
-      // ghead[l] = du[l] (as [M2][f*D]) . Wup'  (+ d_hidden)
-      GemmParams g2 = fh_gemm_params();
-      g2.X = fh_operand(x.W(p.du), FH_R_CONTIG, (long)s.f * D);
-      g2.X.gstride = M2 * s.f * D;
-      g2.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wup) + (long)l0 * p.wl.head_wup_stride * p.es, FH_R_STRIDED, D);
-      g2.Y.gstride = p.wl.head_wup_stride;
-      g2.C = x.at(p.ghead, (long)l0 * M2 * D);
-      g2.M = (int)M2; g2.N = D; g2.Kseg = s.f * D; g2.ldc = D;
-      g2.c_gstride = M2 * D;
-      g2.groups = Lh;
-      if (d_hidden) {
-        g2.ep.residual = (const unsigned char*)d_hidden + (long)l0 * M2 * D * p.es;
+      const long fP = (long)s.f * P;
+      const unsigned char* wm = (const unsigned char*)x.rel(p.wl.head_wm) + (long)l0 * fP * D * p.es;
+      {  // ghead[l] = d_pred[l] (as [M2][f*P]) . Wm[l]  (+ d_hidden)
+        GemmParams g = fh_gemm_params();
+        g.X = fh_operand(d_pred, FH_R_CONTIG, fP);
+        g.X.gstride = M2 * fP;
+        g.Y = fh_operand(wm, FH_R_STRIDED, D);
+        g.Y.gstride = fP * D;
+        g.C = x.at(p.ghead, (long)l0 * M2 * D);
+        g.M = (int)M2; g.N = D; g.Kseg = (int)fP; g.ldc = D;
+        g.c_gstride = M2 * D;
+        g.groups = Lh;
+        if (d_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)l0 * M2 * D * p.es;
+        RC(fh_gemm_launch(g, dt, x.st));
       }
-      RC(fh_gemm_launch(g2, dt, x.st));
+      // dWm[l][(j, p)][ci] = sum_m d_pred[l][m][(j, p)] * x[l][m][ci]   (fp32 scratch), this pass's column sums of d_pred
+      RC((int)hipMemsetAsync(x.W(p.dwm), 0, (long)Lh * fP * D * 4, x.st));
+      RC((int)hipMemsetAsync(x.W(p.dbl), 0, (long)Lh * P * 4, x.st));
+      {
+        GemmOperand A = fh_operand(x.at(p.xo, (long)(l0 + 1) * M2 * D), FH_R_STRIDED, D);
+        A.gstride = M2 * D;
+        RC(wgrad(x, d_pred, fP, A, x.W<float>(p.dwm), (int)fP, D, M2, Lh, M2 * fP, fP * D));
+        RC(fh_colsum_launch(dt, d_pred, x.W<float>(p.dbl), (int)(M2 * s.f), P, P, Lh, M2 * fP, P, 0, 1.f, x.st));
+      }
+      // chain rule onto the reference's parameters (fp32 GEMMs on the fp32 masters, accumulate into the gradient buffer)
+      const float* wupf = (const float*)x.rel(p.wl.head_wupf) + (long)l0 * p.wl.head_wup_stride;
+      for (int j = 0; j < s.f; ++j) {
+        {  // dWlin[p][co] += sum_ci dWm[j][p][ci] * Wup[ci][co][j]
+          GemmParams g = fh_gemm_params();
+          g.X = fh_operand(x.W<float>(p.dwm) + (long)j * P * D, FH_R_CONTIG, D);
+          g.X.gstride = fP * D;
+          g.Y = fh_operand(wupf + (long)j * D * D, FH_R_CONTIG, D);
+          g.Y.gstride = p.wl.head_wup_stride;
+          g.C = grads + hp0 + p.pl.h_lin_w;
+          g.M = P; g.N = D; g.Kseg = D; g.ldc = D;
+          g.c_gstride = p.pl.head_stride;
+          g.groups = Lh;
+          g.ep.atomic = 1;
+          RC(fh_gemm_launch(g, 0, x.st));
+        }
+        {  // dWup[ci][co][j] += sum_p dWm[j][p][ci] * Wlin[p][co]
+          GemmParams g = fh_gemm_params();
+          g.X = fh_operand(x.W<float>(p.dwm) + (long)j * P * D, FH_R_STRIDED, D);
+          g.X.gstride = fP * D;
+          g.Y = fh_operand(x.params + hp0 + p.pl.h_lin_w, FH_R_STRIDED, D);
+          g.Y.gstride = p.pl.head_stride;
+          g.C = grads + hp0 + p.pl.h_up_w + j;
+          g.M = D; g.N = D; g.Kseg = P; g.ldc = (long)D * s.f;
+          g.c_gstride = p.pl.head_stride;
+          g.groups = Lh;
+          g.ep.atomic = 1;
+          g.ep.idiv = 1; g.ep.si1 = (long)D * s.f; g.ep.si0 = 0;
+          g.ep.jdiv = 1; g.ep.sj1 = s.f; g.ep.sj0 = 0;
+          RC(fh_gemm_launch(g, 0, x.st));
+        }
+      }
+      hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(Lh), dim3(256), 0, x.st, x.params, grads, hp0, p.pl.head_stride, p.pl.h_lin_w,
+                         p.pl.h_lin_b, p.pl.h_up_b, (const float*)x.W<float>(p.dbl), P, D);
+      FH_CHECK_LAUNCH();
+      dlin_in = nullptr;
     } else {
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(d_pred, FH_R_CONTIG, P);
@@ -751,23 +858,12 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     }
     (void)dlin_in;
     have_ghead = true;
-    // weight grads of the heads
-    const void* lin_x = c.tr_factor > 0 ? (const void*)x.W(p.u) : (const void*)x.at(p.xo, (long)(l0 + 1) * M2 * D);
-    const long lin_x_g = c.tr_factor > 0 ? M2 * s.f * D : M2 * D;
-    {
-      GemmOperand A = fh_operand(lin_x, FH_R_STRIDED, D);
-      A.gstride = lin_x_g;
-      RC(wgrad(x, d_pred, P, A, grads + hp0 + p.pl.h_lin_w, P, D, M2 * s.f, Lh, M2 * s.f * P, p.pl.head_stride));
-      RC(fh_colsum_launch(dt, d_pred, grads + hp0 + p.pl.h_lin_b, (int)(M2 * s.f), P, P, Lh, M2 * s.f * P, p.pl.head_stride, 0, 1.f, x.st));
-    }
-    if (c.tr_factor > 0) {
-      // dWup[ci][co][j] += sum_m du[m][j*D+co] * xo[m][ci] :  i = j*D+co, column = ci
+    // weight grads of the heads (Linear only; the time-reduced recipe handled them through the merged weights above)
+    if (c.tr_factor == 0) {
       GemmOperand A = fh_operand(x.at(p.xo, (long)(l0 + 1) * M2 * D), FH_R_STRIDED, D);
       A.gstride = M2 * D;
-      RC(wgrad(x, x.W(p.du), (long)s.f * D, A, grads + hp0 + p.pl.h_up_w, s.f * D, D, M2, Lh, M2 * s.f * D, p.pl.head_stride,
-               /*jdiv*/ 1, /*sj1*/ (long)D * s.f, /*sj0*/ 0, /*idiv*/ D, /*si1*/ 1, /*si0*/ s.f));
-      RC(fh_colsum_launch(dt, x.W(p.du), grads + hp0 + p.pl.h_up_b, (int)M2, s.f * D, (long)s.f * D, Lh, M2 * s.f * D,
-                          p.pl.head_stride, D, 1.f, x.st));
+      RC(wgrad(x, d_pred, P, A, grads + hp0 + p.pl.h_lin_w, P, D, M2, Lh, M2 * P, p.pl.head_stride));
+      RC(fh_colsum_launch(dt, d_pred, grads + hp0 + p.pl.h_lin_b, (int)M2, P, P, Lh, M2 * P, p.pl.head_stride, 0, 1.f, x.st));
     }
   }
 

@@ -12,13 +12,13 @@ for i in range(2):
     e = StudentEngine(CustomStudentModelConfig(**cfg), dtype="bf16"); e.load_state_dict(sd); engs.append(e)
 wav = 0.1 * torch.randn(2, 16000, device="cuda")
 wav[1, 12000:] = 0
-names = ["y0", "y1", "y4", "y8", "ln0", "features", "x0", "zc", "psum", "x1", "xo", "qkv", "attn", "s1", "xa", "h", "f2", "s2", "u", "pred"]
+names = ["y0", "y1", "y4", "y8", "ln0", "features", "x0", "zc", "psum", "x1", "xo", "qkv", "attn", "s1", "xa", "h", "f2", "s2", "pred"]
 ref = None
 bad = 0
 for it in range(40):
     e = engs[it % 2]
     ws = e.forward(wav, [16000, 12000], training=False, heads_on=bool(it % 3))
-    cur = {n: ws.view(n).clone() for n in names if n not in ("u", "pred")}
+    cur = {n: ws.view(n).clone() for n in names if n not in ("pred",)}
     cur["pred_last"] = ws.view("pred")[-1].clone()
     torch.cuda.synchronize()
     if ref is None:
