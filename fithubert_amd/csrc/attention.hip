@@ -540,10 +540,6 @@ int check_dims(int dtype, int H, int dh, int dh_max = 64) {
   return 0;
 }
 
-template <typename T> int resident_tiles_unused();
-}  // namespace
-
-namespace {
 template <typename T> int resident_tiles(int n) {  // 0 = tiled path
   static int mode = -1;  // FH_ATTN_RESIDENT=0 forces the tiled path (A/B comparisons)
   if (mode < 0) {
