@@ -338,7 +338,9 @@ class TeacherModel(nn.Module):
             if self._native is None:
                 self._native = _NativeFrontend(self)
             native = self._native
-            key = tuple(source.shape)
+            S_ = int(source.shape[1])
+            lg = max(S_, 1).bit_length() - 1
+            key = (int(source.shape[0]), lg * 4 + (((S_ - (1 << lg)) * 4) >> lg))   # (batch, quarter-octave class of the length)
             if key not in native._tuned and dt == torch.bfloat16 and os.environ.get("FH_GEMM_AUTOTUNE", "1") != "0":
                 # first forward of this shape: the HIP GEMMs (conv layers, fc1) measure their main-loop candidates.  Their
                 # outputs are overwritten, not accumulated, so measuring inside a real forward is harmless; it blocks once.
