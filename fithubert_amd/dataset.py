@@ -5,13 +5,17 @@ consecutive chunks of ``batch_size`` (a trailing chunk is kept only if it has mo
 then shuffles whole buckets (train.py:423-428) and Lightning's DistributedSampler deals them out rank-strided.
 A batch is ``{'x': zero-padded B x S_max fp32, 'padding_mask': B x S_max bool (True = pad)}`` (dataset.py:63-74).
 
-FLAC decoding is out of scope (the metric is on synthetic audio): ``SyntheticLibriDataset`` draws utterance lengths
-(from a length table, or fixed) and fills them with seeded Gaussian noise of speech-like RMS.
+``LibriDataset`` is the reference's real-data dataset (CSV length tables + audio files under ``libri_root``); decoding uses
+``soundfile`` or ``torchaudio`` when one is installed and the standard library for 16-bit PCM ``.wav``.  The benchmark metric is
+on synthetic audio: ``SyntheticLibriDataset`` draws utterance lengths (from a length table, or fixed) and fills them with
+seeded Gaussian noise of speech-like RMS.
 """
 from __future__ import annotations
 
+import csv
+import os
 import random
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -96,3 +100,73 @@ def draw_lengths(table: np.ndarray, n: int, seed: int = 0) -> List[int]:
     """n utterance lengths drawn (with replacement, seeded) from an empirical length table."""
     rng = np.random.RandomState(seed)
     return [int(v) for v in rng.choice(table, size=n, replace=True)]
+
+
+# ------------------------------------------------------------------ real data (reference utils/dataset.py:11-74)
+def read_length_tables(file_path: str, sets: Sequence[str]) -> List[Tuple[str, int]]:
+    """utils/dataset.py:27-31: concatenate ``<file_path>/<set>.csv`` (columns ``,file_path,length,label``) and sort by
+    length descending.  -> [(relative audio path, samples)]."""
+    rows: List[Tuple[str, int]] = []
+    for s in sets:
+        with open(os.path.join(file_path, s + ".csv"), newline="") as f:
+            for r in csv.DictReader(f):
+                rows.append((r["file_path"], int(r["length"])))
+    rows.sort(key=lambda t: -t[1])
+    return rows
+
+
+def load_audio(path: str) -> torch.Tensor:
+    """1-D float32 waveform in [-1, 1) (what ``torchaudio.load(...)[0].squeeze()`` yields, utils/dataset.py:59-61)."""
+    try:
+        import soundfile as sf  # type: ignore
+        data, _ = sf.read(path, dtype="float32", always_2d=False)
+        return torch.from_numpy(np.asarray(data, dtype=np.float32)).reshape(-1) if data.ndim == 1 else torch.from_numpy(data[:, 0].copy())
+    except ImportError:
+        pass
+    try:
+        import torchaudio  # type: ignore
+        wav, _ = torchaudio.load(path)
+        return wav.squeeze().float()
+    except ImportError:
+        pass
+    if path.lower().endswith(".wav"):
+        import wave
+        with wave.open(path, "rb") as w:
+            if w.getsampwidth() != 2:
+                raise RuntimeError(f"{path}: only 16-bit PCM wav is decoded without soundfile / torchaudio")
+            raw = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+            if w.getnchannels() > 1:
+                raw = raw.reshape(-1, w.getnchannels())[:, 0]
+        return torch.from_numpy(raw.copy())
+    raise RuntimeError(f"{path}: decoding needs the 'soundfile' or 'torchaudio' package (neither is installed)")
+
+
+class LibriDataset:
+    """Librispeech waveform dataset for distillation: the reference's class (utils/dataset.py:11-74), same constructor,
+    ``__getitem__`` returning one whole bucket ``{'x', 'padding_mask'}`` and the pass-through ``collate_fn``."""
+
+    def __init__(self, batch_size: int, file_path: str = "./data/len_for_bucket", sets: Sequence[str] = ("train-clean-100",),
+                 libri_root: str = "../db/LibriSpeech"):
+        self.libri_root = libri_root
+        self.root = file_path
+        table = read_length_tables(file_path, sets)
+        self.num_samples = len(table)
+        names = [t[0] for t in table]
+        self.lengths = [t[1] for t in table]
+        self.X = [[names[i] for i in b] for b in bucket_by_length(self.lengths, batch_size)]
+        self._bucket_samples = [max(self.lengths[i] for i in b) * len(b) for b in bucket_by_length(self.lengths, batch_size)]
+
+    def collate_fn(self, items):
+        return items[0]
+
+    def bucket_samples(self) -> List[int]:
+        return list(self._bucket_samples)
+
+    def _load_feat(self, feat_path: str) -> torch.Tensor:
+        return load_audio(os.path.join(self.libri_root, feat_path))
+
+    def __getitem__(self, index: int) -> Dict[str, torch.Tensor]:
+        return collate([self._load_feat(x) for x in self.X[index]])
+
+    def __len__(self):
+        return len(self.X)

@@ -17,7 +17,7 @@ from __future__ import annotations
 import math
 import os
 import random
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
@@ -310,6 +310,86 @@ class W2V2Distil:
         self._micro = 0
         self.student_model.mark_params_updated()
         self.student_model._flat_version = self.student_model.flat._version
+
+    # ------------------------------------------------------------------ validation / epoch loop (train.py:179-199, 475-501)
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx: int = 0) -> Dict[str, torch.Tensor]:
+        """train.py:179-199: the loss on a held-out bucket, dropout off; with random-layer distillation the monitored value is
+        the LAST layer's loss (train.py:194-195)."""
+        x, pm = batch["x"], batch.get("padding_mask")
+        lengths = None
+        if pm is not None and bool(pm.any()):
+            lengths = (~pm).sum(-1).tolist()
+        hid = self.teacher_hiddens(batch)
+        ws = self.engine.forward(x, lengths, training=False, heads_on=self.student_model._heads_on)
+        if self._rows_loss:
+            out, _ = self.engine.kd_loss_rows(ws, hid, self.layer_w, self.teacher_layer, loss_type=0 if self.rec_loss_type == "mse" else 1,
+                                              rec_weight=float(self.rec_loss_weight), sim_weight=float(self.sim_loss_weight), want_grad=False)
+            total = out[-1]
+        else:
+            out, _ = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer, loss_type=0 if self.rec_loss_type == "mse" else 1,
+                                         want_grad=False)
+            total = float(self.rec_loss_weight) * out[-1]
+        if self.train_cfg["distil_random_layer"] > 0:
+            total = out[self.num_encoders - 1]
+        return {"v_loss": total}
+
+    def fit(self, train_data, eval_data=None, num_epochs: Optional[int] = None, output_dir: Optional[str] = None, patience: int = 15,
+            save_top_k: int = 3, rank: int = 0, world: int = 1, log=None) -> Dict[str, object]:
+        """The reference's Trainer configuration in one loop (train.py:475-501): shuffled length buckets dealt out rank-strided,
+        gradient accumulation, ``training_epoch_end`` re-sampling, validation ``v_loss`` per epoch, ModelCheckpoint(save_last,
+        save_top_k=3, monitor v_loss) and EarlyStopping(patience 15).  Datasets index whole buckets (``LibriDataset`` /
+        ``SyntheticLibriDataset``)."""
+        import os as _os
+        from .dataset import rank_buckets
+        num_epochs = int(num_epochs if num_epochs is not None else self.train_cfg["num_epochs"])
+        steps_per_epoch = max(1, len(train_data) // max(1, world)) // max(1, self.accumulate)
+        if not self.num_training_steps:
+            self.configure_optimizers(max(1, steps_per_epoch * num_epochs))
+        to_dev = lambda b: {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+        best: List[tuple] = []
+        history, bad_epochs, best_v = [], 0, float("inf")
+        for epoch in range(num_epochs):
+            order = rank_buckets(len(train_data), epoch, rank, world, seed=0, shuffle=True)
+            nxt = to_dev(train_data[order[0]])
+            tl = None
+            for i, _ in enumerate(order):
+                cur = nxt
+                nxt = to_dev(train_data[order[i + 1]]) if i + 1 < len(order) else None
+                tl = self.training_step(cur, batch_idx=i, next_batch=nxt)
+            self.training_epoch_end()
+            rec = {"epoch": epoch, "train_loss": float(tl[-1].item()) if tl is not None else float("nan")}
+            if eval_data is not None and len(eval_data) > 0:
+                vs = [self.validation_step(to_dev(eval_data[j]), j)["v_loss"] for j in range(rank, len(eval_data), max(1, world))]
+                v = torch.stack([t.double() for t in vs]).mean()
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+                    v = v / world
+                rec["v_loss"] = float(v.item())
+                if output_dir and rank == 0:
+                    _os.makedirs(output_dir, exist_ok=True)
+                    path = _os.path.join(output_dir, f"checkpoint-epoch={epoch:02d}.ckpt")
+                    self.save_checkpoint(path, epoch=epoch)
+                    best.append((rec["v_loss"], path))
+                    best.sort()
+                    for _, old in best[save_top_k:]:
+                        if _os.path.exists(old):
+                            _os.remove(old)
+                    best = best[:save_top_k]
+                if rec["v_loss"] < best_v - 0.0:
+                    best_v, bad_epochs = rec["v_loss"], 0
+                else:
+                    bad_epochs += 1
+            if output_dir and rank == 0:
+                _os.makedirs(output_dir, exist_ok=True)
+                self.save_checkpoint(_os.path.join(output_dir, "last.ckpt"), epoch=epoch)
+            history.append(rec)
+            if log:
+                log(rec)
+            if bad_epochs >= patience:
+                break
+        return {"history": history, "best": best, "stopped_early": bad_epochs >= patience}
 
     # ------------------------------------------------------------------ checkpoints (train.py:475-483 key convention)
     def state_dict(self) -> Dict[str, torch.Tensor]:

@@ -338,3 +338,33 @@ def test_attention_and_value_relation_transfer(attn_type):
     task.configure_optimizers(num_training_steps=10)
     out = task.training_step(b, batch_idx=0)
     assert abs(out[-1].item() - lo.item()) < 2e-3 * abs(lo.item()), (out[-1].item(), lo.item())
+
+
+def test_fit_loop_validation_checkpoints_and_early_stopping(tmp_path):
+    """train.py:179-199 + 475-501: epochs over shuffled buckets, v_loss per epoch (last layer's loss with random-layer
+    distillation), top-k + last checkpoints in the Lightning key convention, early stopping."""
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+
+    y = yaml.safe_load(open(os.path.join(ROOT, "conf", "fithubert.yaml")))
+    y["distiller"].update(encoder_layers=2)
+    y["train"].update(distil_random_layer=1, accumulate_grad_batches=1, num_epochs=4)
+    y["optimizer"]["lr"] = 1e-3
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 2
+    task = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=tc, seed=0, teacher_native_frontend=True)
+    train = SyntheticLibriDataset([16000, 15000, 14000, 12000, 11000, 9000], batch_size=2, seed=1)
+    held = SyntheticLibriDataset([13000, 10000], batch_size=2, seed=2)
+    v0 = task.validation_step({k: v.to(DEV) for k, v in held[0].items()})["v_loss"].item()
+    res = task.fit(train, held, num_epochs=4, output_dir=str(tmp_path), patience=15, save_top_k=2)
+    hist = res["history"]
+    assert len(hist) == 4 and all("v_loss" in h for h in hist)
+    assert hist[-1]["v_loss"] < v0                       # it learns the held-out bucket's teacher a little
+    files = sorted(os.listdir(tmp_path))
+    assert "last.ckpt" in files and len([f for f in files if f.startswith("checkpoint-epoch=")]) == 2   # save_top_k
+    ck = torch.load(os.path.join(tmp_path, "last.ckpt"), map_location="cpu", weights_only=False)
+    assert any(k.startswith("student_model.encoder.layers.1.") for k in ck["state_dict"]) and ck["epoch"] == 3
+    # early stopping: patience 0 stops as soon as v_loss fails to improve
+    res2 = task.fit(train, held, num_epochs=50, output_dir=None, patience=1)
+    assert res2["stopped_early"] and len(res2["history"]) < 50
