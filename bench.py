@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "float32"])
     ap.add_argument("--config", default=os.path.join(ROOT, "conf", "fithubert.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=0, help="variant: student encoder_layers (default: the yaml's 12; BASELINE.json "
+                    "words configs[1] as '24-layer' -- with more student layers than teacher layers the reference's random-layer loss "
+                    "indexes the teacher out of range, so use it with --teacher large; SURVEY 0.1)")
+    ap.add_argument("--teacher", default="base", choices=["base", "large"], help="variant: HuBERT-Large-shaped teacher (24 x 1024)")
     ap.add_argument("--teacher-frontend", default="native", choices=["native", "torch"],
                     help="frozen teacher's conv frontend + positional conv: the student's HIP kernels (native) or stock "
                          "PyTorch-ROCm ops (torch); its transformer layers always run on PyTorch-ROCm")
@@ -107,7 +111,17 @@ def main():
     with open(args.config) as f:
         cfg = yaml.load(f, Loader=yaml.FullLoader)
     cfg["train"]["accumulate_grad_batches"] = 1  # one optimizer step (and one all-reduce) per timed step
-    task = W2V2Distil(cfg, dtype=args.dtype, device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native")
+    variant = args.layers > 0 or args.teacher != "base"
+    teacher_cfg = None
+    if args.layers > 0:
+        cfg["distiller"]["encoder_layers"] = args.layers
+        cfg["train"]["distil_random_layer"] = args.layers - 1   # all but the last, as the yaml's 11 of 12
+    if args.teacher == "large":
+        from fithubert_amd.teacher import TeacherConfig
+        teacher_cfg = TeacherConfig.large()
+        cfg["distiller"]["pred_head_final_dim"] = 1024
+    task = W2V2Distil(cfg, dtype=args.dtype, device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native",
+                      teacher_cfg=teacher_cfg)
     total_steps = args.steps + args.warmup
     task.configure_optimizers(num_training_steps=max(total_steps, 100))
 
@@ -212,14 +226,16 @@ def main():
             "value": round(value, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "fithubert.yaml student (480-dim, 12 layers) + HuBERT-Base-shaped teacher (random init), "
-                                   "full distillation step on fixed 10 s clips (BASELINE.json configs[1])",
+            "config": {"workload": ("fithubert.yaml student (480-dim, 12 layers) + HuBERT-Base-shaped teacher (random init), "
+                                    "full distillation step on fixed 10 s clips (BASELINE.json configs[1])") if not variant else
+                                   ("VARIANT: fithubert.yaml student with %d layers + HuBERT-%s-shaped teacher (random init), fixed 10 s clips"
+                                    % (cfg["distiller"]["encoder_layers"], "Large" if args.teacher == "large" else "Base")),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": SAMPLES_10S, "parallelism": f"dp{world}",
                        "teacher": "bf16; " + ("conv frontend, pos-conv, attention, add+LayerNorm: HIP kernels shared with the student; "
                                               "q|k|v / out-proj / fc1 / fc2 GEMMs: hipBLASLt via PyTorch-ROCm" if args.teacher_frontend == "native"
                                               else "stock PyTorch-ROCm (MIOpen convs, hipBLASLt, SDPA)"), "optimizer": "fused AdamW every step"},
-            "step_tflops": round(value * GF_STEP / 1e3, 1),
-            "step_frac_of_mfma_peak": round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
+            "step_tflops": None if variant else round(value * GF_STEP / 1e3, 1),
+            "step_frac_of_mfma_peak": None if variant else round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
             "final_loss": loss,
             "roofline": roof,
         }

@@ -40,6 +40,10 @@ int fh_add_layernorm_forward(int dtype, const void* x, const void* res, const fl
                              int M, int C, float eps, fh_stream_t stream) {
   return fh_add_layernorm_fwd_launch(dtype, x, res, gamma, beta, y, M, C, eps, ST(stream));
 }
+int fh_layernorm_gelu_forward(int dtype, const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps,
+                              fh_stream_t stream) {
+  return fh_add_layernorm_fwd_launch(dtype, x, nullptr, gamma, beta, y, M, C, eps, ST(stream), 1);
+}
 int fh_layernorm_backward(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                           const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
                           int M, int C, fh_drop out_drop, fh_drop in_drop, fh_stream_t stream) {

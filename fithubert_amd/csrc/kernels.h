@@ -17,7 +17,7 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
 int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                             float* rstd, int M, int C, float eps, fh_drop drop, hipStream_t st);
 int fh_add_layernorm_fwd_launch(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
-                                int M, int C, float eps, hipStream_t st);
+                                int M, int C, float eps, hipStream_t st, int gelu = 0);
 int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                             const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
                             int M, int C, fh_drop out_drop, fh_drop in_drop, hipStream_t st);

@@ -18,7 +18,7 @@ template <typename T, int NCH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
-                                                     int C, float eps, DropCfg drop, const T* __restrict__ res) {
+                                                     int C, float eps, DropCfg drop, const T* __restrict__ res, int gelu) {
   // res != nullptr: normalises T(x + res) -- the post-LN residual add of the frozen teacher's layers, rounded to the
   // storage type first so that the result equals the unfused add-then-LayerNorm
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -105,6 +105,10 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
         float o[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = fmaf((v[rr][u][e] - mean[rr]) * rstd[rr], gm[u][e], bt[u][e]);
+        if (gelu) {  // conv -> LayerNorm -> GELU blocks of a layer_norm-mode feature extractor (HuBERT Large)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = gelu_f(o[e]);
+        }
         if (drop.p > 0.f) drop_scale_vec<VEC>(drop, (unsigned long long)row * C + ch * VEC, o);
         st16(y + (long)row * C + ch * VEC, pack16<T>(o));
       }
@@ -266,17 +270,17 @@ __global__ void zero_rows_kernel(T* x, int B, int Tn, int C, int from) {
 
 template <typename T>
 int ln_fwd_t(const T* x, const float* g, const float* b, T* y, float* mean, float* rstd, int M, int C, float eps,
-             DropCfg drop, hipStream_t st, const T* res = nullptr) {
+             DropCfg drop, hipStream_t st, const T* res = nullptr, int gelu = 0) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return -301;
   const int nch = (C / VEC + 63) / 64;
   dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
   if (nch == 1)
-    hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res);
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res, gelu);
   else if (nch == 2)
-    hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res);
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res, gelu);
   else if (nch <= 4)
-    hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res);
+    hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, g, b, y, mean, rstd, M, C, eps, drop, res, gelu);
   else
     return -302;
   FH_CHECK_LAUNCH();
@@ -318,11 +322,11 @@ int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const 
 }
 
 int fh_add_layernorm_fwd_launch(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
-                                int M, int C, float eps, hipStream_t st) {
+                                int M, int C, float eps, hipStream_t st, int gelu) {
   if (M <= 0) return 0;
   fh_drop nodrop{0.f, 0u, 0u};
-  return dtype == 0 ? ln_fwd_t<float>((const float*)x, gamma, beta, (float*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const float*)res)
-                    : ln_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const bf16*)res);
+  return dtype == 0 ? ln_fwd_t<float>((const float*)x, gamma, beta, (float*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const float*)res, gelu)
+                    : ln_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const bf16*)res, gelu);
 }
 
 int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,

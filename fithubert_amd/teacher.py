@@ -171,6 +171,7 @@ class _NativeFrontend:
         self.spec = fe.spec
         self.mode = fe.mode
         self._tuned = set()
+        self._f32_cache = {}
         self.layers = []
         for i, (dim, k, s) in enumerate(self.spec):
             conv = getattr(fe.conv_layers[i], "0")
@@ -198,8 +199,8 @@ class _NativeFrontend:
         enc = model.encoder
         self.heads = model.cfg.encoder_attention_heads
         self.dh = D // self.heads
-        self.layers_native = (not model.cfg.layer_norm_first) and (self.tdt == torch.bfloat16 and self.dh <= 64 or self.dh <= 48) \
-            and self.dh % 8 == 0
+        self.pre_ln = bool(model.cfg.layer_norm_first)
+        self.layers_native = self.dh <= 64 and self.dh % 8 == 0   # head widths the attention kernel is built for
         # fc1 + GELU: hipBLASLt GEMM + PyTorch GELU kernel measured 0.9 ms / forward faster (B = 128) than the HIP GEMM with the
         # GELU epilogue on this K = 768, N = 3072 shape; FH_TEACHER_FC1=native selects the fused kernel
         self.fc1_native = os.environ.get("FH_TEACHER_FC1", "torch") == "native"
@@ -220,13 +221,53 @@ class _NativeFrontend:
     def _st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
+    def _f32(self, p):
+        """fp32 contiguous copy of a (frozen) parameter, cached"""
+        c = self._f32_cache.get(id(p))
+        if c is None:
+            c = p.detach().float().contiguous()
+            self._f32_cache[id(p)] = c
+        return c
+
     def add_ln(self, x, res, gamma, beta, out):
         M, C = x.numel() // x.shape[-1], x.shape[-1]
         self.L.check(self.lib.fh_add_layernorm_forward(self.dt, x.data_ptr(), res.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                        out.data_ptr(), M, C, 1e-5, self._st()), "fh_add_layernorm_forward")
         return out
 
+    def ln(self, x, gamma, beta, out=None, gelu: bool = False):
+        """LayerNorm (optionally followed by GELU) over the last dim on the HIP kernel."""
+        x = x.contiguous()
+        out = torch.empty_like(x) if out is None else out
+        M, C = x.numel() // x.shape[-1], x.shape[-1]
+        if gelu:
+            self.L.check(self.lib.fh_layernorm_gelu_forward(self.dt, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                                            M, C, 1e-5, self._st()), "fh_layernorm_gelu_forward")
+        else:
+            self.L.check(self.lib.fh_layernorm_forward(self.dt, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), None,
+                                                       None, M, C, 1e-5, self.L.Drop(0.0, 0, 0), self._st()), "fh_layernorm_forward")
+        return out
+
+    def layer_pre_ln(self, i: int, x: torch.Tensor, key_len, out: torch.Tensor):
+        """One pre-LN layer (layer_norm_first=True, HuBERT Large): x += attn(LN(x)); x += ffn(LN(x)); the layer output (what the
+        reference's forward hook captures, utils/utils.py:74-78) is the residual stream."""
+        L, lib, w = self.L, self.lib, self.tl[i]
+        B, T, D = x.shape
+        h = self.ln(x, w["g1"], w["b1"])
+        qkv = F.linear(h, w["wqkv"], w["bqkv"])
+        attn = torch.empty(B, T, D, device=self.dev, dtype=self.tdt)
+        L.check(lib.fh_attention_forward(self.dt, qkv.data_ptr(), attn.data_ptr(), None, key_len.data_ptr() if key_len is not None else None,
+                                         B, T, self.heads, self.dh, float(self.dh) ** -0.5, L.Drop(0.0, 0, 0), self._st()),
+                "fh_attention_forward")
+        x1 = x + F.linear(attn, w["wo"], w["bo"])
+        h2 = self.ln(x1, w["g2"], w["b2"])
+        lr = F.linear(F.gelu(F.linear(h2, w["w1"], w["c1t"])), w["w2"], w["c2"])
+        torch.add(x1, lr, out=out)
+        return out, lr
+
     def layer(self, i: int, x: torch.Tensor, key_len, out: torch.Tensor):
+        if self.pre_ln:
+            return self.layer_pre_ln(i, x, key_len, out)
         """One post-LN transformer layer (fairseq TransformerSentenceEncoderLayer, layer_norm_first=False) -> (out, fc2 out).
         q|k|v / out_proj / fc2 are plain library GEMMs (hipBLASLt via F.linear); attention, both residual-add + LayerNorm
         pairs and fc1 + bias + GELU are HIP kernels.  ``key_len``: int32 [B] valid frames (right-padded batch) or None."""
@@ -268,7 +309,7 @@ class _NativeFrontend:
         else:  # layer_norm mode: conv (Cin = 1) -> LayerNorm over channels -> GELU (HuBERT-Large)
             y = F.linear(wav.to(self.tdt).unfold(1, k0, s0), self.w0.to(self.tdt), None if self.b0 is None else self.b0.to(self.tdt))
             ln = getattr(model.feature_extractor.conv_layers[0], "2")[1]
-            y = F.gelu(ln(y))
+            y = self.ln(y, self._f32(ln.weight), self._f32(ln.bias), gelu=True)
         for i, (dim, k, s) in enumerate(self.spec[1:], start=1):
             wf, b = self.layers[i - 1]
             Tn = (T - k) // s + 1
@@ -278,7 +319,7 @@ class _NativeFrontend:
                                           self._st()), "fh_conv1d_forward")
             if self.mode != "default":
                 ln = getattr(model.feature_extractor.conv_layers[i], "2")[1]
-                out = F.gelu(ln(out))
+                out = self.ln(out, self._f32(ln.weight), self._f32(ln.bias), out=out, gelu=True)
             y, T = out, Tn
         return y
 

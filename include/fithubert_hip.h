@@ -125,6 +125,10 @@ int fh_layernorm_forward(int dtype, const void* x, const float* gamma, const flo
  * TransformerSentenceEncoderLayer, layer_norm_first = False; reference teacher via utils/utils.py:51-99).  Forward only. */
 int fh_add_layernorm_forward(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                              int M, int C, float eps, fh_stream_t stream);
+/* y = gelu(LayerNorm(x)): the conv -> LayerNorm -> GELU block of a layer_norm-mode feature extractor (HuBERT-Large teacher;
+ * fairseq ConvFeatureExtractionModel, mode 'layer_norm').  Forward only. */
+int fh_layernorm_gelu_forward(int dtype, const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps,
+                              fh_stream_t stream);
 int fh_layernorm_backward(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                           const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
                           int M, int C, fh_drop out_drop, fh_drop in_drop, fh_stream_t stream);
