@@ -334,3 +334,52 @@ def test_single_task_head_is_a_plain_linear(golden_dir):
         rg = sdg[k].grad
         if rg is not None and rg.norm().item() > 1e-6:
             assert _rel_l2(gv.float(), rg) < 2e-3, k
+
+
+def test_full_size_properties_10s():
+    """BASELINE.json's full utterance size (10 s, 160000 samples) through size-independent properties, bf16:
+    batch-permutation equivariance (bitwise: a row's reduction order does not depend on its position), independence of an
+    utterance from its batch neighbours (bitwise, padded or not), and additivity of the gradient over the batch."""
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    eng, _ = _engine(cfg, 5, "bf16")
+    S = 160000
+    wav = (0.3 * torch.randn(4, S, generator=torch.Generator().manual_seed(9))).to(DEV)
+    ws = eng.forward(wav, None, training=False)
+    pred = ws.view("pred").clone()                                     # [12][4][498][768]
+    assert pred.shape == (12, 4, 498, 768) and torch.isfinite(pred.float()).all()
+    perm = [2, 0, 3, 1]
+    pred_p = eng.forward(wav[perm].contiguous(), None, training=False).view("pred").clone()
+    assert torch.equal(pred_p, pred[:, perm])
+    # utterance 1 cut to 6 s and padded back: its valid frames must not depend on the padding or on its neighbours
+    n6 = 96000
+    wav_pad = wav.clone()
+    wav_pad[1, n6:] = 0
+    lens = [S, n6, S, S]
+    pred_pad = eng.forward(wav_pad, lens, training=False).view("pred").clone()
+    # (not against the un-padded 6 s clip: as in the reference, the conv-0 GroupNorm statistics run over the padded length)
+    alone = eng.forward(wav_pad[1:2].contiguous(), [n6], training=False).view("pred").clone()    # same padding, no neighbours
+    assert torch.equal(pred_pad[:, 1], alone[:, 0])
+    assert torch.equal(pred_pad[:, 0], pred[:, 0])                      # an unpadded neighbour is untouched, bit for bit
+    Tv = (n6 - 400) // 320 + 1                                          # 299 valid frames after the frontend -> 298 predictions
+    assert pred_pad[:, 1, 2 * (Tv // 2):].abs().max().item() < 30       # padded frames stay finite (they carry bias-only values)
+    # gradient additivity: d(mean over 4)/dW = 0.5 * (d(mean over first 2) + d(mean over last 2))
+    teacher = torch.randn(12, 4, 499, 768, generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.bfloat16)
+    w = torch.full((12,), 0.1, device=DEV)
+    w[11] = 1.0
+    tl = torch.arange(12, dtype=torch.int32, device=DEV)
+
+    def grads_of(sl):
+        eng.grads.zero_()
+        wsx = eng.forward(wav[sl].contiguous(), None, training=True, seed=3)
+        out, d_pred = eng.kd_loss(wsx, teacher[:, sl].contiguous(), w, tl)
+        eng.backward(wsx, d_pred=d_pred)
+        torch.cuda.synchronize()
+        return out[12].item(), eng.grads.clone()
+
+    l_all, g_all = grads_of(slice(0, 4))
+    l_a, g_a = grads_of(slice(0, 2))
+    l_b, g_b = grads_of(slice(2, 4))
+    assert abs(l_all - 0.5 * (l_a + l_b)) < 2e-3 * abs(l_all)
+    # the conv-0 GroupNorm statistics are per utterance, LayerNorms per frame: nothing couples batch items, so gradients add
+    assert _rel_l2(g_all, 0.5 * (g_a + g_b)) < 2e-2
