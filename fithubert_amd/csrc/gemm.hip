@@ -1791,13 +1791,16 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.splitk = c.splitk;
     if (launch_path(q, c.path, stream) != 0) continue;
-    hipEventRecord(a, stream);
-    launch_path(q, c.path, stream);
-    launch_path(q, c.path, stream);
-    hipEventRecord(b, stream);
-    if (hipEventSynchronize(b) != hipSuccess) continue;
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, a, b);
+    float ms = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {  // best of two 3-launch timings: the candidates are often within a few percent
+      hipEventRecord(a, stream);
+      for (int i = 0; i < 3; ++i) launch_path(q, c.path, stream);
+      hipEventRecord(b, stream);
+      if (hipEventSynchronize(b) != hipSuccess) break;
+      float t = 0.f;
+      hipEventElapsedTime(&t, a, b);
+      ms = t < ms ? t : ms;
+    }
     if (ms < best_ms) { best_ms = ms; best = c; }
   }
   hipEventDestroy(a);
