@@ -578,144 +578,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   gemm_epilogue_staged<T>(p, acc, lds, i0, j0, xi0, yj0, lane, wave, g);
 }
 
-// ------------------------------------------------------------------ bf16 main loop with direct-to-LDS loads (LDS-DMA)
+// ------------------------------------------------------------------ direct-to-LDS loads (LDS-DMA): shared pieces
 // global_load_lds_dwordx4 moves 16 B per lane straight into LDS (no VGPR staging, no ds_write pass): one wave
 // instruction fills 1 KiB of LINEAR LDS.  Tiles are therefore unpadded; bank conflicts are removed with an XOR swizzle
-// applied to the per-lane SOURCE address and, identically, to the fragment reads (guide rule 21).
-// Pipeline: a ring of NST = 4 stages of BK = 32 (8 KiB per operand per stage, 64 KiB per block -> 2 blocks per CU).
-// Three K-tiles are in flight while one feeds the MFMAs; the only synchronisation per K-tile is a COUNTED
-// s_waitcnt vmcnt(8) (this wave's share of the oldest tile has landed) followed by one raw s_barrier (everyone's has,
-// and everyone is done reading the stage that is about to be refilled).  The student's GEMMs have short reductions
-// (K = 480): with one tile of prefetch every K-step exposed the full HBM/L2 latency.
+// applied to the per-lane SOURCE address and, identically, to the fragment reads (guide rule 21).  A lane whose row / column /
+// reduction index is out of range fetches from a 16-byte zero chunk, so tails need no masking.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int DMA_BK = 32;
-constexpr int DMA_NST = 4;
-constexpr int DMA_STAGE = 16384;  // X tile 8 KiB + Y tile 8 KiB
-
 __device__ __forceinline__ int strided_key(int kl) { return ((kl & 3) << 1) | (((kl >> 3) & 1) << 3); }
 
-// Loaders keep one running 64-bit source pointer per wave instruction.  Full K-tiles inside a segment take the FAST path
-// (pointer += per-lane step, no bounds logic, no branches: a lane whose row/column is out of range points at the zero
-// chunk with step 0).  The first tile of a segment and a partial last tile take the SLOW path that re-derives pointers.
-template <int LAYOUT> struct DmaLoader;
-
-template <> struct DmaLoader<FH_R_CONTIG> {  // LDS tile [128 rows][64 B]; 16-B chunk c of row R stored at chunk c ^ ((R>>2)&3)
-  const bf16* base;
-  long off[2];
-  long segdelta;
-  unsigned vmask;
-  int kch[2];  // logical k-chunk (8 elements) this lane fetches for its u-th wave instruction
-  int wave;
-  const unsigned char* ptr[2];
-  int step[2];
-  __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid) {
-    base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
-    wave = tid >> 6;
-    const int lane = tid & 63;
-    vmask = 0;
-    segdelta = (long)(o.tshift[1] - o.tshift[0]) * o.ld + (o.segoff[1] - o.segoff[0]);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = (wave * 2 + u) * 16 + (lane >> 2);
-      kch[u] = (lane & 3) ^ ((row >> 2) & 3);
-      const int idx = idx0 + row;
-      const bool rv = idx < idx_limit;
-      RowMap rm = map_row(rv ? idx : 0, o.rpb);
-      off[u] = (long)rm.b * o.bstride + (long)(rm.t + o.tshift[0]) * o.ld + o.segoff[0];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int ts = rm.t + o.tshift[s];
-        const bool v = rv && (s < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid));
-        vmask |= (v ? 1u : 0u) << (2 * u + s);
-      }
-    }
-  }
-  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {  // slow path
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int k = k0 + kch[u] * 8;
-      const bool v = (k < Kseg) && ((vmask >> (2 * u + seg)) & 1u);
-      ptr[u] = v ? (const unsigned char*)(base + off[u] + (long)seg * segdelta + k) : (const unsigned char*)g_zero_chunk;
-      step[u] = v ? DMA_BK * 2 : 0;
-    }
-  }
-  __device__ __forceinline__ void issue(unsigned char* tile) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * 2 + u) * 1024), 16, 0, 0);
-      ptr[u] += step[u];
-    }
-  }
-};
-
-template <> struct DmaLoader<FH_R_STRIDED> {  // LDS tile [32 k][256 B]; chunk c of k-row kl stored at chunk c ^ strided_key(kl)
-  const bf16* base;
-  int col[2];
-  int kl[2];
-  unsigned cvalid;
-  int wave;
-  const unsigned char* ptr[2];
-  int tcur[2];
-  long step;   // bytes per tile (32 reduction rows)
-  long wrap;   // extra bytes when the mapped row index crosses a batch item
-  int rpb;
-  __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid) {
-    base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
-    wave = tid >> 6;
-    const int lane = tid & 63;
-    cvalid = 0;
-    rpb = o.rpb;
-    step = (long)DMA_BK * o.ld * 2;
-    wrap = (o.bstride - (long)o.rpb * o.ld) * 2;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      kl[u] = (wave * 2 + u) * 4 + (lane >> 4);
-      const int c = (lane & 15) ^ strided_key(kl[u]);
-      col[u] = idx0 + c * 8;
-      cvalid |= (col[u] < idx_limit ? 1u : 0u) << u;
-    }
-  }
-  __device__ __forceinline__ void set_tile(const GemmOperand& o, int seg, int k0, int Kseg) {  // slow path
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = k0 + kl[u];
-      ptr[u] = (const unsigned char*)g_zero_chunk;
-      tcur[u] = -1;  // < 0: this lane stays on the zero chunk
-      if (((cvalid >> u) & 1u) && r < Kseg) {
-        RowMap rm = map_row(r, o.rpb);
-        ptr[u] = (const unsigned char*)(base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col[u]);
-        tcur[u] = rm.t;
-      }
-    }
-  }
-  __device__ __forceinline__ void issue(unsigned char* tile) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      __builtin_amdgcn_global_load_lds((gptr_t)ptr[u], (lptr_t)(tile + (wave * 2 + u) * 1024), 16, 0, 0);
-      if (tcur[u] >= 0) {
-        ptr[u] += step;
-        if (rpb > 0) {
-          tcur[u] += DMA_BK;
-          if (tcur[u] >= rpb) {  // requires rpb >= DMA_BK (checked on the host)
-            tcur[u] -= rpb;
-            ptr[u] += wrap;
-          }
-        }
-      }
-    }
-  }
-};
-
+// fragment of a [32 k][256 B] R_STRIDED LDS block (chunk c of k-row kl stored at chunk c ^ strided_key(kl)), read transposed
 template <int LAYOUT> __device__ __forceinline__ bf16x8 frag_dma(const unsigned char* lds, int row0, int lane);
-template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_CONTIG>(const unsigned char* lds, int row0, int lane) {
-  const int R = row0 + (lane & 15);
-  const int phys = (lane >> 4) ^ ((R >> 2) & 3);
-  return *reinterpret_cast<const bf16x8*>(lds + R * 64 + phys * 16);
-}
 template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_STRIDED>(const unsigned char* lds, int row0, int lane) {
   const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
   const int kl = 8 * q + qq;
@@ -729,97 +605,6 @@ template <> __device__ __forceinline__ bf16x8 frag_dma<FH_R_STRIDED>(const unsig
   u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
   u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 256));
   return u.v;
-}
-
-template <int XL, int YL>
-__global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // DMA_NST stages x (X 8 KiB | Y 8 KiB)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.z;
-  const int tiles_j = (p.N + BN - 1) / BN;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
-  const int i0 = ti * BM, j0 = tj * BN;
-  const int tiles_per_seg = (p.Kseg + DMA_BK - 1) / DMA_BK;
-  const int ntiles = tiles_per_seg * p.X.nseg;
-  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
-  const int t0 = blockIdx.y * per_split;
-  const int t1 = min(ntiles, t0 + per_split);
-  if (t0 >= t1) return;
-  const int nt = t1 - t0;
-
-  DmaLoader<XL> lx;
-  DmaLoader<YL> ly;
-  lx.init(p.X, g, i0, p.M, tid);
-  ly.init(p.Y, g, j0, p.N, tid);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int xi0 = (wave & 1) * 64, yj0 = (wave >> 1) * 64;
-
-  // (seg, k0) of the next tile to issue, advanced incrementally (no division in the loop)
-  int is_seg = t0 / tiles_per_seg;
-  int is_k0 = (t0 - is_seg * tiles_per_seg) * DMA_BK;
-  int issued = 0;
-  bool need_slow = true;
-  auto issue_next = [&](int stage) {
-    unsigned char* st = lds + stage * DMA_STAGE;
-    if (issued >= nt) {  // pipeline drain: keep the vmcnt bookkeeping uniform with harmless zero-chunk loads
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        lx.ptr[u] = (const unsigned char*)g_zero_chunk;
-        ly.ptr[u] = (const unsigned char*)g_zero_chunk;
-      }
-      __builtin_amdgcn_global_load_lds((gptr_t)lx.ptr[0], (lptr_t)(st + (wave * 2) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)lx.ptr[0], (lptr_t)(st + (wave * 2 + 1) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)ly.ptr[0], (lptr_t)(st + 8192 + (wave * 2) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)ly.ptr[0], (lptr_t)(st + 8192 + (wave * 2 + 1) * 1024), 16, 0, 0);
-      ++issued;
-      return;
-    }
-    const bool partial = is_k0 + DMA_BK > p.Kseg;
-    if (need_slow || partial) {
-      lx.set_tile(p.X, is_seg, is_k0, p.Kseg);
-      ly.set_tile(p.Y, is_seg, is_k0, p.Kseg);
-    }
-    lx.issue(st);
-    ly.issue(st + 8192);
-    ++issued;
-    is_k0 += DMA_BK;
-    need_slow = false;
-    if (is_k0 >= p.Kseg) {
-      is_k0 = 0;
-      is_seg = min(is_seg + 1, 1);
-      need_slow = true;
-    }
-  };
-#pragma unroll
-  for (int s = 0; s < DMA_NST - 1; ++s) issue_next(s);
-
-  int stage = 0;
-  for (int it = 0; it < nt; ++it) {
-    // this wave's 4 loads of tile `it` have landed (8 younger loads may still be in flight) ...
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    // ... and after the barrier so have everyone's; the stage read in iteration it-1 is free again: refill it
-    issue_next(stage == 0 ? DMA_NST - 1 : stage - 1);
-    const unsigned char* bx = lds + stage * DMA_STAGE;
-    const unsigned char* by = bx + 8192;
-    bf16x8 fx[4], fy[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) fx[m] = frag_dma<XL>(bx, xi0 + 16 * m, lane);
-#pragma unroll
-    for (int n = 0; n < 4; ++n) fy[n] = frag_dma<YL>(by, yj0 + 16 * n, lane);
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
-    stage = stage == DMA_NST - 1 ? 0 : stage + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero-chunk) tail loads before LDS is reused
-  gemm_epilogue_staged<bf16>(p, acc, lds, i0, j0, xi0, yj0, lane, wave, g);
 }
 
 // ------------------------------------------------------------------ bf16 main loop, large tiles (LDS-DMA ring, 16x16x32 MFMA)
@@ -1155,30 +940,6 @@ int launch_32(const GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
-int launch_dma(const GemmParams& p, hipStream_t stream) {
-  const int tiles_i = (p.M + BM - 1) / BM, tiles_j = (p.N + BN - 1) / BN;
-  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(256);
-  const size_t smem = (size_t)DMA_NST * DMA_STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_dma_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_dma_kernel<FH_R_CONTIG, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_dma_kernel<FH_R_STRIDED, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_dma_kernel<FH_R_STRIDED, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
-  const int xl = p.X.layout, yl = p.Y.layout;
-  if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
-    hipLaunchKernelGGL((gemm_dma_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p);
-  else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
-    hipLaunchKernelGGL((gemm_dma_kernel<FH_R_CONTIG, FH_R_STRIDED>), grid, block, smem, stream, p);
-  else if (xl == FH_R_STRIDED && yl == FH_R_CONTIG)
-    hipLaunchKernelGGL((gemm_dma_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p);
-  else
-    hipLaunchKernelGGL((gemm_dma_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p);
-  FH_CHECK_LAUNCH();
-  return 0;
-}
 
 // Ping-pong form of the ring (256 x 256 tile, 8 waves, BK = 32, 4 tile buffers): each K-tile is two phases of 16 MFMAs
 // (the wave's upper / lower 64 output rows), every phase = { LDS reads of its fragments + two LDS-DMA issues | barrier |
@@ -1695,34 +1456,28 @@ bool ring_ok(const GemmParams& p, int bk) {
 }
 
 // ------------------------------------------------------------------ bf16 main-loop selection
-// g_gemm_path: 0 = 16x16x32 register staging, 1 = 128-tile LDS-DMA ring, 2 = 32x32x16 register staging, 3 = 256x256 ring
+// g_gemm_path: 0 = 16x16x32 register staging, 2 = 32x32x16 register staging, 3 = 256x256 ring
 // (BK 64, 2 stages), 4 = 256x128 ring (BK 32, 3 stages, 2 workgroups / CU), 5 = 256x256 ring (BK 32, 4 stages),
 // 6 = 256x256 ping-pong ring (BK 32, two barrier-staggered wave groups), 7 = 256x256 8-phase loop (BK 64), 9 = per-shape choice
 // (default): a table filled by fh_gemm_tune(1) measurements, path 2 for shapes never measured.
-// FH_GEMM_PATH = reg | dma | 2..7 forces one loop (A/B comparisons; tools/gemm_bench.py).
+// FH_GEMM_PATH = reg | 2..7 forces one loop (A/B comparisons; tools/gemm_bench.py).
 int g_gemm_path = -1;
 int g_tune_mode = 0;
 int g_last_loop = 2;  // main loop the last bf16 launch ran (for the per-launch profile)
 struct TuneChoice { int path, splitk; };
 std::unordered_map<unsigned long long, TuneChoice> g_tune;
 
-bool dma_ok(const GemmParams& p) {
-  if (p.X.layout == FH_R_STRIDED && p.X.rpb > 0 && p.X.rpb < DMA_BK) return false;
-  if (p.Y.layout == FH_R_STRIDED && p.Y.rpb > 0 && p.Y.rpb < DMA_BK) return false;
-  return true;
-}
 void resolve_path() {
   if (g_gemm_path < 0) {
     const char* e = getenv("FH_GEMM_PATH");
-    g_gemm_path = !e ? 9 : (e[0] == 'd' ? 1 : (e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '7') ? e[0] - '0' : 9)));
+    g_gemm_path = !e ? 9 : ((e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '7') ? e[0] - '0' : 9)));
   }
 }
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   g_last_loop = 2;
-  if ((path == 1 && dma_ok(p)) || path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32)) ||
+  if (path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32)) ||
       (path == 7 && ring_ok(p, 64)))
     g_last_loop = path;
-  if (path == 1 && dma_ok(p)) return launch_dma(p, stream);
   if (path == 0) return launch_t<bf16>(p, stream);
   if (path == 3 && ring_ok(p, 64)) return launch_ring<256, 256, 2, 4, 64, 2>(p, stream);
   if (path == 4 && ring_ok(p, 32)) return launch_ring<256, 128, 2, 2, 32, 3>(p, stream);
