@@ -124,6 +124,7 @@ SIGNATURES = {
     "fh_layernorm_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _F, Drop, _P]),
     "fh_add_layernorm_forward": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "fh_layernorm_gelu_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "fh_gelu_forward": (_I, [_I, _P, _P, _L, _P]),
     "fh_layernorm_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, Drop, Drop, _P]),
     "fh_colsum": (_I, [_I, _P, _P, _I, _I, _L, _I, _L, _L, _I, _F, _P]),
     "fh_posconv_prepare": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

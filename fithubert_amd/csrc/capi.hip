@@ -44,6 +44,9 @@ int fh_layernorm_gelu_forward(int dtype, const void* x, const float* gamma, cons
                               fh_stream_t stream) {
   return fh_add_layernorm_fwd_launch(dtype, x, nullptr, gamma, beta, y, M, C, eps, ST(stream), 1);
 }
+int fh_gelu_forward(int dtype, const void* x, void* y, long n, fh_stream_t stream) {
+  return fh_unary_launch(dtype, x, y, n, 0, ST(stream));
+}
 int fh_layernorm_backward(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                           const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
                           int M, int C, fh_drop out_drop, fh_drop in_drop, fh_stream_t stream) {

@@ -83,23 +83,39 @@ __global__ void mul_gelu_grad_kernel(const T* __restrict__ src, const T* __restr
   }
 }
 
-// mode 0: dst = gelu(src);  mode 1: dst += src
+// mode 0: dst = gelu(src);  mode 1: dst += src.  Four 16-byte vectors per thread are in flight per trip (the loads are issued
+// before the first use), which is what a pure streaming kernel needs to approach the HBM rate.
 template <typename T>
-__global__ void unary_kernel(const T* __restrict__ src, T* __restrict__ dst, long nvec, int mode) {
+__global__ void unary_kernel(const T* src, T* dst, long nvec, int mode) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-    float a[VEC];
-    unpack16<T>(ld16(src + i * VEC), a);
-    if (mode == 0) {
+  constexpr int U = 4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += U * stride) {
+    V16 raw[U], rawd[U];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) a[e] = gelu_f(a[e]);
-    } else {
-      float d[VEC];
-      unpack16<T>(ld16(dst + i * VEC), d);
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * stride < nvec) raw[u] = ld16(src + (i0 + u * stride) * VEC);
+    if (mode != 0) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) a[e] += d[e];
+      for (int u = 0; u < U; ++u)
+        if (i0 + u * stride < nvec) rawd[u] = ld16(dst + (i0 + u * stride) * VEC);
     }
-    st16(dst + i * VEC, pack16<T>(a));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u * stride >= nvec) break;
+      float a[VEC];
+      unpack16<T>(raw[u], a);
+      if (mode == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = gelu_f(a[e]);
+      } else {
+        float d[VEC];
+        unpack16<T>(rawd[u], d);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += d[e];
+      }
+      st16(dst + (i0 + u * stride) * VEC, pack16<T>(a));
+    }
   }
 }
 

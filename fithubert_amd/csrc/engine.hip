@@ -43,19 +43,33 @@ __global__ void head_bias_merge_kernel(const float* __restrict__ params, long he
 // dWlin[p][co] += dbl[p] * b_up[co]   (the merged bias depends on Wlin too)
 __global__ void head_bias_bwd_kernel(const float* __restrict__ params, float* __restrict__ grads, long head_base, long head_stride,
                                      long o_lin_w, long o_lin_b, long o_up_b, const float* __restrict__ dbl, int P, int D) {
+  // grid (heads, ceil(D / 16)); a workgroup owns 16 columns co of one head: 16 x 16 threads = (row lane, column)
+  __shared__ float part[16][17];
   const int l = blockIdx.x;
   const float* hp = params + head_base + (long)l * head_stride;
   float* hg = grads + head_base + (long)l * head_stride;
   const float* d = dbl + (long)l * P;
-  for (int pp = threadIdx.x; pp < P; pp += blockDim.x) hg[o_lin_b + pp] += d[pp];
-  for (int co = threadIdx.x; co < D; co += blockDim.x) {
-    float s = 0.f;
-    for (int pp = 0; pp < P; ++pp) s = fmaf(hp[o_lin_w + (long)pp * D + co], d[pp], s);
-    hg[o_up_b + co] += s;
+  if (blockIdx.y == 0)
+    for (int pp = threadIdx.x; pp < P; pp += blockDim.x) hg[o_lin_b + pp] += d[pp];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int co = blockIdx.y * 16 + cl;
+  float s = 0.f;
+  if (co < D) {
+    const float bu = hp[o_up_b + co];
+    for (int pp = rl; pp < P; pp += 16) {
+      const long i = o_lin_w + (long)pp * D + co;
+      const float dv = d[pp];
+      s = fmaf(hp[i], dv, s);
+      hg[i] += dv * bu;
+    }
   }
-  for (long i = threadIdx.x; i < (long)P * D; i += blockDim.x) {
-    const int pp = (int)(i / D), co = (int)(i - (long)pp * D);
-    hg[o_lin_w + i] += d[pp] * hp[o_up_b + co];
+  part[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && co < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += part[r][cl];
+    hg[o_up_b + co] += t;
   }
 }
 
@@ -838,7 +852,7 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
           RC(fh_gemm_launch(g, 0, x.st));
         }
       }
-      hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(Lh), dim3(256), 0, x.st, x.params, grads, hp0, p.pl.head_stride, p.pl.h_lin_w,
+      hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(Lh, (D + 15) / 16), dim3(256), 0, x.st, x.params, grads, hp0, p.pl.head_stride, p.pl.h_lin_w,
                          p.pl.h_lin_b, p.pl.h_up_b, (const float*)x.W<float>(p.dbl), P, D);
       FH_CHECK_LAUNCH();
       dlin_in = nullptr;

@@ -1464,6 +1464,7 @@ bool ring_ok(const GemmParams& p, int bk) {
 int g_gemm_path = -1;
 int g_tune_mode = 0;
 int g_last_loop = 2;  // main loop the last bf16 launch ran (for the per-launch profile)
+int g_last_splitk = 1;
 struct TuneChoice { int path, splitk; };
 std::unordered_map<unsigned long long, TuneChoice> g_tune;
 
@@ -1475,6 +1476,7 @@ void resolve_path() {
 }
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   g_last_loop = 2;
+  g_last_splitk = p.splitk;
   if (path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32)) ||
       (path == 7 && ring_ok(p, 64)))
     g_last_loop = path;
@@ -1581,7 +1583,7 @@ int launch_bf16(const GemmParams& p, hipStream_t stream) {
 
 // ------------------------------------------------------------------ optional per-launch HIP-event timing (bench.py roofline)
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+struct ProfRec { hipEvent_t a, b; double flops; int variant; int M, N, K, groups, splitk; };
 std::vector<ProfRec> g_prof;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 bool g_prof_on = false;
@@ -1622,16 +1624,23 @@ extern "C" int fh_prof_enable(int on) {
 extern "C" int fh_prof_collect(double* ms /*[64]*/, double* flops /*[64]*/, long* launches /*[64]*/) {
   for (int i = 0; i < 64; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   int n = 0;
+  // FH_GEMM_TRACE=<file>: one line per launch (shape, operand layouts, loop, split, ms) -- a tuning aid
+  const char* trace = getenv("FH_GEMM_TRACE");
+  FILE* tf = trace && *trace ? fopen(trace, "a") : nullptr;
   for (auto& r : g_prof) {
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    if (tf)
+      fprintf(tf, "%d %d %d %d %d %d %d %d %.4f\n", r.M, r.N, r.K, r.groups, (r.variant >> 1) & 1, r.variant & 1,
+              r.variant >> 3, r.splitk, t);
     ms[r.variant] += t;
     flops[r.variant] += r.flops;
     launches[r.variant] += 1;
     g_pool.emplace_back(r.a, r.b);
     ++n;
   }
+  if (tf) fclose(tf);
   g_prof.clear();
   return n;
 }
@@ -1660,9 +1669,10 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   }
   r.flops = 2.0 * p.M * p.N * (double)p.Kseg * p.X.nseg * p.groups;
   r.variant = (dtype ? 4 : 0) + p.X.layout * 2 + p.Y.layout;
+  r.M = p.M; r.N = p.N; r.K = p.Kseg * p.X.nseg; r.groups = p.groups; r.splitk = p.splitk;
   hipEventRecord(r.a, stream);
   const int rc = dtype == 0 ? launch_t<float>(p, stream) : launch_bf16(p, stream);
-  if (dtype != 0) r.variant += 8 * (g_last_loop & 7);
+  if (dtype != 0) { r.variant += 8 * (g_last_loop & 7); r.splitk = g_last_splitk; }
   hipEventRecord(r.b, stream);
   g_prof.push_back(r);
   return rc;

@@ -129,6 +129,9 @@ int fh_add_layernorm_forward(int dtype, const void* x, const void* res, const fl
  * fairseq ConvFeatureExtractionModel, mode 'layer_norm').  Forward only. */
 int fh_layernorm_gelu_forward(int dtype, const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps,
                               fh_stream_t stream);
+/* y = gelu(x), exact-erf form (fairseq get_activation_fn('gelu') -> F.gelu; the teacher's fc1 activation, reference teacher via
+ * utils/utils.py:51-99).  y may alias x.  n must be a multiple of the 16-byte vector (4 fp32 / 8 bf16).  Forward only. */
+int fh_gelu_forward(int dtype, const void* x, void* y, long n, fh_stream_t stream);
 int fh_layernorm_backward(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                           const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
                           int M, int C, fh_drop out_drop, fh_drop in_drop, fh_stream_t stream);

@@ -148,6 +148,23 @@ def test_colsum(dt):
     assert _rel(out, ref) < 1e-5 * 10
 
 
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("n", [8, 4096 + 8, 3 * 1024 * 1024 + 40])  # below one trip / ragged tail / several trips of the 4-deep loop
+def test_gelu_forward_out_of_place_and_in_place(dt, n):
+    """exact-erf GELU (F.gelu default) -- the teacher's fc1 activation; tolerance: 2e-5 fp32 (A&S 7.1.26 erf, 1.5e-7 abs), bf16 rounding"""
+    torch.manual_seed(5)
+    x = (3.0 * torch.randn(n, device=DEV)).to(_tdt(dt))
+    x[:8] = torch.tensor([0.0, -0.0, 10.0, -10.0, 0.75, -0.75, 40.0, -40.0], device=DEV).to(_tdt(dt))
+    ref = F.gelu(x.double())
+    y = torch.full_like(x, float("nan"))
+    L.check(L.lib().fh_gelu_forward(dt, _p(x), _p(y), n, _st()), "gelu")
+    assert _rel(y, ref) < _tol(dt)
+    x2 = x.clone()
+    L.check(L.lib().fh_gelu_forward(dt, _p(x2), _p(x2), n, _st()), "gelu in place")
+    assert torch.equal(x2, y)
+    assert L.lib().fh_gelu_forward(dt, _p(x), _p(y), 7, _st()) == -701  # not a whole number of 16-byte vectors
+
+
 # ------------------------------------------------------------------------------------------ positional conv
 def _posconv_ref(x, g, v, bias, groups, K):
     w = g * v / v.norm(2, dim=(0, 1), keepdim=True)

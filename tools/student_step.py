@@ -33,3 +33,15 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for i in range(a.steps): out = step(i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / a.steps
 print(f"student step B={a.batch}: {dt*1e3:.2f} ms  ({dt*1e3/a.batch:.3f} ms/utt, {105.7*a.batch/dt/1e3:.0f} TF/s algorithmic) loss {out[-1].item():.4f}")
+if os.environ.get("FH_GEMM_TRACE"):
+    # one traced step: per-launch shape / loop / ms lines go to the file named by FH_GEMM_TRACE (see gemm.hip fh_prof_collect)
+    import ctypes as C
+    from fithubert_amd import _lib
+    L = _lib.lib()
+    L.fh_prof_enable(1)
+    step(0)
+    torch.cuda.synchronize()
+    ms = (C.c_double * 64)(); fl = (C.c_double * 64)(); ln = (C.c_long * 64)()
+    L.fh_prof_collect(ms, fl, ln)
+    L.fh_prof_enable(0)
+    print(f"traced GEMM launches: {sum(ln)}, {sum(ms):.2f} ms, {sum(fl)/sum(ms)/1e9:.0f} TF/s")
