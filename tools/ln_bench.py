@@ -22,3 +22,7 @@ for (M, C) in [(63872, 768), (31872, 480), (63872, 512)]:
     dx = torch.empty_like(x); dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
     us = timeit(lambda: L.check(lib.fh_layernorm_backward(1, y.data_ptr(), None, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dx.data_ptr(), None, dg.data_ptr(), db.data_ptr(), M, C, L.Drop(0.0, 0, 0), L.Drop(0.0, 0, 0), st()), "b"))
     print(f"    LN bwd M={M} C={C}: {us:7.1f} us {3*M*C*2/us/1e6:6.2f} TB/s")
+    if C == 480:  # the student's LN2 backward call: two incoming gradients, dropout on the output gradient, second (dropped) dx copy
+        dx2 = torch.empty_like(x)
+        us = timeit(lambda: L.check(lib.fh_layernorm_backward(1, y.data_ptr(), r.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dx.data_ptr(), dx2.data_ptr(), dg.data_ptr(), db.data_ptr(), M, C, L.Drop(0.1, 3, 5), L.Drop(0.1, 3, 6), st()), "b"))
+        print(f"    LN bwd (dy2, drops, dx2) M={M} C={C}: {us:7.1f} us {5*M*C*2/us/1e6:6.2f} TB/s")

@@ -13,3 +13,14 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): h = t.hidden_stack(x, None)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 print(f"teacher fwd B={a.batch}: {dt*1e3:.2f} ms ({148.1*a.batch/dt/1e3:.0f} TF/s algorithmic)")
+if os.environ.get("FH_GEMM_TRACE"):  # one traced forward: per-launch lines of the HIP GEMMs (the conv layers) -> tools/gemm_trace_table.py
+    import ctypes as C
+    from fithubert_amd import _lib
+    L = _lib.lib()
+    L.fh_prof_enable(1)
+    t.hidden_stack(x, None)
+    torch.cuda.synchronize()
+    ms = (C.c_double * 64)(); fl = (C.c_double * 64)(); ln = (C.c_long * 64)()
+    L.fh_prof_collect(ms, fl, ln)
+    L.fh_prof_enable(0)
+    print(f"traced GEMM launches: {sum(ln)}, {sum(ms):.2f} ms, {sum(fl)/sum(ms)/1e9:.0f} TF/s")
