@@ -124,6 +124,10 @@ template <typename T> __device__ __forceinline__ void zero_lds(unsigned char* ld
   for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16) st16(lds + i, v16_zero());
 }
 
+// Dropout index of probability (b, h, query, key) = ((b H + h) Tn + query) * pitch + key with an EVEN row pitch: the pair form
+// of the mask (common.cuh drop_pair: one hash word serves indices 2j and 2j + 1) needs every row to start on an even index,
+// otherwise the forward's (row base + even offset) pairs and the dK/dV pass's (index & ~1) pairs disagree for odd Tn.
+__device__ __forceinline__ unsigned long long drop_row_pitch(int Tn) { return (unsigned long long)((Tn + 1) & ~1); }
 __device__ __forceinline__ float xor_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
   // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
-  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * (unsigned long long)Tn);
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
 
   const int ntile = (klen + 63) / 64;
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
@@ -232,7 +236,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[qt][dt][e] *= alpha;
       if (drop.p > 0.f) {
-        const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
+        const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * drop_row_pitch(Tn) + kt0;
         const DropKey dk = drop_key_at(dspan, rowbase);
         const uint32_t lo = (uint32_t)rowbase;
 #pragma unroll
@@ -290,7 +294,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
   // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
-  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * (unsigned long long)Tn);
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
 
   const int ntile = (klen + 63) / 64;
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           const int query = q0 + 16 * qt + r;
-          const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
+          const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * drop_row_pitch(Tn) + kt0;
           const DropKey dk = drop_key_at(dspan, rowbase);
           const uint32_t lo = (uint32_t)rowbase;
           float dsc[4] = {1.f, 1.f, 1.f, 1.f};
@@ -420,7 +424,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
   const T* dobase = dout + (long)b * Tn * D + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
   // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
-  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * (unsigned long long)Tn);
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
 
   const int ntile = (Tn + 63) / 64;
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
@@ -499,7 +503,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
             if (drop.p > 0.f) {
               // same (key-tile-relative) split of the index as the forward: hi word of (row base + tile start), lo + offset
               const int kt0 = key & ~63;
-              const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * (unsigned long long)Tn + kt0;
+              const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * drop_row_pitch(Tn) + kt0;
               dsc = drop_pair_one(drop_key_at(dspan, rowbase), (uint32_t)rowbase + (key - kt0));
             }
             pd[half][kt][e] = p * dsc;
@@ -511,6 +515,187 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
       for (int kt = 0; kt < 2; ++kt) {
         mma_transposed<T, NDT>(Os, m2, pd[0][kt], pd[1][kt], dv[kt], lane);
         mma_transposed<T, NDT>(Qs, m2, ds[0][kt], ds[1][kt], dk[kt], lane);
+      }
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = k0 + 16 * kt + r;
+    if (key >= Tn) continue;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int d = 16 * dt + 4 * q;
+      if (d < dh) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dk[kt][dt][e];
+        st4(dqkv + ((long)b * Tn + key) * ld + D + h * dh + d, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dv[kt][dt][e];
+        st4(dqkv + ((long)b * Tn + key) * ld + 2 * D + h * dh + d, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: fused dQ / dK / dV
+// One workgroup = one (batch, head), Tn <= 256, bf16; 8 waves, wave w owns keys [32w, 32w + 32) exactly like the dK/dV pass above
+// (its K / V fragments and dK / dV accumulators stay in registers while it walks the resident Q / dO tiles).  What the two-pass
+// form computes twice -- P (an exp2 per score), the dropout mask (a hash per score) and dS -- is computed once: after each
+// 32-query step the wave leaves its dS block, transposed ([key][query], bf16), in an LDS scratch; one barrier later six waves
+// (one per 16-query x 16-d output tile) contract the scratch with the resident K tile over all 256 keys, dQ^T = K^T dS^T, both
+// operands through transposing LDS reads, and store that dQ block (complete: every key has been seen).  The scratch is double
+// buffered, so the step costs ONE barrier and the dQ MFMAs overlap the next step's exp / hash work.
+// LDS: 4 x (Q | dO | lse | delta) tiles 75,776 B + K 36,864 B + 2 x dS^T scratch 36,864 B = 149,504 B.
+constexpr int FUSED_SRS = 72;  // scratch row: 32 queries x 2 B + 8 B pad (conflict-free transposing reads)
+template <int NDT>
+__global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                             const int* __restrict__ key_len, int B, int Tn, int H, int dh,
+                                                             float scale, float scale_log2e, DropCfg drop) {
+  typedef bf16 T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RS = AT<T>::RS;
+  constexpr int PAIR = 2 * 64 * RS + 512;  // Q tile | dO tile | 64 x LSE | 64 x delta
+  constexpr int NK = AT<T>::NK;
+  constexpr int TOTAL = 4 * PAIR + 256 * RS + 2 * 256 * FUSED_SRS;
+  typedef typename AT<T>::frag frag;
+  unsigned char* Kt = lds + 4 * PAIR;
+  unsigned char* Sc = Kt + 256 * RS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = wave * 32;
+  const int D = H * dh;
+  const long ld = 3L * D;
+  const T* base = qkv + (long)b * Tn * ld + h * dh;
+  const T* dobase = dout + (long)b * Tn * D + h * dh;
+  const T* obase = out + (long)b * Tn * D + h * dh;
+  const int klen = key_len ? min(key_len[b], Tn) : Tn;
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
+  const int ntile = (Tn + 63) / 64;
+
+  zero_lds<T>(lds, TOTAL);
+  __syncthreads();
+  for (int kt = 0; kt < ntile; ++kt) {
+    unsigned char* sb = lds + kt * PAIR;
+    stage_tile<T>(sb, base, ld, kt * 64, Tn, dh);
+    stage_tile<T>(sb + 64 * RS, dobase, D, kt * 64, Tn, dh);
+    stage_tile<T>(Kt + kt * 64 * RS, base + D, ld, kt * 64, Tn, dh);
+  }
+  {  // lse, and delta[query] = sum_d out * dout: two threads per query row
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    float part = 0.f;
+    if (row < Tn)
+      for (int c = half; c < dh / 8; c += 2) {
+        float a[8], g[8];
+        unpack16<T>(ld16(obase + (long)row * D + c * 8), a);
+        unpack16<T>(ld16(dobase + (long)row * D + c * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part = fmaf(a[e], g[e], part);
+      }
+    part += __shfl_xor(part, 1, 64);
+    if (half == 0) {
+      float* L2w = reinterpret_cast<float*>(lds + (row >> 6) * PAIR + 2 * 64 * RS);
+      L2w[row & 63] = row < Tn ? lse[((long)b * H + h) * Tn + row] : INFINITY;
+      L2w[64 + (row & 63)] = part;
+      if (row < Tn) delta[((long)b * H + h) * Tn + row] = part;
+    }
+  }
+  frag kf[2][NK], vf[2][NK];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = k0 + 16 * kt + r;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      kf[kt][ks] = gfrag<T>(base + D + (long)key * ld, key < Tn, ks, lane, dh);
+      vf[kt][ks] = gfrag<T>(base + 2 * D + (long)key * ld, key < Tn, ks, lane, dh);
+    }
+  }
+  f32x4 dk[2][NDT], dv[2][NDT];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  __syncthreads();
+
+  const int nstep = (Tn + 31) / 32;  // 32-query steps
+  const int nkc = (Tn + 31) / 32;    // 32-key chunks of the dQ contraction
+  const int i16 = r, qq = i16 >> 2, pp = i16 & 3;
+  for (int st = 0; st < nstep; ++st) {
+    const int m2 = st & 1, qt0 = (st >> 1) * 64;
+    const unsigned char* Qs = lds + (st >> 1) * PAIR;
+    const unsigned char* Os = Qs + 64 * RS;
+    const float* L2s = reinterpret_cast<const float*>(Qs + 2 * 64 * RS);
+    const float* Dls = L2s + 64;
+    unsigned char* Sb = Sc + (st & 1) * 256 * FUSED_SRS;
+    f32x4 pd[2][2], ds[2][2];  // [half][kt]
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int qb = 2 * m2 + half;
+      f32x4 s[2], dp[2];
+      s[0] = s[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const frag aq = lfrag<T>(Qs, 16 * qb + r, ks, lane);
+        const frag ao = lfrag<T>(Os, 16 * qb + r, ks, lane);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          s[kt] = mma(aq, kf[kt][ks], s[kt]);
+          dp[kt] = mma(ao, vf[kt][ks], dp[kt]);
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int key = k0 + 16 * kt + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ql = 16 * qb + 4 * q + e;
+          const int query = qt0 + ql;
+          float p = key < klen ? exp2f(s[kt][e] * scale_log2e - L2s[ql]) : 0.f;
+          float dsc = 1.f;
+          if (drop.p > 0.f) {
+            const int kt0 = key & ~63;
+            const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * drop_row_pitch(Tn) + kt0;
+            dsc = drop_pair_one(drop_key_at(dspan, rowbase), (uint32_t)rowbase + (key - kt0));
+          }
+          pd[half][kt][e] = p * dsc;
+          ds[half][kt][e] = p * (dp[kt][e] * dsc - Dls[ql]) * scale;
+        }
+        // dS^T block of this wave: row = key, 4 consecutive queries per lane
+        uint2 pk;
+        pk.x = bf16_bits(ds[half][kt][0]) | (bf16_bits(ds[half][kt][1]) << 16);
+        pk.y = bf16_bits(ds[half][kt][2]) | (bf16_bits(ds[half][kt][3]) << 16);
+        *reinterpret_cast<uint2*>(Sb + (k0 + 16 * kt + r) * FUSED_SRS + (16 * half + 4 * q) * 2) = pk;
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      mma_transposed<T, NDT>(Os, m2, pd[0][kt], pd[1][kt], dv[kt], lane);
+      mma_transposed<T, NDT>(Qs, m2, ds[0][kt], ds[1][kt], dk[kt], lane);
+    }
+    __syncthreads();
+    if (wave < 2 * NDT) {  // dQ^T tile (16 d x 16 queries) of this step: K^T [d][keys] . dS^T [keys][queries]
+      const int qb2 = wave / NDT, dt = wave - qb2 * NDT;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kc = 0; kc < nkc; ++kc) {
+        const unsigned char* a0 = Kt + (32 * kc + 4 * q + qq) * RS + (16 * dt + 4 * pp) * 2;
+        const unsigned char* b0 = Sb + (32 * kc + 4 * q + qq) * FUSED_SRS + (16 * qb2 + 4 * pp) * 2;
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } ua, ub;
+        ua.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        ua.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * RS));
+        ub.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b0);
+        ub.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + 16 * FUSED_SRS));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc, 0, 0, 0);
+      }
+      const int query = st * 32 + 16 * qb2 + r, d = 16 * dt + 4 * q;
+      if (query < Tn && d < dh) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[e];
+        st4(dqkv + ((long)b * Tn + query) * ld + h * dh + d, v);
       }
     }
   }
@@ -582,6 +767,24 @@ int bwd_launch_t(const T* qkv, const T* out, const T* dout, const float* lse, fl
   FH_CHECK_LAUNCH();
   return 0;
 }
+template <int NDT>
+int bwd_fused_launch(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, float* delta, bf16* dqkv,
+                     const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
+  const size_t smem = 4 * (2 * 64 * AT<bf16>::RS + 512) + 256 * AT<bf16>::RS + 2 * 256 * FUSED_SRS;
+  set_lds(attn_bwd_fused_kernel<NDT>, smem);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NDT>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len, B, Tn,
+                     H, dh, scale, sl2, drop);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+bool fused_bwd_enabled() {  // FH_ATTN_FUSED=0 selects the two-pass backward (A/B comparisons)
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("FH_ATTN_FUSED");
+    mode = (e && e[0] == '0') ? 0 : 1;
+  }
+  return mode != 0;
+}
 int wide_waves(int res, int Tn, int max_nw = 16) {  // waves per workgroup: FH_ATTN_WAVES = 4 | 8 | 16 overrides
   static int forced = -1;
   if (forced < 0) {
@@ -636,6 +839,10 @@ int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const v
   const int res = resident_tiles<bf16>(Tn);
   const int nw = wide_waves(res, Tn, 8);  // the 16-wave backward builds spill under the 128-VGPR cap
   const bf16 *q = (const bf16*)qkv, *o = (const bf16*)out, *d = (const bf16*)dout;
+  if (res && Tn <= 256 && Tn > 64 && fused_bwd_enabled()) {
+    if (dh > 48) return bwd_fused_launch<4>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+    return bwd_fused_launch<3>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+  }
   if (dh > 48) {
     if (nw == 8) return bwd_launch_t<bf16, 4, 8>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
     return bwd_launch_t<bf16, 4, 4>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);

@@ -323,6 +323,57 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(dt):
     assert _rel(dqkv[0, :dh, 2 * D:2 * D + dh], dv_ref) < (1e-4 if dt == L.DT_F32 else 3e-2)
 
 
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("T,masked", [(200, False), (249, True), (300, False)])  # <= 256 bf16: the fused backward; 300: the two-pass one
+def test_attention_dropout_backward_matches_autograd_with_the_forward_mask(dt, T, masked):
+    """Reads the forward's complete dropout mask of one head through one-hot V probes, then checks dq / dk / dv of that head
+    against autograd with that mask held fixed (the backward kernels regenerate the mask from (seed, site, index))."""
+    torch.manual_seed(11)
+    B, H, dh = 2, 12, 40
+    D = H * dh
+    keep = 0.8
+    lib = L.lib()
+    drop = L.drop(1.0 - keep, 7, 3)
+    qkv = torch.randn(B, T, 3 * D, device=DEV).to(_tdt(dt))
+    key_len = torch.tensor([T, T * 3 // 4], device=DEV, dtype=torch.int32) if masked else None
+    bb, hh = 1, 5
+    vcol = 2 * D + hh * dh
+    out = torch.empty(B, T, D, device=DEV, dtype=_tdt(dt))
+    lse = torch.empty(B, H, T, device=DEV)
+    pdrop = torch.zeros(T, T, device=DEV, dtype=torch.float64)
+    for k0 in range(0, T, dh):  # V = one-hot rows for keys k0..k0+dh-1 -> out[:, d] = P_drop[:, k0 + d]
+        probe = qkv.clone()
+        probe[bb, :, vcol:vcol + dh] = 0
+        n = min(dh, T - k0)
+        probe[bb, k0:k0 + n, vcol:vcol + n] = torch.eye(n, device=DEV, dtype=probe.dtype)
+        L.check(lib.fh_attention_forward(dt, _p(probe), _p(out), _p(lse), _p(key_len), B, T, H, dh, dh ** -0.5, drop, _st()), "attn")
+        pdrop[:, k0:k0 + n] = out[bb, :, hh * dh:hh * dh + n].double()
+    klen = int(key_len[bb].item()) if masked else T
+    mask = (pdrop > 0).double()
+    assert abs(mask[:, :klen].mean().item() - keep) < 0.02
+    L.check(lib.fh_attention_forward(dt, _p(qkv), _p(out), _p(lse), _p(key_len), B, T, H, dh, dh ** -0.5, drop, _st()), "attn")
+    q = qkv[bb, :, hh * dh:(hh + 1) * dh].double().requires_grad_(True)
+    k = qkv[bb, :, D + hh * dh:D + (hh + 1) * dh].double().requires_grad_(True)
+    v = qkv[bb, :, vcol:vcol + dh].double().requires_grad_(True)
+    sc = q @ k.t() * dh ** -0.5
+    sc = sc.masked_fill(torch.arange(T, device=DEV)[None, :] >= klen, float("-inf"))
+    o = (torch.softmax(sc, -1) * mask / keep) @ v
+    assert _rel(out[bb, :, hh * dh:(hh + 1) * dh], o) < _tol(dt) * 2
+    dout = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+    o.backward(dout[bb, :, hh * dh:(hh + 1) * dh].double())
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(B, H, T, device=DEV)
+    L.check(lib.fh_attention_backward(dt, _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(key_len), B, T, H, dh,
+                                      dh ** -0.5, drop, _st()), "attn bwd")
+    assert not torch.isnan(dqkv.float()).any()
+    tol = 2e-4 if dt == L.DT_F32 else 4e-2
+    assert _rel(dqkv[bb, :, hh * dh:(hh + 1) * dh], q.grad) < tol, "dq"
+    assert _rel(dqkv[bb, :, D + hh * dh:D + (hh + 1) * dh], k.grad) < tol, "dk"
+    assert _rel(dqkv[bb, :, vcol:vcol + dh], v.grad) < tol, "dv"
+    dl_ref = (out[bb, :, hh * dh:(hh + 1) * dh].double() * dout[bb, :, hh * dh:(hh + 1) * dh].double()).sum(-1)
+    assert _rel(delta[bb, hh], dl_ref) < (1e-5 if dt == L.DT_F32 else 1e-2)
+
+
 # ------------------------------------------------------------------------------------------ KD loss
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
 @pytest.mark.parametrize("tdt", [L.DT_F32, L.DT_BF16])
