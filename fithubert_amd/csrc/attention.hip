@@ -128,6 +128,9 @@ template <typename T> __device__ __forceinline__ void zero_lds(unsigned char* ld
 // of the mask (common.cuh drop_pair: one hash word serves indices 2j and 2j + 1) needs every row to start on an even index,
 // otherwise the forward's (row base + even offset) pairs and the dK/dV pass's (index & ~1) pairs disagree for odd Tn.
 __device__ __forceinline__ unsigned long long drop_row_pitch(int Tn) { return (unsigned long long)((Tn + 1) & ~1); }
+// v_exp_f32 without libm's denormal-range rescue (a compare, two selects and an ldexp per call): every exponent here is <= 0 up
+// to rounding and a probability below 2^-126 may flush to zero
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float xor_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -218,14 +221,14 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
         }
       mx = xor_max(mx) * scale_log2e;  // scale > 0: max commutes with it; the per-element scaling rides in the fma below
       const float mnew = fmaxf(m[qt], mx);
-      const float alpha = exp2f(m[qt] - mnew);
+      const float alpha = fast_exp2(m[qt] - mnew);
       m[qt] = mnew;
       float rs = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = exp2f(fmaf(s[kb][qt][e], scale_log2e, -mnew));
+          const float p = fast_exp2(fmaf(s[kb][qt][e], scale_log2e, -mnew));
           rs += p;
           s[kb][qt][e] = p;
         }
@@ -379,7 +382,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int key = kt0 + 16 * kb + 4 * q + e;
-            float p = key < klen ? exp2f(fmaf(s[qt][e], scale_log2e, -L2[qt])) : 0.f;
+            float p = key < klen ? fast_exp2(fmaf(s[qt][e], scale_log2e, -L2[qt])) : 0.f;
             ds[half][qt][e] = p * (dp[qt][e] * dsc[e] - dl[qt]) * scale;
           }
         }
@@ -498,7 +501,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
           for (int e = 0; e < 4; ++e) {
             const int ql = 16 * qb + 4 * q + e;
             const int query = qt0 + ql;
-            float p = key < klen ? exp2f(s[kt][e] * scale_log2e - L2s[ql]) : 0.f;
+            float p = key < klen ? fast_exp2(s[kt][e] * scale_log2e - L2s[ql]) : 0.f;
             float dsc = 1.f;
             if (drop.p > 0.f) {
               // same (key-tile-relative) split of the index as the forward: hi word of (row base + tile start), lo + offset
@@ -548,7 +551,31 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
 // buffered, so the step costs ONE barrier and the dQ MFMAs overlap the next step's exp / hash work.
 // LDS: 4 x (Q | dO | lse | delta) tiles 75,776 B + K 36,864 B + 2 x dS^T scratch 36,864 B = 149,504 B.
 constexpr int FUSED_SRS = 72;  // scratch row: 32 queries x 2 B + 8 B pad (conflict-free transposing reads)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // one v_cvt_pk_bf16_f32
+  union { bf16x2 v; uint32_t u; } c;
+  c.v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  return c.u;
+}
+// acc[dt] += Tile^T[d-tile dt][rows] * P with P already packed: lo / hi = the 4 bf16 of the two C tiles covering tile rows
+// [32 m2, 32 m2 + 16) and [32 m2 + 16, 32 m2 + 32)  (mma_transposed<bf16> without its conversions)
 template <int NDT>
+__device__ __forceinline__ void mma_transposed_packed(const unsigned char* tile, int m2, uint2 lo, uint2 hi, f32x4 (&acc)[NDT], int lane) {
+  const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
+  union { struct { uint2 lo, hi; } s; bf16x8 v; } pb;
+  pb.s.lo = lo;
+  pb.s.hi = hi;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    const unsigned char* a0 = tile + (32 * m2 + 4 * q + qq) * AT<bf16>::RS + (16 * dt + 4 * pp) * 2;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * AT<bf16>::RS));
+    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pb.v, acc[dt], 0, 0, 0);
+  }
+}
+template <int NDT, bool DROP>
 __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -559,7 +586,6 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
   constexpr int RS = AT<T>::RS;
   constexpr int PAIR = 2 * 64 * RS + 512;  // Q tile | dO tile | 64 x LSE | 64 x delta
   constexpr int NK = AT<T>::NK;
-  constexpr int TOTAL = 4 * PAIR + 256 * RS + 2 * 256 * FUSED_SRS;
   typedef typename AT<T>::frag frag;
   unsigned char* Kt = lds + 4 * PAIR;
   unsigned char* Sc = Kt + 256 * RS;
@@ -571,10 +597,9 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
   const T* dobase = dout + (long)b * Tn * D + h * dh;
   const T* obase = out + (long)b * Tn * D + h * dh;
   const int klen = key_len ? min(key_len[b], Tn) : Tn;
-  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
   const int ntile = (Tn + 63) / 64;
 
-  zero_lds<T>(lds, TOTAL);
+  zero_lds<T>(lds, 4 * PAIR + 256 * RS);  // the scratch is fully rewritten every step
   __syncthreads();
   for (int kt = 0; kt < ntile; ++kt) {
     unsigned char* sb = lds + kt * PAIR;
@@ -582,7 +607,7 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
     stage_tile<T>(sb + 64 * RS, dobase, D, kt * 64, Tn, dh);
     stage_tile<T>(Kt + kt * 64 * RS, base + D, ld, kt * 64, Tn, dh);
   }
-  {  // lse, and delta[query] = sum_d out * dout: two threads per query row
+  {  // lse (negated: the exponent is fma(s, c, -lse)), and delta[query] = sum_d out * dout: two threads per query row
     const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
     float part = 0.f;
     if (row < Tn)
@@ -596,7 +621,7 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
     part += __shfl_xor(part, 1, 64);
     if (half == 0) {
       float* L2w = reinterpret_cast<float*>(lds + (row >> 6) * PAIR + 2 * 64 * RS);
-      L2w[row & 63] = row < Tn ? lse[((long)b * H + h) * Tn + row] : INFINITY;
+      L2w[row & 63] = row < Tn ? -lse[((long)b * H + h) * Tn + row] : -INFINITY;
       L2w[64 + (row & 63)] = part;
       if (row < Tn) delta[((long)b * H + h) * Tn + row] = part;
     }
@@ -619,19 +644,33 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
       dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  // masked keys (lane <-> key): exp2(-inf) = 0 through an additive bias instead of a select per score
+  const float kbias[2] = {k0 + r < klen ? 0.f : -INFINITY, k0 + 16 + r < klen ? 0.f : -INFINITY};
+  // dropout: keys 2j and 2j + 1 share one hash word (drop_pair) and sit in neighbouring lanes, so a lane hashes the words of TWO of
+  // its four queries per C tile (4q + 2 par + {0, 1}) and takes the other two from its neighbour (one DPP move per word).
+  // Index = ((b H + h) Tn + query) * pitch + key, split as in the forward: (row base + 64-key tile start) picks the key of the
+  // high word, the tile-relative offset is added to the low word only.
+  const int par = r & 1;
+  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
+  const uint32_t t16 = dspan.k.thresh >> 8;
+  const float inv_keep = dspan.k.inv_keep;
+  const unsigned long long pitch = drop_row_pitch(Tn);
+  const int kt0w = k0 & ~63;
+  const unsigned long long ib0 = (((unsigned long long)b * H + h) * Tn + 4 * q + 2 * par) * pitch + kt0w;
+  const uint32_t koff = (uint32_t)(k0 - kt0w) + (uint32_t)(r & ~1);
+  const uint32_t hshift = 16u * par;
   __syncthreads();
 
   const int nstep = (Tn + 31) / 32;  // 32-query steps
-  const int nkc = (Tn + 31) / 32;    // 32-key chunks of the dQ contraction
-  const int i16 = r, qq = i16 >> 2, pp = i16 & 3;
+  const int qq = r >> 2, pp = r & 3;
   for (int st = 0; st < nstep; ++st) {
-    const int m2 = st & 1, qt0 = (st >> 1) * 64;
+    const int m2 = st & 1;
     const unsigned char* Qs = lds + (st >> 1) * PAIR;
     const unsigned char* Os = Qs + 64 * RS;
     const float* L2s = reinterpret_cast<const float*>(Qs + 2 * 64 * RS);
     const float* Dls = L2s + 64;
     unsigned char* Sb = Sc + (st & 1) * 256 * FUSED_SRS;
-    f32x4 pd[2][2], ds[2][2];  // [half][kt]
+    uint2 pdp[2][2], dsp[2][2];  // packed bf16 P.drop and dS, [half][kt]
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int qb = 2 * m2 + half;
@@ -647,54 +686,73 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
           dp[kt] = mma(ao, vf[kt][ks], dp[kt]);
         }
       }
+      const f32x4 nl = *reinterpret_cast<const f32x4*>(L2s + 16 * qb + 4 * q);  // -lse of queries 4q .. 4q + 3
+      const f32x4 dl = *reinterpret_cast<const f32x4*>(Dls + 16 * qb + 4 * q);
+      uint32_t hw[2][4];  // [kt][e] hash words
+      if (DROP) {
+        uint32_t mine[2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const unsigned long long rb = ib0 + (unsigned long long)(st * 32 + 16 * half + jj) * pitch;
+          const uint32_t key = (uint32_t)(rb >> 32) == dspan.hi0 ? dspan.k.k : dspan.k_next;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) mine[kt][jj] = fh_mix32(((uint32_t)rb + koff + 16u * kt) ^ key);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[kt][jj], 0xB1, 0xf, 0xf, true);  // lane ^ 1
+            hw[kt][jj] = par ? other : mine[kt][jj];
+            hw[kt][2 + jj] = par ? mine[kt][jj] : other;
+          }
+      }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        const int key = k0 + 16 * kt + r;
+        float pdv[4], dsv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int ql = 16 * qb + 4 * q + e;
-          const int query = qt0 + ql;
-          float p = key < klen ? exp2f(s[kt][e] * scale_log2e - L2s[ql]) : 0.f;
+          const float p = fast_exp2(fmaf(s[kt][e], scale_log2e, nl[e] + kbias[kt]));
           float dsc = 1.f;
-          if (drop.p > 0.f) {
-            const int kt0 = key & ~63;
-            const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * drop_row_pitch(Tn) + kt0;
-            dsc = drop_pair_one(drop_key_at(dspan, rowbase), (uint32_t)rowbase + (key - kt0));
-          }
-          pd[half][kt][e] = p * dsc;
-          ds[half][kt][e] = p * (dp[kt][e] * dsc - Dls[ql]) * scale;
+          if (DROP) dsc = __builtin_amdgcn_ubfe(hw[kt][e], hshift, 16u) >= t16 ? inv_keep : 0.f;
+          pdv[e] = p * dsc;
+          dsv[e] = (p * scale) * fmaf(dp[kt][e], dsc, -dl[e]);
         }
+        pdp[half][kt] = make_uint2(pack_bf16x2(pdv[0], pdv[1]), pack_bf16x2(pdv[2], pdv[3]));
+        dsp[half][kt] = make_uint2(pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3]));
         // dS^T block of this wave: row = key, 4 consecutive queries per lane
-        uint2 pk;
-        pk.x = bf16_bits(ds[half][kt][0]) | (bf16_bits(ds[half][kt][1]) << 16);
-        pk.y = bf16_bits(ds[half][kt][2]) | (bf16_bits(ds[half][kt][3]) << 16);
-        *reinterpret_cast<uint2*>(Sb + (k0 + 16 * kt + r) * FUSED_SRS + (16 * half + 4 * q) * 2) = pk;
+        *reinterpret_cast<uint2*>(Sb + (k0 + 16 * kt + r) * FUSED_SRS + (16 * half + 4 * q) * 2) = dsp[half][kt];
       }
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      mma_transposed<T, NDT>(Os, m2, pd[0][kt], pd[1][kt], dv[kt], lane);
-      mma_transposed<T, NDT>(Qs, m2, ds[0][kt], ds[1][kt], dk[kt], lane);
+      mma_transposed_packed<NDT>(Os, m2, pdp[0][kt], pdp[1][kt], dv[kt], lane);
+      mma_transposed_packed<NDT>(Qs, m2, dsp[0][kt], dsp[1][kt], dk[kt], lane);
     }
     __syncthreads();
-    if (wave < 2 * NDT) {  // dQ^T tile (16 d x 16 queries) of this step: K^T [d][keys] . dS^T [keys][queries]
+    if (wave < 2 * NDT) {  // dQ^T tile (16 d x 16 queries) of this step: K^T [d][keys] . dS^T [keys][queries], all 256 key rows
       const int qb2 = wave / NDT, dt = wave - qb2 * NDT;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int kc = 0; kc < nkc; ++kc) {
-        const unsigned char* a0 = Kt + (32 * kc + 4 * q + qq) * RS + (16 * dt + 4 * pp) * 2;
-        const unsigned char* b0 = Sb + (32 * kc + 4 * q + qq) * FUSED_SRS + (16 * qb2 + 4 * pp) * 2;
-        union { struct { s16x4 lo, hi; } s; bf16x8 v; } ua, ub;
-        ua.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-        ua.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * RS));
-        ub.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b0);
-        ub.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + 16 * FUSED_SRS));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc, 0, 0, 0);
+      const unsigned char* a0 = Kt + (4 * q + qq) * RS + (16 * dt + 4 * pp) * 2;
+      const unsigned char* b0 = Sb + (4 * q + qq) * FUSED_SRS + (16 * qb2 + 4 * pp) * 2;
+      union { struct { s16x4 lo, hi; } s; bf16x8 v; } ua[8], ub[8];
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        ua[kc].s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 32 * kc * RS));
+        ua[kc].s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (32 * kc + 16) * RS));
+        ub[kc].s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + 32 * kc * FUSED_SRS));
+        ub[kc].s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + (32 * kc + 16) * FUSED_SRS));
+      }
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};  // two chains: half the MFMA dependency latency
+#pragma unroll
+      for (int kc = 0; kc < 8; kc += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua[kc].v, ub[kc].v, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua[kc + 1].v, ub[kc + 1].v, acc1, 0, 0, 0);
       }
       const int query = st * 32 + 16 * qb2 + r, d = 16 * dt + 4 * q;
       if (query < Tn && d < dh) {
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[e];
+        for (int e = 0; e < 4; ++e) v[e] = acc0[e] + acc1[e];
         st4(dqkv + ((long)b * Tn + query) * ld + h * dh + d, v);
       }
     }
@@ -771,9 +829,15 @@ template <int NDT>
 int bwd_fused_launch(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, float* delta, bf16* dqkv,
                      const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
   const size_t smem = 4 * (2 * 64 * AT<bf16>::RS + 512) + 256 * AT<bf16>::RS + 2 * 256 * FUSED_SRS;
-  set_lds(attn_bwd_fused_kernel<NDT>, smem);
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<NDT>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len, B, Tn,
-                     H, dh, scale, sl2, drop);
+  if (drop.p > 0.f) {
+    set_lds(attn_bwd_fused_kernel<NDT, true>, smem);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NDT, true>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
+                       B, Tn, H, dh, scale, sl2, drop);
+  } else {
+    set_lds(attn_bwd_fused_kernel<NDT, false>, smem);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NDT, false>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
+                       B, Tn, H, dh, scale, sl2, drop);
+  }
   FH_CHECK_LAUNCH();
   return 0;
 }
