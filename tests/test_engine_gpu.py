@@ -383,3 +383,64 @@ def test_full_size_properties_10s():
     assert abs(l_all - 0.5 * (l_a + l_b)) < 2e-3 * abs(l_all)
     # the conv-0 GroupNorm statistics are per utterance, LayerNorms per frame: nothing couples batch items, so gradients add
     assert _rel_l2(g_all, 0.5 * (g_a + g_b)) < 2e-2
+
+
+@pytest.mark.parametrize("samples,lengths", [(32000, None), (32000, [32000, 25000]), (24000, None)])
+def test_training_mode_gradients_match_finite_differences_with_dropout_on(samples, lengths):
+    """With dropout ON every mask is a pure function of (seed, site, index), so the training loss is a deterministic
+    differentiable function of the parameters: its central finite difference along random directions must match grads . v.
+    This is the check that every backward kernel regenerates exactly the forward's mask (frame counts here are odd --
+    T' = 99 / 74, T2 = 49 / 37 -- the case where an index-pairing bug once hid).  fp32 engine; tolerance 2 % of |grads . v|."""
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=2)
+    eng, sd = _engine(cfg, 4, "float32")
+    B = 2
+    g = torch.Generator().manual_seed(1)
+    wav = (0.5 * torch.randn(B, samples, generator=g)).to(DEV)
+    if lengths is not None:
+        for b, n in enumerate(lengths):
+            wav[b, n:] = 0
+    Tp, T2 = eng.frames(samples)
+    teacher = torch.randn(2, B, Tp, 768, generator=g).to(DEV)
+    w = torch.tensor([0.1, 1.0], device=DEV)
+    tl = torch.arange(2, dtype=torch.int32, device=DEV)
+
+    def loss_only():
+        ws = eng.forward(wav, lengths, training=True, seed=77)
+        out, dp = eng.kd_loss(ws, teacher, w, tl)
+        return ws, out[-1].item(), dp
+
+    ws, l0, dp = loss_only()
+    eng.grads.zero_()
+    eng.backward(ws, d_pred=dp)
+    grads = eng.grads.double().clone()
+    base = eng.params.clone()
+    views = eng.param_views(torch.arange(eng.n_params, device=DEV))  # name -> flat indices
+    groups = {
+        "all": None,
+        "encoder layers": [k for k in views if k.startswith("encoder.layers.")],
+        "frontend": [k for k in views if k.startswith("feature_extractor.") or k.startswith("post_extract_proj") or k.startswith("layer_norm")],
+        "pos_conv": [k for k in views if k.startswith("encoder.pos_conv")],
+        "heads": [k for k in views if k.startswith("proj_head.")],
+    }
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    for name, keys in groups.items():
+        v = torch.zeros(eng.n_params, device=DEV, dtype=torch.float64)
+        if keys is None:
+            sel = torch.arange(eng.n_params, device=DEV)
+        else:
+            assert keys, name
+            sel = torch.cat([views[k].reshape(-1) for k in keys])
+        # direction: random signs scaled by each parameter's magnitude floor, so that every tensor contributes
+        v[sel] = (torch.randint(0, 2, (sel.numel(),), device=DEV, generator=gen).double() * 2 - 1) * (base[sel].abs().double() + 1e-2)
+        ana = float((grads * v).sum().item())
+        eps = 2e-3
+        vals = []
+        for sgn in (+1, -1):
+            eng.params.copy_((base.double() + sgn * eps * v).float())
+            eng.version += 1
+            vals.append(loss_only()[1])
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(fd - ana) <= 0.02 * abs(ana) + 1e-6, (name, fd, ana, l0)
+    eng.params.copy_(base)
+    eng.version += 1
