@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t fh_mix32(uint32_t x) {
 }
 typedef fh_drop DropCfg;  // {p, seed, site}
 // Split form: the per-site key (depends on seed, site and the HIGH index word only) is hoisted out of inner loops; per
-// element it is one 32-bit mix + an integer compare.  keep  <=>  top 24 hash bits >= p * 2^24.
+// pair of elements it is one 32-bit mix + two integer compares (drop_apply / drop_pair below).
 struct DropKey {
   uint32_t k;
   uint32_t thresh;
@@ -155,9 +155,12 @@ __device__ __forceinline__ DropKey drop_key(const DropCfg& d, uint32_t idx_hi) {
   r.inv_keep = 1.0f / (1.0f - d.p);
   return r;
 }
+// Pair form: ONE hash word serves the two adjacent indices 2j and 2j + 1, 16 random bits each (keep <=> 16 bits >= p * 2^16).
+// Every mask in the library is this function of (seed, site, index); vector callers hash once per pair.
 __device__ __forceinline__ float drop_apply(const DropKey& k, uint32_t idx_lo) {
-  const uint32_t h = fh_mix32(idx_lo ^ k.k);
-  return (h >> 8) >= k.thresh ? k.inv_keep : 0.0f;
+  const uint32_t h = fh_mix32((idx_lo & ~1u) ^ k.k);
+  const uint32_t u = (idx_lo & 1u) ? (h >> 16) : (h & 0xffffu);
+  return u >= (k.thresh >> 8) ? k.inv_keep : 0.0f;
 }
 __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
   return drop_apply(drop_key(d, (uint32_t)(idx >> 32)), (uint32_t)idx);
@@ -181,27 +184,27 @@ __device__ __forceinline__ DropKey drop_key_at(const DropKeySpan& s, unsigned lo
   k.k = (uint32_t)(idx >> 32) == s.hi0 ? s.k.k : s.k_next;
   return k;
 }
-// N consecutive elements starting at an index that is a multiple of N (N <= 8): one key for all of them -- the low word
-// cannot carry into the high word inside an aligned group.  (drop_scale per element re-derived the key, a hash and an IEEE
-// division, for every element.)
-template <int N> __device__ __forceinline__ void drop_scale_vec(const DropCfg& d, unsigned long long idx, float* v) {
-  const DropKey k = drop_key(d, (uint32_t)(idx >> 32));
-  const uint32_t lo = (uint32_t)idx;
-#pragma unroll
-  for (int e = 0; e < N; ++e) v[e] *= drop_apply(k, lo + e);
-}
-// Pair form (attention probabilities): ONE hash serves the two adjacent even/odd indices, 16 random bits each
-// (keep <=> 16 bits >= p * 2^16).  `idx_lo_even` must be even; s0 / s1 are the scales of idx_lo_even and idx_lo_even + 1.
+// `idx_lo_even` must be even; s0 / s1 are the scales of idx_lo_even and idx_lo_even + 1.
 __device__ __forceinline__ void drop_pair(const DropKey& k, uint32_t idx_lo_even, float& s0, float& s1) {
   const uint32_t h = fh_mix32(idx_lo_even ^ k.k);
   const uint32_t t16 = k.thresh >> 8;
   s0 = (h & 0xffffu) >= t16 ? k.inv_keep : 0.0f;
   s1 = (h >> 16) >= t16 ? k.inv_keep : 0.0f;
 }
-__device__ __forceinline__ float drop_pair_one(const DropKey& k, uint32_t idx_lo) {
-  const uint32_t h = fh_mix32((idx_lo & ~1u) ^ k.k);
-  const uint32_t u = (idx_lo & 1u) ? (h >> 16) : (h & 0xffffu);
-  return u >= (k.thresh >> 8) ? k.inv_keep : 0.0f;
+__device__ __forceinline__ float drop_pair_one(const DropKey& k, uint32_t idx_lo) { return drop_apply(k, idx_lo); }
+// N consecutive elements starting at an index that is a multiple of N (N even, <= 8): one key for all of them -- the low word
+// cannot carry into the high word inside an aligned group -- and one hash per two elements.
+template <int N> __device__ __forceinline__ void drop_scale_vec(const DropCfg& d, unsigned long long idx, float* v) {
+  static_assert(N % 2 == 0, "pair form");
+  const DropKey k = drop_key(d, (uint32_t)(idx >> 32));
+  const uint32_t lo = (uint32_t)idx;
+#pragma unroll
+  for (int e = 0; e < N; e += 2) {
+    float s0, s1;
+    drop_pair(k, lo + e, s0, s1);
+    v[e] *= s0;
+    v[e + 1] *= s1;
+  }
 }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)

@@ -1534,6 +1534,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
       }
       add(2, ring_splitk(p, 128, 128, 1024));
     } else {
+      add(0, p.splitk);
       if (ring_ok(p, 64)) add(3, p.splitk);
       if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); add(6, p.splitk); }
       if (ring_ok(p, 64)) add(7, p.splitk);
