@@ -19,6 +19,8 @@ import torch.distributed as dist
 
 def init_distributed(backend: Optional[str] = None) -> tuple:
     """(rank, world, local_rank) from the torchrun environment; initialises the default group when WORLD_SIZE > 1."""
+    # the host driver of this pool only supports dmabuf IPC; RCCL's peer mappings fail with the legacy mode (set before HIP starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
