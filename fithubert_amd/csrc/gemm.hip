@@ -328,12 +328,39 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     }
     return;
   }
+  // a lane keeps ONE 8-column group j for all its rows: the bias vector, the column bound and the index bases are hoisted out of
+  // the row loop, and the row -> (batch, frame) map, the output offset and the dropout index advance incrementally (the integer
+  // division / modulo and the 64-bit multiplies of the straightforward form cost more VALU than the GELU for plain epilogues)
+  const int j = j0 + yj0 + 8 * (lane & 7);
+  if (j >= p.N) return;
+  const int i_first = i0 + xi0 + 32 * h + (lane >> 3);
+  if (i_first >= p.M) return;
+  float bv[8];
+  if (ep.bias) {
+    const float* bp = ep.bias + (long)g * ep.bias_gstride + (ep.bias_mod > 0 ? (j % ep.bias_mod) : j);
+    ld4(bp, bv);
+    ld4(bp + 4, bv + 4);
+  }
+  RowMap rm = map_row(i_first, p.c_rpb);
+  long coff = (long)g * p.c_gstride + (long)rm.b * p.c_bstride + (long)rm.t * p.ldc + j;
+  unsigned long long didx = ((unsigned long long)g * p.M + i_first) * (unsigned long long)p.N + j;
+  const long wrap = p.c_bstride - (long)p.c_rpb * p.ldc;  // offset correction when a row step crosses into the next batch entry
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int rl = it * 8 + (lane >> 3);
-    const int i = i0 + xi0 + 32 * h + rl;
-    const int j = j0 + yj0 + 8 * (lane & 7);
-    if (i >= p.M || j >= p.N) continue;
+    const int i = i_first + it * 8;
+    if (i >= p.M) break;
+    if (it > 0) {
+      rm.t += 8;
+      coff += 8L * p.ldc;
+      didx += 8ULL * (unsigned long long)p.N;
+      if (p.c_rpb > 0)
+        while (rm.t >= p.c_rpb) {
+          rm.t -= p.c_rpb;
+          ++rm.b;
+          coff += wrap;
+        }
+    }
     float v[8];
     {
       const f32x4 a = *reinterpret_cast<const f32x4*>(my + rl * EPI_ROW + (lane & 7) * 32);
@@ -344,13 +371,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
         v[4 + e] = b[e] * ep.alpha;
       }
     }
-    RowMap rm = map_row(i, p.c_rpb);
-    const long coff = (long)g * p.c_gstride + (long)rm.b * p.c_bstride + (long)rm.t * p.ldc + j;
     if (ep.bias) {
-      const float* bp = ep.bias + (long)g * ep.bias_gstride + (ep.bias_mod > 0 ? (j % ep.bias_mod) : j);
-      float bv[8];
-      ld4(bp, bv);
-      ld4(bp + 4, bv + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bv[e];
     }
@@ -359,10 +380,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
     }
-    if (ep.drop.p > 0.f) {
-      const unsigned long long didx = ((unsigned long long)g * p.M + i) * (unsigned long long)p.N + j;
-      drop_scale_vec<8>(ep.drop, didx, v);
-    }
+    if (ep.drop.p > 0.f) drop_scale_vec<8>(ep.drop, didx, v);
     if (ep.gelu_aux) {
       float a[8];
       ld8<T>(reinterpret_cast<const T*>(ep.gelu_aux) + coff, a);
