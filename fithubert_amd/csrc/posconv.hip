@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) wn_norm2_kernel(const float* __restrict__
   if (threadIdx.x == 0) norm2[j] = red[0];
 }
 
-// w_fwd[g][j][co][ci] = w[g*cg+co][ci][j] ; w_bwd[g][j'][ci][co] = w[g*cg+co][ci][K-1-j']  (zero padded to CP)
+// w_fwd[g][j][co][ci] = w[g*cg+co][ci][j] ; w_bwd[g][j'][ci][co] = w[g*cg+co][ci][K-1-j']  (zero padded to CP; fp32 as written,
+// bf16 with each tap's [CP][CP] block permuted into MFMA-fragment order)
 template <typename T, int CP>
 __global__ void wn_layout_kernel(const float* __restrict__ gsc, const float* __restrict__ v,
                                  const float* __restrict__ norm2, T* __restrict__ w_fwd, T* __restrict__ w_bwd,
@@ -66,8 +67,15 @@ __global__ void wn_layout_kernel(const float* __restrict__ gsc, const float* __r
     const int jj = K - 1 - j;
     wb = gsc[jj] * v[((long)(g * cg + b) * cg + a) * K + jj] * rsqrtf(norm2[jj]);
   }
-  w_fwd[o] = from_f<T>(wf);
-  w_bwd[o] = from_f<T>(wb);
+  long dst = o;
+  if constexpr (sizeof(T) == 2) {
+    // bf16: MFMA-fragment order -- the 64 lanes x 8 elements of one (tap, k-slab, 16-row block) A operand are contiguous, so a
+    // wave's weight load is 8 full cache lines (with 64-wide rows the [row][col] order made it 16 half lines; see posconv_wide.hip)
+    const int ks = b / 32, qq = (b % 32) / 8, e = b % 8, cb = a / 16, rr = a % 16;
+    dst = (((((long)g * K + j) * (CP / 32) + ks) * (CP / 16) + cb) * 64 + (qq * 16 + rr)) * 8 + e;
+  }
+  w_fwd[dst] = from_f<T>(wf);
+  w_bwd[dst] = from_f<T>(wb);
 }
 
 // ---------------------------------------------------------------- fragment helpers
@@ -78,8 +86,8 @@ template <int CP> struct Frag<bf16, CP> {
   static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int kr) {
     return *reinterpret_cast<const bf16x8*>(lds + row * PC<bf16, CP>::RS + kr * 64 + (lane >> 4) * 16);
   }
-  static __device__ __forceinline__ type gmem_row(const bf16* w, int row, int lane, int kr) {
-    return *reinterpret_cast<const bf16x8*>(w + (long)row * CP + kr * 32 + (lane >> 4) * 8);
+  static __device__ __forceinline__ type gmem_frag(const bf16* wtap, int cb, int lane, int kr) {  // fragment-order layout
+    return *reinterpret_cast<const bf16x8*>(wtap + ((kr * (CP / 16) + cb) * 64 + lane) * 8);
   }
   static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -91,8 +99,8 @@ template <int CP> struct Frag<float, CP> {
   static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int kr) {
     return *reinterpret_cast<const f32x4*>(lds + row * PC<float, CP>::RS + kr * 64 + (lane >> 4) * 16);
   }
-  static __device__ __forceinline__ type gmem_row(const float* w, int row, int lane, int kr) {
-    return *reinterpret_cast<const f32x4*>(w + (long)row * CP + kr * 16 + (lane >> 4) * 4);
+  static __device__ __forceinline__ type gmem_frag(const float* wtap, int cb, int lane, int kr) {  // [row][col] layout
+    return *reinterpret_cast<const f32x4*>(wtap + (long)(cb * 16 + (lane & 15)) * CP + kr * 16 + (lane >> 4) * 4);
   }
   static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) {
 #pragma unroll
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
 #pragma unroll
   for (int kr = 0; kr < F::NK; ++kr)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) wn[kr][cb] = F::gmem_row(wg, cb * 16 + r, lane, kr);
+    for (int cb = 0; cb < CB; ++cb) wn[kr][cb] = F::gmem_frag(wg, cb, lane, kr);
 #pragma unroll 2
   for (int j = 0; j < K; ++j) {
     typename F::type wf[F::NK][CB];
@@ -180,7 +188,7 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
 #pragma unroll
     for (int kr = 0; kr < F::NK; ++kr)
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) wn[kr][cb] = F::gmem_row(wg + (long)jn * CP * CP, cb * 16 + r, lane, kr);
+      for (int cb = 0; cb < CB; ++cb) wn[kr][cb] = F::gmem_frag(wg + (long)jn * CP * CP, cb, lane, kr);
 #pragma unroll
     for (int kr = 0; kr < F::NK; ++kr) {
       typename F::type xf[NTT];

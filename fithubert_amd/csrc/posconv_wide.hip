@@ -2,14 +2,16 @@
 // Conv1d(768, 768, k=128, pad=64, groups=16) + SamePad + GELU + residual (fairseq HubertModel.encoder.pos_conv, used by
 // the reference through utils/utils.py:84-88).  Same scheme as posconv.hip (window staged once in LDS, one tap = one
 // MFMA K-slab over the group's input channels, weights streamed from L2) with the channel padding at 64.
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.h"
 
 namespace {
 
 constexpr int CPW = 64;
-constexpr int TTW = 256;   // frames per workgroup: 4 waves x 64 frames (each tap's weight fragments serve 4 frame tiles)
-constexpr int NTT = TTW / 64;  // 16-frame tiles per wave
+// frames per workgroup = 4 waves x 16 NTT frames: each tap's weight fragments (streamed from L2 by every wave) serve NTT frame
+// tiles, so NTT sets the L2 traffic per MFMA
 
 template <typename T> struct PW { static constexpr int RS = CPW * (int)sizeof(T) + 16; };
 
@@ -40,7 +42,16 @@ __global__ void wnw_layout_kernel(const float* __restrict__ gsc, const float* __
   const int j = (int)((o / (CPW * CPW)) % K), g = (int)(o / ((long)CPW * CPW * K));
   float w = 0.f;
   if (co < cg && ci < cg) w = gsc[j] * v[((long)(g * cg + co) * cg + ci) * K + j] * rsqrtf(norm2[j]);
-  w_fwd[o] = from_f<T>(w);
+  if constexpr (sizeof(T) == 2) {
+    // bf16: MFMA-fragment order -- the 64 lanes x 8 elements of one (tap, k-slab, 16-channel block) A operand are contiguous
+    // (1 KiB = 8 full cache lines per wave load; in [co][ci] order the same load touched 16 half lines and the CU's vector
+    // memory path, not the MFMA, set the pace)
+    const int ks = ci / 32, qq = (ci % 32) / 8, e = ci % 8, cb = co / 16, rr = co % 16;
+    const long dst = (((((long)g * K + j) * 2 + ks) * 4 + cb) * 64 + (qq * 16 + rr)) * 8 + e;
+    w_fwd[dst] = from_f<T>(w);
+  } else {
+    w_fwd[o] = from_f<T>(w);
+  }
 }
 
 __device__ __forceinline__ void ld2w(const float* p, float* f) {
@@ -57,7 +68,7 @@ __device__ __forceinline__ void st2w(bf16* p, const float* f) {
   *reinterpret_cast<uint32_t*>(p) = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
 }
 
-template <typename T>
+template <typename T, int NTT>
 __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                            const float* __restrict__ bias, T* __restrict__ y, int B, int Tn,
                                                            int D, int cg, int K, int pad_left) {
@@ -65,6 +76,7 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
   constexpr int RS = PW<T>::RS;
   constexpr bool IS_BF = sizeof(T) == 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  constexpr int TTW = 64 * NTT;
   const int t0 = blockIdx.x * TTW, g = blockIdx.y, b = blockIdx.z;
   const int nrows = TTW + K - 1;
   const int units = CPW / 2;
@@ -84,36 +96,38 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
     for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * K * CPW * CPW;
   if constexpr (IS_BF) {
-    // next tap's weight fragments are loaded (from L2) while this tap's MFMAs run
-    bf16x8 wn[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-        wn[ks][cb] = *reinterpret_cast<const bf16x8*>(wg + (long)(cb * 16 + r) * CPW + ks * 32 + q * 8);
-    for (int j = 0; j < K; ++j) {
-      bf16x8 wf[2][4];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) wf[ks][cb] = wn[ks][cb];
-      const T* wj = wg + (long)(j + 1 < K ? j + 1 : j) * CPW * CPW;
+    // the weight fragments of tap j + 3 are requested (from L2, by every wave) while tap j's MFMAs run: a tap is 24 MFMAs
+    // (~160 ns) and only two waves share a SIMD, so a single tap of look-ahead left the L2 latency exposed.  Ring of four
+    // register buffers, indices resolved at compile time (K % 4 == 0, checked on the host).
+    bf16x8 wr[4][2][4];
+    auto load_tap = [&](int slot, int tap) {
+      const T* wj = wg + (long)(tap < K ? tap : K - 1) * CPW * CPW;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
-          if (cb < ncb) wn[ks][cb] = *reinterpret_cast<const bf16x8*>(wj + (long)(cb * 16 + r) * CPW + ks * 32 + q * 8);
+          if (cb < ncb) wr[slot][ks][cb] = *reinterpret_cast<const bf16x8*>(wj + ((ks * 4 + cb) * 64 + lane) * 8);
+    };
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 xf[NTT];
+    for (int u = 0; u < 3; ++u) load_tap(u, u);
+    for (int j0 = 0; j0 < K; j0 += 4) {
 #pragma unroll
-        for (int tt = 0; tt < NTT; ++tt)
-          xf[tt] = *reinterpret_cast<const bf16x8*>(lds + (wave * (16 * NTT) + tt * 16 + r + j) * RS + ks * 64 + q * 16);
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        load_tap((u + 3) & 3, j + 3);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          if (cb < ncb) {
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 xf[NTT];
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cb], xf[tt], acc[cb][tt], 0, 0, 0);
+          for (int tt = 0; tt < NTT; ++tt)
+            xf[tt] = *reinterpret_cast<const bf16x8*>(lds + (wave * (16 * NTT) + tt * 16 + r + j) * RS + ks * 64 + q * 16);
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            if (cb < ncb) {
+#pragma unroll
+              for (int tt = 0; tt < NTT; ++tt)
+                acc[cb][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[u][ks][cb], xf[tt], acc[cb][tt], 0, 0, 0);
+            }
           }
         }
       }
@@ -187,19 +201,26 @@ extern "C" int fh_posconv_wide_forward(int dtype, const void* x, const void* w_f
                                        int groups, int K, fh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const int cg = D / groups;
-  if (cg > CPW || cg % 2 || K % 2) return -551;
-  dim3 grid((T + TTW - 1) / TTW, groups, B), block(256);
-  if (dtype == 0) {
-    const size_t smem = (size_t)(TTW + K - 1) * PW<float>::RS;
-    hipFuncSetAttribute((const void*)posconv_wide_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(posconv_wide_kernel<float>, grid, block, smem, st, (const float*)x, (const float*)w_fwd, bias, (float*)y, B,
-                       T, D, cg, K, K / 2);
-  } else {
-    const size_t smem = (size_t)(TTW + K - 1) * PW<bf16>::RS;
-    hipFuncSetAttribute((const void*)posconv_wide_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(posconv_wide_kernel<bf16>, grid, block, smem, st, (const bf16*)x, (const bf16*)w_fwd, bias, (bf16*)y, B, T, D,
-                       cg, K, K / 2);
+  if (cg > CPW || cg % 2 || K % 4) return -551;
+  static int ntt = 0;
+  if (!ntt) {
+    const char* e = getenv("FH_POSCONV_WIDE_NTT");
+    ntt = e ? atoi(e) : 4;
+    if (ntt != 4 && ntt != 8) ntt = 4;
   }
+  const int TTW = 64 * ntt;
+  dim3 grid((T + TTW - 1) / TTW, groups, B), block(256);
+#define FH_PW_LAUNCH(TY, NT)                                                                                                   \
+  do {                                                                                                                       \
+    const size_t smem = (size_t)(64 * NT + K - 1) * PW<TY>::RS;                                                              \
+    hipFuncSetAttribute((const void*)posconv_wide_kernel<TY, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);     \
+    hipLaunchKernelGGL((posconv_wide_kernel<TY, NT>), grid, block, smem, st, (const TY*)x, (const TY*)w_fwd, bias, (TY*)y, B, T, D, \
+                       cg, K, K / 2);                                                                                        \
+  } while (0)
+  if (dtype == 0) FH_PW_LAUNCH(float, 4);
+  else if (ntt == 8) FH_PW_LAUNCH(bf16, 8);
+  else FH_PW_LAUNCH(bf16, 4);
+#undef FH_PW_LAUNCH
   FH_CHECK_LAUNCH();
   return 0;
 }
