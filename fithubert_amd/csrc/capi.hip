@@ -13,8 +13,7 @@ int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream) {
 
 long fh_conv0_scratch_floats(int B, int S, int C0, int K, int stride) {
   const int T0 = (S - K) / stride + 1;
-  // float2 partials [B][nchunk][C0] + float2 ab [B][C0]
-  return 2L * B * fh_conv0_nchunk(T0) * C0 + 2L * B * C0;
+  return fh_conv0_scratch_n(B, T0, C0);
 }
 int fh_conv0_forward(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
                      float* mean, float* rstd, float* scratch, int B, int S, int C0, int K, int stride, float eps,

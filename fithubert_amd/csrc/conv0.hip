@@ -9,7 +9,7 @@
 // (utterance, channel) over time, so the un-normalised conv output is never written: pass 1 computes
 // chunk-local (mean, M2) with a pivot (no catastrophic cancellation), a tiny kernel merges chunks with
 // Chan's formula in fp64, pass 2 recomputes the conv (10 FMA/elem) and writes GELU(GN(.)) once.
-// Backward mirrors it: one reduction pass + one pass that accumulates dW (the waveform needs no grad).
+// Backward is ONE pass over dy (by linearity, below) + a tiny combine; the waveform needs no grad.
 #include "common.cuh"
 #include "kernels.h"
 
@@ -173,98 +173,35 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
   }
 }
 
-// ---------------------------------------------------------------- backward pass 1: per-(b,c) sums of g and g*xhat
+// ---------------------------------------------------------------- backward, one pass over dy
+// With g[t] = dy[t] * gelu'(z[t]) and xh the normalised conv output, GroupNorm's backward is
+//   dv[t] = rstd * (gamma g[t] - m1 - xh[t] m2),   m1 = gamma mean_t g,  m2 = gamma mean_t (g xh),
+// and dW[c][j] = sum_t dv[t] x_j[t] with x_j[t] = wave[stride t + j].  m1 / m2 are only known after a full pass over t -- the
+// two-pass form therefore evaluated the conv and gelu' twice per element.  But dW is LINEAR in dv:
+//   dW[c][j] = rstd * ( gamma A_j - m1 Sx_j - m2 * rstd * ((w_c Rx)_j - mean Sx_j) ),   A_j = sum_t g[t] x_j[t],
+// where Sx_j = sum_t x_j[t] and Rx = sum_t x[t] x[t]^T are the waveform sums the forward's statistics pass already uses
+// (sum_t xh[t] x_j[t] = rstd (sum_i w_ci Rx_ij - mean Sx_j)).  So ONE pass accumulates A_j (K values), S1 = sum g and
+// S2 = sum g xh per (utterance, channel, block); a small fp64 combine applies the formula.
+// Partials: wpart[b][blk][c][KT + 2] = A_0 .. A_{KT-1}, S1, S2.
 template <typename T, int KT>
-__global__ void __launch_bounds__(256) conv0_bwd_reduce_kernel(Conv0Args a, const float* mean, const float* rstd,
-                                                               const T* dy, float2* part) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sw = smem;
-  float* red = smem + ((TCH - 1) * a.stride + a.K + MAXK + 3) / 4 * 4;  // [2][256][CV]
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int nt = stage_wave(a, b, chunk, sw);
-  const ChanMap m(a.C0);
-  float w[CV][KT];
-  load_w4<KT>(a, m.c0, w);
-  float mu[CV], rs[CV], ga[CV], be[CV], s1[CV], s2[CV];
-#pragma unroll
-  for (int e = 0; e < CV; ++e) {
-    const int c = m.c0 + e;
-    mu[e] = mean[b * a.C0 + c]; rs[e] = rstd[b * a.C0 + c]; ga[e] = a.gamma[c]; be[e] = a.beta[c];
-    s1[e] = 0.f; s2[e] = 0.f;
-  }
-  const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + m.c0;
-#pragma unroll 2
-  for (int t = m.tl; t < nt; t += m.nlan) {
-    float v[CV], d[CV];
-    ld4(dyp + (long)t * a.C0, d);
-    conv4_at<KT>(sw, w, t, a.stride, v);
-#pragma unroll
-    for (int e = 0; e < CV; ++e) {
-      const float xh = (v[e] - mu[e]) * rs[e];
-      const float g = d[e] * gelu_grad_f(fmaf(xh, ga[e], be[e]));
-      s1[e] += g;
-      s2[e] = fmaf(g, xh, s2[e]);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < CV; ++e) {
-    red[threadIdx.x * CV + e] = s1[e];
-    red[256 * CV + threadIdx.x * CV + e] = s2[e];
-  }
-  __syncthreads();
-  if (m.tl == 0) {
-#pragma unroll
-    for (int e = 0; e < CV; ++e) {
-      float a1 = s1[e], a2 = s2[e];
-      for (int l = 1; l < m.nlan; ++l) {
-        a1 += red[(l * m.ngrp + m.cg) * CV + e];
-        a2 += red[256 * CV + (l * m.ngrp + m.cg) * CV + e];
-      }
-      part[((long)b * a.nchunk + chunk) * a.C0 + m.c0 + e] = make_float2(a1, a2);
-    }
-  }
-}
-
-// per (b, c): A = gamma * mean_t(g), Bq = gamma * mean_t(g * xhat); dgamma += sum g*xhat, dbeta += sum g
-__global__ void conv0_bwd_final_kernel(const float2* part, const float* gamma, float2* ab, float* dgamma, float* dbeta,
-                                       int B, int nchunk, int C0, int T0) {
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C0; c += blockDim.x) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float2 p = part[((long)b * nchunk + k) * C0 + c];
-      s1 += p.x;
-      s2 += p.y;
-    }
-    const double g = gamma[c];
-    ab[b * C0 + c] = make_float2((float)(g * s1 / T0), (float)(g * s2 / T0));
-    atomicAdd(dbeta + c, (float)s1);
-    atomicAdd(dgamma + c, (float)s2);
-  }
-}
-
-// ---------------------------------------------------------------- backward pass 2: dW[c][j] += sum_t dv[t] * wave[stride*t + j]
-template <typename T, int KT>
-__global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, const float* mean, const float* rstd,
-                                                               const float2* ab, const T* dy, float scale, float* dw) {
+__global__ void __launch_bounds__(256) conv0_bwd_onepass_kernel(Conv0Args a, const float* mean, const float* rstd, const T* dy,
+                                                                float* wpart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
   float* red = smem + ((TCH - 1) * a.stride + a.K + MAXK + 3) / 4 * 4;  // [256][CV]
   const int b = blockIdx.y;
   const ChanMap m(a.C0);
-  float w[CV][KT], acc[CV][KT];
+  float w[CV][KT], acc[CV][KT + 2];
   load_w4<KT>(a, m.c0, w);
-  float mu[CV], rs[CV], ga[CV], be[CV], aa[CV], bb[CV];
+  float mu[CV], rs[CV], ga[CV], be[CV];
 #pragma unroll
   for (int e = 0; e < CV; ++e) {
     const int c = m.c0 + e;
     mu[e] = mean[b * a.C0 + c]; rs[e] = rstd[b * a.C0 + c]; ga[e] = a.gamma[c]; be[e] = a.beta[c];
-    const float2 abv = ab[b * a.C0 + c];
-    aa[e] = abv.x; bb[e] = abv.y;
 #pragma unroll
-    for (int j = 0; j < KT; ++j) acc[e][j] = 0.f;
+    for (int j = 0; j < KT + 2; ++j) acc[e][j] = 0.f;
   }
-  // the block walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... keeping its dW partial in registers
+  // the block walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... keeping its partial sums in registers
   for (int chunk = blockIdx.x; chunk < a.nchunk; chunk += gridDim.x) {
     __syncthreads();
     const int nt = stage_wave(a, b, chunk, sw);
@@ -279,7 +216,9 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
       for (int e = 0; e < CV; ++e) {
         const float xh = (v[e] - mu[e]) * rs[e];
         const float g = d[e] * gelu_grad_f(fmaf(xh, ga[e], be[e]));
-        v[e] = rs[e] * (g * ga[e] - aa[e] - xh * bb[e]);  // dv
+        v[e] = g;
+        acc[e][KT] += g;
+        acc[e][KT + 1] = fmaf(g, xh, acc[e][KT + 1]);
       }
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
@@ -289,22 +228,57 @@ __global__ void __launch_bounds__(256) conv0_bwd_weight_kernel(Conv0Args a, cons
       }
     }
   }
+  float* out = wpart + (((long)b * gridDim.x + blockIdx.x) * a.C0 + m.c0) * (KT + 2);
 #pragma unroll
-  for (int j = 0; j < KT; ++j) {
-    if (j < a.K) {
-      __syncthreads();
+  for (int j = 0; j < KT + 2; ++j) {
+    __syncthreads();
 #pragma unroll
-      for (int e = 0; e < CV; ++e) red[threadIdx.x * CV + e] = acc[e][j];
-      __syncthreads();
-      if (m.tl == 0) {
+    for (int e = 0; e < CV; ++e) red[threadIdx.x * CV + e] = acc[e][j];
+    __syncthreads();
+    if (m.tl == 0) {
 #pragma unroll
-        for (int e = 0; e < CV; ++e) {
-          float s = acc[e][j];
-          for (int l = 1; l < m.nlan; ++l) s += red[(l * m.ngrp + m.cg) * CV + e];
-          atomicAdd(dw + (m.c0 + e) * a.K + j, s * scale);
-        }
+      for (int e = 0; e < CV; ++e) {
+        float s = acc[e][j];
+        for (int l = 1; l < m.nlan; ++l) s += red[(l * m.ngrp + m.cg) * CV + e];
+        out[e * (KT + 2) + j] = s;
       }
     }
+  }
+}
+
+// per utterance b: waveform sums from the statistics partials (fp64), then for every channel the formula above
+__global__ void __launch_bounds__(256) conv0_bwd_combine_kernel(const float* spart, const float* wpart, const float* w,
+                                                                const float* gamma, const float* mean, const float* rstd, float* dw,
+                                                                float* dgamma, float* dbeta, int nchunk, int nblk, int C0, int K,
+                                                                int KT, int T0, float scale) {
+  __shared__ double sx[MAXK], rx[MAXK * MAXK];
+  const int b = blockIdx.x;
+  const int ns = K + K * K;
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < nchunk; ++k) acc += (double)spart[((long)b * nchunk + k) * ns + s];
+    if (s < K) sx[s] = acc; else rx[s - K] = acc;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C0; c += blockDim.x) {
+    double A[MAXK], s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < K; ++j) A[j] = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      const float* pp = wpart + (((long)b * nblk + k) * C0 + c) * (KT + 2);
+      for (int j = 0; j < K; ++j) A[j] += (double)pp[j];
+      s1 += (double)pp[KT];
+      s2 += (double)pp[KT + 1];
+    }
+    const double g = gamma[c], rs = rstd[b * C0 + c], mu = mean[b * C0 + c];
+    const double m1 = g * s1 / T0, m2 = g * s2 / T0;
+    for (int j = 0; j < K; ++j) {
+      double q = 0.0;
+      for (int i = 0; i < K; ++i) q += (double)w[c * K + i] * rx[i * K + j];
+      const double sxh = rs * (q - mu * sx[j]);  // sum_t xhat[t] x_j[t]
+      atomicAdd(dw + c * K + j, (float)(rs * (g * A[j] - m1 * sx[j] - m2 * sxh) * (double)scale));
+    }
+    atomicAdd(dbeta + c, (float)s1);
+    atomicAdd(dgamma + c, (float)s2);
   }
 }
 
@@ -316,6 +290,16 @@ size_t smem_bytes(int stride, int K, bool red2) {
 }  // namespace
 
 int fh_conv0_nchunk(int T0) { return (T0 + TCH - 1) / TCH; }
+int fh_conv0_bwd_blocks(int B, int nchunk) {
+  const int per_b = (1024 + B - 1) / B;
+  return nchunk < per_b ? nchunk : (per_b > 1 ? per_b : 1);
+}
+// scratch (floats) shared by forward and backward: float2 partials [B][nchunk][C0] | float2 [B][C0] | backward partial sums
+// [B][blocks][C0][MAXK + 2]
+long fh_conv0_scratch_n(int B, int T0, int C0) {
+  const long nchunk = fh_conv0_nchunk(T0);
+  return 2L * B * nchunk * C0 + 2L * B * C0 + (long)B * fh_conv0_bwd_blocks(B, (int)nchunk) * C0 * (MAXK + 2);
+}
 
 int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, float2* part, int B, int S, int C0, int K, int stride, float eps,
@@ -353,22 +337,21 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
   a.T0 = (S - K) / stride + 1;
   a.nchunk = fh_conv0_nchunk(a.T0);
   dim3 grid(a.nchunk, B), block(256);
-#define FH_C0_RED(T, KT) \
-  hipLaunchKernelGGL((conv0_bwd_reduce_kernel<T, KT>), grid, block, smem_bytes(stride, K, true), st, a, mean, rstd, (const T*)dy, part)
-  if (dtype == 0) { if (K == 10) FH_C0_RED(float, 10); else FH_C0_RED(float, MAXK); }
-  else { if (K == 10) FH_C0_RED(bf16, 10); else FH_C0_RED(bf16, MAXK); }
-#undef FH_C0_RED
+  // statistics partials of the waveform (the same pass as the forward's) -> `part`, read as floats [B][nchunk][K + K*K]
+  if (K + K * K > 2 * C0) return -202;
+  hipLaunchKernelGGL(conv0_stats_kernel, grid, dim3(128), smem_bytes(stride, K, false), st, a, (float*)part);
   FH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3(B), dim3(256), 0, st, part, gamma, ab, dgamma, dbeta, B, a.nchunk, C0,
-                     a.T0);
-  FH_CHECK_LAUNCH();
-  const int per_b = (1024 + B - 1) / B;  // ~1024 blocks in total; each flushes its dW partial once
-  dim3 wgrid(min(a.nchunk, max(1, per_b)), B);
+  const int nblk = fh_conv0_bwd_blocks(B, a.nchunk);  // ~1024 blocks in total; each writes its partial sums once
+  dim3 wgrid(nblk, B);
+  float* wpart = (float*)(ab + (long)B * C0);
 #define FH_C0_WG(T, KT) \
-  hipLaunchKernelGGL((conv0_bwd_weight_kernel<T, KT>), wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, ab, (const T*)dy, grad_scale, dw)
+  hipLaunchKernelGGL((conv0_bwd_onepass_kernel<T, KT>), wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (const T*)dy, wpart)
   if (dtype == 0) { if (K == 10) FH_C0_WG(float, 10); else FH_C0_WG(float, MAXK); }
   else { if (K == 10) FH_C0_WG(bf16, 10); else FH_C0_WG(bf16, MAXK); }
 #undef FH_C0_WG
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv0_bwd_combine_kernel, dim3(B), dim3(256), 0, st, (const float*)part, (const float*)wpart, w, gamma, mean,
+                     rstd, dw, dgamma, dbeta, a.nchunk, nblk, C0, K, K == 10 ? 10 : MAXK, a.T0, grad_scale);
   FH_CHECK_LAUNCH();
   return 0;
 }

@@ -321,10 +321,7 @@ struct Plan {
     }
     c0_mean = ws.add("c0_mean", {B, c.conv_dim[0]}, 4);
     c0_rstd = ws.add("c0_rstd", {B, c.conv_dim[0]}, 4);
-    {
-      const long nchunk = fh_conv0_nchunk(sh.T[0]);
-      c0_scratch = ws.add("c0_scratch", {2 * B * nchunk * c.conv_dim[0] + 2 * B * c.conv_dim[0]}, 4);
-    }
+    c0_scratch = ws.add("c0_scratch", {fh_conv0_scratch_n((int)B, sh.T[0], c.conv_dim[0])}, 4);
     const long E = c.conv_dim[c.n_conv - 1];
     ln0 = ws.add("ln0", {Mp, E}, es);
     ln0_mean = ws.add("ln0_mean", {Mp}, 4);

@@ -5,6 +5,8 @@
 
 // ---- conv0.hip : Conv1d(1, C0, k, s) + GroupNorm(C0, C0) + GELU
 int fh_conv0_nchunk(int T0);
+int fh_conv0_bwd_blocks(int B, int nchunk);
+long fh_conv0_scratch_n(int B, int T0, int C0);  // floats of scratch for fh_conv0_fwd_launch / fh_conv0_bwd_launch (part | ab | backward partials)
 int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, float2* part, int B, int S, int C0, int K, int stride, float eps,
                         hipStream_t st);
