@@ -430,6 +430,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+// (logical tile, reduction split) of this workgroup.  A split-K launch is a (tiles, splits) grid dispatched x-fastest, so the
+// tiles of ONE split -- which re-read the same reduction slab of an operand (a weight gradient with 3 column tiles read dY three
+// times) -- would sit on different XCDs; remapping the flattened id keeps them back to back on one XCD's L2.
+// It is a per-shape choice (bit 16 of fh_gemm_desc.splitk, set by the tuner): the layer weight gradients gain ~10 %, the long
+// conv-layer reductions (one row tile, 171 splits) lose as much.
+constexpr int FH_SPLIT_REMAP = 1 << 16;
+struct LogicalBlock { int lb, split; };
+__device__ __forceinline__ LogicalBlock logical_block(int splitk_field) {
+  if (gridDim.y == 1 || !(splitk_field & FH_SPLIT_REMAP)) return {xcd_remap(blockIdx.x, gridDim.x), (int)blockIdx.y};
+  const int l = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int sp = l / (int)gridDim.x;
+  return {l - sp * (int)gridDim.x, sp};
+}
 
 // ------------------------------------------------------------------ bf16 main loop on 32x32x16 MFMA (register-staged tiles)
 // Half as many MFMA and LDS-read instructions per K-tile as the 16x16x32 form (16 + 16 vs 32 + 32 per wave): the student's
@@ -467,13 +480,14 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
   const int tiles_j = (p.N + BN - 1) / BN;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const LogicalBlock lblk = logical_block(p.splitk);
+  const int lb = lblk.lb;
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * BM, j0 = tj * BN;
   const int tiles_per_seg = (p.Kseg + BK - 1) / BK;
   const int ntiles = tiles_per_seg * p.X.nseg;
-  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
-  const int t0 = blockIdx.y * per_split;
+  const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
   if (t0 >= t1) return;
 
@@ -551,14 +565,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
   const int tiles_j = (p.N + BN - 1) / BN;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const LogicalBlock lblk = logical_block(p.splitk);
+  const int lb = lblk.lb;
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * BM, j0 = tj * BN;
 
   const int tiles_per_seg = (p.Kseg + BK - 1) / BK;
   const int ntiles = tiles_per_seg * p.X.nseg;
-  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
-  const int t0 = blockIdx.y * per_split;
+  const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
   if (t0 >= t1) return;  // (only possible in atomic split-K mode)
 
@@ -818,13 +833,14 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
   const int tiles_j = (p.N + BN_ - 1) / BN_;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const LogicalBlock lblk = logical_block(p.splitk);
+  const int lb = lblk.lb;
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * BM_, j0 = tj * BN_;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
   const int ntiles = tiles_per_seg * p.X.nseg;
-  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
-  const int t0 = blockIdx.y * per_split;
+  const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
   if (t0 >= t1) return;
   const int nt = t1 - t0;
@@ -928,7 +944,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
 
 template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM - 1) / BM, tiles_j = (p.N + BN - 1) / BN;
-  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(256);
+  dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(256);
   const int xl = p.X.layout, yl = p.Y.layout;
   if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
     hipLaunchKernelGGL((gemm_kernel<T, FH_R_CONTIG, FH_R_CONTIG>), grid, block, 0, stream, p);
@@ -944,7 +960,7 @@ template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
 
 int launch_32(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM - 1) / BM, tiles_j = (p.N + BN - 1) / BN;
-  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(256);
+  dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(256);
   const int xl = p.X.layout, yl = p.Y.layout;
   if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
     hipLaunchKernelGGL((gemm32_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, 0, stream, p);
@@ -978,13 +994,14 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
   const int tiles_j = (p.N + BN_ - 1) / BN_;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const LogicalBlock lblk = logical_block(p.splitk);
+  const int lb = lblk.lb;
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * BM_, j0 = tj * BN_;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
   const int ntiles = tiles_per_seg * p.X.nseg;
-  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
-  const int t0 = blockIdx.y * per_split;
+  const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
   if (t0 >= t1) return;
   const int nt = t1 - t0;
@@ -1098,7 +1115,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
 
 int launch_pp(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256;
-  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(512);
+  dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(512);
   const size_t smem = (size_t)4 * 512 * 32 * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1289,13 +1306,14 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.z;
   const int tiles_j = (p.N + 255) / 256;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const LogicalBlock lblk = logical_block(p.splitk);
+  const int lb = lblk.lb;
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * 256, j0 = tj * 256;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
   const int ntiles = tiles_per_seg * p.X.nseg;
-  const int per_split = (ntiles + p.splitk - 1) / p.splitk;
-  const int t0 = blockIdx.y * per_split;
+  const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
   if (t0 >= t1) return;
   const int nt = t1 - t0;
@@ -1420,7 +1438,7 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
 
 int launch_8ph(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256;
-  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(512);
+  dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(512);
   const size_t smem = 131072;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1445,7 +1463,7 @@ int launch_8ph(const GemmParams& p, hipStream_t stream) {
 
 template <int BM_, int BN_, int WM, int WN, int BK_, int NST> int launch_ring(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM_ - 1) / BM_, tiles_j = (p.N + BN_ - 1) / BN_;
-  dim3 grid(tiles_i * tiles_j, p.splitk, p.groups), block(WM * WN * 64);
+  dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(WM * WN * 64);
   const size_t smem = (size_t)NST * (BM_ + BN_) * BK_ * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1546,9 +1564,14 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
   const long red = (long)p.Kseg * p.X.nseg;
   if (red >= 256) {
     if (p.ep.atomic) {
+      const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
       for (int target : {256, 512}) {
-        if (ring_ok(p, 64)) { add(3, ring_splitk(p, 256, 256, target)); add(7, ring_splitk(p, 256, 256, target)); }
-        if (ring_ok(p, 32)) add(5, ring_splitk(p, 256, 256, target));
+        const int sk = ring_splitk(p, 256, 256, target);
+        for (int remap : {0, FH_SPLIT_REMAP}) {
+          if (remap && (sk < 2 || tiles256 < 2)) continue;  // nothing to co-locate
+          if (ring_ok(p, 64)) { add(3, sk | remap); add(7, sk | remap); }
+          if (ring_ok(p, 32)) add(5, sk | remap);
+        }
       }
       add(2, ring_splitk(p, 128, 128, 1024));
     } else {
@@ -1674,7 +1697,7 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.X.layout == FH_R_STRIDED && (p.M % vec || p.X.ld % vec || p.X.bstride % vec)) return -104;
   if (p.Y.layout == FH_R_STRIDED && (p.N % vec || p.Y.ld % vec || p.Y.bstride % vec)) return -105;
   if (p.X.nseg != p.Y.nseg || p.X.nseg < 1 || p.X.nseg > 2) return -106;
-  if (p.splitk > 1 && !p.ep.atomic) return -107;
+  if ((p.splitk & 0xffff) > 1 && !p.ep.atomic) return -107;
   if (!p.ep.atomic && (p.ldc % 8 || p.c_bstride % 8 || p.c_gstride % 8)) return -108;
   if (p.ep.row_len && p.c_rpb <= 0) return -109;
   if ((p.X.segoff[0] | p.X.segoff[1] | p.Y.segoff[0] | p.Y.segoff[1] | p.X.gstride | p.Y.gstride) % vec) return -110;

@@ -74,7 +74,8 @@ typedef struct {
   long c_bstride;
   long c_gstride;
   int groups;
-  int splitk; /* > 1 requires atomic */
+  int splitk; /* low 16 bits: reduction splits (> 1 requires atomic); bit 16: co-locate the tiles of one split on one XCD (set by the
+                 per-shape tuner, fh_gemm_tune) */
   fh_gemm_epilogue ep;
 } fh_gemm_desc;
 
