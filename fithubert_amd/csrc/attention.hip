@@ -278,6 +278,103 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
   }
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // one v_cvt_pk_bf16_f32
+  union { bf16x2 v; uint32_t u; } c;
+  c.v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  return c.u;
+}
+// acc[dt] += Tile^T[d-tile dt][rows] * P with P already packed: lo / hi = the 4 bf16 of the two C tiles covering tile rows
+// [32 m2, 32 m2 + 16) and [32 m2 + 16, 32 m2 + 32)  (mma_transposed<bf16> without its conversions)
+template <int NDT>
+__device__ __forceinline__ void mma_transposed_packed(const unsigned char* tile, int m2, uint2 lo, uint2 hi, f32x4 (&acc)[NDT], int lane) {
+  const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
+  union { struct { uint2 lo, hi; } s; bf16x8 v; } pb;
+  pb.s.lo = lo;
+  pb.s.hi = hi;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    const unsigned char* a0 = tile + (32 * m2 + 4 * q + qq) * AT<bf16>::RS + (16 * dt + 4 * pp) * 2;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * AT<bf16>::RS));
+    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pb.v, acc[dt], 0, 0, 0);
+  }
+}
+// Per-lane state of a wave that owns 32 keys (two 16-key C tiles, lane <-> key) and walks 16-query blocks: the dK/dV side of
+// both backward forms (bf16).  block() turns the S and dP tiles of one 16-query block into the packed bf16 P.drop and dS tiles.
+//  * masked keys: exp2(-inf) = 0 through an additive bias instead of a select per score
+//  * dropout: keys 2j and 2j + 1 share one hash word (drop_pair) and sit in neighbouring lanes, so a lane hashes the words of TWO
+//    of its four queries per C tile (4q + 2 par + {0, 1}) and takes the other two from its neighbour (one DPP move per word).
+//    Index = ((b H + h) Tn + query) * pitch + key, split as in the forward: (row base + 64-key tile start) picks the key of the
+//    high word, the tile-relative offset is added to the low word only.
+struct KeyScore {
+  float kbias[2], scale, scale_log2e, inv_keep;
+  uint32_t t16, koff, hshift, hi0, key0, key1;
+  unsigned long long ib0, pitch;
+  int par;
+  __device__ __forceinline__ void init(const DropCfg& drop, int b, int h, int H, int Tn, int klen, int k0, int lane, float sc,
+                                       float sl2) {
+    const int r = lane & 15, q = lane >> 4;
+    kbias[0] = k0 + r < klen ? 0.f : -INFINITY;
+    kbias[1] = k0 + 16 + r < klen ? 0.f : -INFINITY;
+    scale = sc;
+    scale_log2e = sl2;
+    par = r & 1;
+    const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
+    t16 = dspan.k.thresh >> 8;
+    inv_keep = dspan.k.inv_keep;
+    hi0 = dspan.hi0;
+    key0 = dspan.k.k;
+    key1 = dspan.k_next;
+    pitch = drop_row_pitch(Tn);
+    const int kt0w = k0 & ~63;
+    ib0 = (((unsigned long long)b * H + h) * Tn + 4 * q + 2 * par) * pitch + kt0w;
+    koff = (uint32_t)(k0 - kt0w) + (uint32_t)(r & ~1);
+    hshift = 16u * par;
+  }
+  // q16 = first query of the 16-query block; lse4 / dl4 = log-sum-exp (log2 domain, +inf for rows past Tn) and delta of this
+  // lane's four queries q16 + 4q .. 4q + 3
+  template <bool DROP>
+  __device__ __forceinline__ void block(int q16, const f32x4 (&s)[2], const f32x4 (&dp)[2], f32x4 lse4, f32x4 dl4, uint2 (&pdp)[2],
+                                        uint2 (&dsp)[2]) const {
+    uint32_t hw[2][4];  // [kt][e] hash words
+    if (DROP) {
+      uint32_t mine[2][2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const unsigned long long rb = ib0 + (unsigned long long)(q16 + jj) * pitch;
+        const uint32_t key = (uint32_t)(rb >> 32) == hi0 ? key0 : key1;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) mine[kt][jj] = fh_mix32(((uint32_t)rb + koff + 16u * kt) ^ key);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[kt][jj], 0xB1, 0xf, 0xf, true);  // lane ^ 1
+          hw[kt][jj] = par ? other : mine[kt][jj];
+          hw[kt][2 + jj] = par ? mine[kt][jj] : other;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      float pdv[4], dsv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = fast_exp2(fmaf(s[kt][e], scale_log2e, kbias[kt] - lse4[e]));
+        float dsc = 1.f;
+        if (DROP) dsc = __builtin_amdgcn_ubfe(hw[kt][e], hshift, 16u) >= t16 ? inv_keep : 0.f;
+        pdv[e] = p * dsc;
+        dsv[e] = (p * scale) * fmaf(dp[kt][e], dsc, -dl4[e]);
+      }
+      pdp[kt] = make_uint2(pack_bf16x2(pdv[0], pdv[1]), pack_bf16x2(pdv[2], pdv[3]));
+      dsp[kt] = make_uint2(pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3]));
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 template <typename T, int NDT, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
@@ -429,6 +526,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
   // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
   const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
 
+  KeyScore ksc;
+  ksc.init(drop, b, h, H, Tn, klen, k0, lane, scale, scale_log2e);
   const int ntile = (Tn + 63) / 64;
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
   auto stage_q = [&](int slot, int qt0) {
@@ -476,6 +575,38 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
       stage_q(0, qt0);
       __syncthreads();
     }
+    if constexpr (sizeof(T) == 2) {
+      // bf16: the shared score step (KeyScore) -- branch-free, pair hashes shared between neighbouring lanes, one bf16 conversion
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        uint2 pdp[2][2], dsp[2][2];  // [half][kt]
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int qb = 2 * m2 + half;
+          f32x4 s[2], dp[2];
+          s[0] = s[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) {
+            const frag aq = lfrag<T>(Qs, 16 * qb + r, ks, lane);
+            const frag ao = lfrag<T>(Os, 16 * qb + r, ks, lane);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              s[kt] = mma(aq, kf[kt][ks], s[kt]);
+              dp[kt] = mma(ao, vf[kt][ks], dp[kt]);
+            }
+          }
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(L2s + 16 * qb + 4 * q);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(Dls + 16 * qb + 4 * q);
+          if (drop.p > 0.f) ksc.template block<true>(qt0 + 16 * qb, s, dp, l4, dl, pdp[half], dsp[half]);
+          else ksc.template block<false>(qt0 + 16 * qb, s, dp, l4, dl, pdp[half], dsp[half]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          mma_transposed_packed<NDT>(Os, m2, pdp[0][kt], pdp[1][kt], dv[kt], lane);
+          mma_transposed_packed<NDT>(Qs, m2, dsp[0][kt], dsp[1][kt], dk[kt], lane);
+        }
+      }
+    } else {
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) {
       f32x4 pd[2][2], ds[2][2];  // [half][kt]
@@ -520,6 +651,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
         mma_transposed<T, NDT>(Qs, m2, ds[0][kt], ds[1][kt], dk[kt], lane);
       }
     }
+    }
   }
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
@@ -551,30 +683,6 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
 // buffered, so the step costs ONE barrier and the dQ MFMAs overlap the next step's exp / hash work.
 // LDS: 4 x (Q | dO | lse | delta) tiles 75,776 B + K 36,864 B + 2 x dS^T scratch 36,864 B = 149,504 B.
 constexpr int FUSED_SRS = 72;  // scratch row: 32 queries x 2 B + 8 B pad (conflict-free transposing reads)
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // one v_cvt_pk_bf16_f32
-  union { bf16x2 v; uint32_t u; } c;
-  c.v = __builtin_convertvector(f32x2{a, b}, bf16x2);
-  return c.u;
-}
-// acc[dt] += Tile^T[d-tile dt][rows] * P with P already packed: lo / hi = the 4 bf16 of the two C tiles covering tile rows
-// [32 m2, 32 m2 + 16) and [32 m2 + 16, 32 m2 + 32)  (mma_transposed<bf16> without its conversions)
-template <int NDT>
-__device__ __forceinline__ void mma_transposed_packed(const unsigned char* tile, int m2, uint2 lo, uint2 hi, f32x4 (&acc)[NDT], int lane) {
-  const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
-  union { struct { uint2 lo, hi; } s; bf16x8 v; } pb;
-  pb.s.lo = lo;
-  pb.s.hi = hi;
-#pragma unroll
-  for (int dt = 0; dt < NDT; ++dt) {
-    const unsigned char* a0 = tile + (32 * m2 + 4 * q + qq) * AT<bf16>::RS + (16 * dt + 4 * pp) * 2;
-    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
-    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * AT<bf16>::RS));
-    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pb.v, acc[dt], 0, 0, 0);
-  }
-}
 template <int NDT, bool DROP>
 __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -607,7 +715,7 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
     stage_tile<T>(sb + 64 * RS, dobase, D, kt * 64, Tn, dh);
     stage_tile<T>(Kt + kt * 64 * RS, base + D, ld, kt * 64, Tn, dh);
   }
-  {  // lse (negated: the exponent is fma(s, c, -lse)), and delta[query] = sum_d out * dout: two threads per query row
+  {  // lse, and delta[query] = sum_d out * dout: two threads per query row
     const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
     float part = 0.f;
     if (row < Tn)
@@ -621,7 +729,7 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
     part += __shfl_xor(part, 1, 64);
     if (half == 0) {
       float* L2w = reinterpret_cast<float*>(lds + (row >> 6) * PAIR + 2 * 64 * RS);
-      L2w[row & 63] = row < Tn ? -lse[((long)b * H + h) * Tn + row] : -INFINITY;
+      L2w[row & 63] = row < Tn ? lse[((long)b * H + h) * Tn + row] : INFINITY;
       L2w[64 + (row & 63)] = part;
       if (row < Tn) delta[((long)b * H + h) * Tn + row] = part;
     }
@@ -644,21 +752,8 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
       dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  // masked keys (lane <-> key): exp2(-inf) = 0 through an additive bias instead of a select per score
-  const float kbias[2] = {k0 + r < klen ? 0.f : -INFINITY, k0 + 16 + r < klen ? 0.f : -INFINITY};
-  // dropout: keys 2j and 2j + 1 share one hash word (drop_pair) and sit in neighbouring lanes, so a lane hashes the words of TWO of
-  // its four queries per C tile (4q + 2 par + {0, 1}) and takes the other two from its neighbour (one DPP move per word).
-  // Index = ((b H + h) Tn + query) * pitch + key, split as in the forward: (row base + 64-key tile start) picks the key of the
-  // high word, the tile-relative offset is added to the low word only.
-  const int par = r & 1;
-  const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
-  const uint32_t t16 = dspan.k.thresh >> 8;
-  const float inv_keep = dspan.k.inv_keep;
-  const unsigned long long pitch = drop_row_pitch(Tn);
-  const int kt0w = k0 & ~63;
-  const unsigned long long ib0 = (((unsigned long long)b * H + h) * Tn + 4 * q + 2 * par) * pitch + kt0w;
-  const uint32_t koff = (uint32_t)(k0 - kt0w) + (uint32_t)(r & ~1);
-  const uint32_t hshift = 16u * par;
+  KeyScore ks_;
+  ks_.init(drop, b, h, H, Tn, klen, k0, lane, scale, scale_log2e);
   __syncthreads();
 
   const int nstep = (Tn + 31) / 32;  // 32-query steps
@@ -686,43 +781,13 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
           dp[kt] = mma(ao, vf[kt][ks], dp[kt]);
         }
       }
-      const f32x4 nl = *reinterpret_cast<const f32x4*>(L2s + 16 * qb + 4 * q);  // -lse of queries 4q .. 4q + 3
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(L2s + 16 * qb + 4 * q);  // lse of queries 4q .. 4q + 3
       const f32x4 dl = *reinterpret_cast<const f32x4*>(Dls + 16 * qb + 4 * q);
-      uint32_t hw[2][4];  // [kt][e] hash words
-      if (DROP) {
-        uint32_t mine[2][2];
+      ks_.template block<DROP>(st * 32 + 16 * half, s, dp, l4, dl, pdp[half], dsp[half]);
+      // dS^T block of this wave: row = key, 4 consecutive queries per lane
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const unsigned long long rb = ib0 + (unsigned long long)(st * 32 + 16 * half + jj) * pitch;
-          const uint32_t key = (uint32_t)(rb >> 32) == dspan.hi0 ? dspan.k.k : dspan.k_next;
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt) mine[kt][jj] = fh_mix32(((uint32_t)rb + koff + 16u * kt) ^ key);
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine[kt][jj], 0xB1, 0xf, 0xf, true);  // lane ^ 1
-            hw[kt][jj] = par ? other : mine[kt][jj];
-            hw[kt][2 + jj] = par ? mine[kt][jj] : other;
-          }
-      }
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        float pdv[4], dsv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = fast_exp2(fmaf(s[kt][e], scale_log2e, nl[e] + kbias[kt]));
-          float dsc = 1.f;
-          if (DROP) dsc = __builtin_amdgcn_ubfe(hw[kt][e], hshift, 16u) >= t16 ? inv_keep : 0.f;
-          pdv[e] = p * dsc;
-          dsv[e] = (p * scale) * fmaf(dp[kt][e], dsc, -dl[e]);
-        }
-        pdp[half][kt] = make_uint2(pack_bf16x2(pdv[0], pdv[1]), pack_bf16x2(pdv[2], pdv[3]));
-        dsp[half][kt] = make_uint2(pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3]));
-        // dS^T block of this wave: row = key, 4 consecutive queries per lane
+      for (int kt = 0; kt < 2; ++kt)
         *reinterpret_cast<uint2*>(Sb + (k0 + 16 * kt + r) * FUSED_SRS + (16 * half + 4 * q) * 2) = dsp[half][kt];
-      }
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
