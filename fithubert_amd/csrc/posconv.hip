@@ -22,7 +22,6 @@ template <typename T, int CP> struct PC {
   static constexpr int RS = CP * (int)sizeof(T) + 16;  // LDS row stride in bytes
   static constexpr int CB = CP / 16;                    // 16-channel MFMA blocks per group
   static constexpr int TS = (sizeof(T) == 4 && CP == 64) ? 128 : 256;  // frames per staged tile (wgrad; LDS budget)
-  static constexpr int JW = CP == 64 ? 2 : 8;          // taps per wave in wgrad (accumulator registers)
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -128,6 +127,21 @@ __device__ __forceinline__ void st2(bf16* p, const float* f) {
 template <typename T, int CP, bool GP>
 __device__ __forceinline__ void stage_rows(unsigned char* lds, const T* src, const T* zc, T* dz, int b, int Tn, int D,
                                            int cg, int g, int t_first, int nrows, int own0, int own1) {
+  if constexpr (!GP && sizeof(T) == 2) {
+    // group rows of a whole number of 16-byte vectors (cg % 8 == 0, e.g. 48 channels): one 16-byte load / LDS store per 8 channels
+    // instead of four 4-byte ones (the 30-channel groups of fithubert.yaml start at 60-byte offsets and cannot)
+    if (cg % 8 == 0) {
+      const int u8 = CP / 8, total8 = nrows * u8;
+      for (int idx = threadIdx.x; idx < total8; idx += blockDim.x) {
+        const int row = idx / u8, u = idx - row * u8;
+        const int t = t_first + row;
+        V16 v = v16_zero();
+        if (t >= 0 && t < Tn && 8 * u < cg) v = ld16(src + ((long)b * Tn + t) * D + g * cg + 8 * u);
+        st16(lds + row * PC<T, CP>::RS + u * 16, v);
+      }
+      return;
+    }
+  }
   const int units = CP / 2;
   const int total = nrows * units;
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
@@ -256,12 +270,15 @@ template <int CP> struct WgFrag {
   }
 };
 
-template <typename T, int CP>
+// CB = 16-channel blocks that hold real channels (3 for the 48-channel groups: the fourth block of the 64-wide padding is all
+// zeros), JW = taps per wave (accumulators: JW * CB * CB tiles).  A workgroup re-stages the same dz / x tiles for its 4 * JW taps
+// only, so JW sets how often every tile is staged: 2 taps per wave made the 64-wide build 5x slower per FLOP than the 32-wide one.
+template <typename T, int CP, int CB, int JW>
 __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict__ dzc, const T* __restrict__ x,
                                                             float* __restrict__ dws, int B, int Tn, int D, int cg, int K,
                                                             int pad_left, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int RS = PC<T, CP>::RS, CB = PC<T, CP>::CB, TS = PC<T, CP>::TS, JW = PC<T, CP>::JW;
+  constexpr int RS = PC<T, CP>::RS, TS = PC<T, CP>::TS;
   unsigned char* ldsA = lds;              // dzc tile  [TS][CP]
   unsigned char* ldsB = lds + TS * RS;    // x window  [TS + K - 1][CP]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -398,16 +415,17 @@ int conv_t(const void* in, const void* zc, const void* w, const float* bias, voi
   FH_CHECK_LAUNCH();
   return 0;
 }
-template <typename T, int CP>
+template <typename T, int CP, int CB, int JW>
 int wgrad_t(const void* dzc, const void* x, float* dws, int B, int Tn, int D, int groups, int K, hipStream_t st) {
-  constexpr int TS = PC<T, CP>::TS, JW = PC<T, CP>::JW;
+  constexpr int TS = PC<T, CP>::TS;
+  if (K % (4 * JW)) return -502;
   const int ntt = (Tn + TS - 1) / TS;
   int nsplit = B * ntt;
   if (nsplit > 8) nsplit = 8;
   dim3 grid(K / (4 * JW), groups, nsplit), block(256);
   const size_t smem = wg_lds<T, CP>(K);
-  set_lds(posconv_wgrad_kernel<T, CP>, smem);
-  hipLaunchKernelGGL((posconv_wgrad_kernel<T, CP>), grid, block, smem, st, (const T*)dzc, (const T*)x, dws, B, Tn, D, D / groups, K,
+  set_lds(posconv_wgrad_kernel<T, CP, CB, JW>, smem);
+  hipLaunchKernelGGL((posconv_wgrad_kernel<T, CP, CB, JW>), grid, block, smem, st, (const T*)dzc, (const T*)x, dws, B, Tn, D, D / groups, K,
                      K / 2, nsplit);
   FH_CHECK_LAUNCH();
   return 0;
@@ -458,8 +476,9 @@ int fh_posconv_bwd_weight_launch(int dtype, const void* dzc, const void* x, floa
   const int cg = D / groups, cp = fh_posconv_cp(cg);
   if (!cp || cg % 2 || K % 32) return -501;
   int rc;
-  if (cp == 32) rc = dtype == 0 ? wgrad_t<float, 32>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 32>(dzc, x, dws, B, Tn, D, groups, K, st);
-  else rc = dtype == 0 ? wgrad_t<float, 64>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64>(dzc, x, dws, B, Tn, D, groups, K, st);
+  if (cp == 32) rc = dtype == 0 ? wgrad_t<float, 32, 2, 8>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 32, 2, 8>(dzc, x, dws, B, Tn, D, groups, K, st);
+  else if (cg <= 48) rc = dtype == 0 ? wgrad_t<float, 64, 3, 4>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64, 3, 4>(dzc, x, dws, B, Tn, D, groups, K, st);
+  else rc = dtype == 0 ? wgrad_t<float, 64, 4, 2>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64, 4, 2>(dzc, x, dws, B, Tn, D, groups, K, st);
   if (rc) return rc;
   if (dbias) return fh_colsum_launch(dtype, dzc, dbias, B * Tn, D, D, 1, 0, 0, 0, 1.0f, st);
   return 0;
