@@ -304,6 +304,18 @@ constexpr int EPI_WAVE = 32 * EPI_ROW;   // 8704 B per wave per pass
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float* f);
 template <> __device__ __forceinline__ void ld8<float>(const float* p, float* f) { ld4(p, f); ld4(p + 4, f + 4); }
 template <> __device__ __forceinline__ void ld8<bf16>(const bf16* p, float* f) { unpack16<bf16>(ld16(p), f); }
+// 8 elements as loaded (conversion deferred to the point of use): one 16-byte vector of bf16, two of fp32
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+  V16 v;
+  __device__ __forceinline__ void load(const bf16* p) { v = ld16(p); }
+  __device__ __forceinline__ void get(float* f) const { unpack16<bf16>(v, f); }
+};
+template <> struct Raw8<float> {
+  V16 v[2];
+  __device__ __forceinline__ void load(const float* p) { v[0] = ld16(p); v[1] = ld16(p + 4); }
+  __device__ __forceinline__ void get(float* f) const { unpack16<float>(v[0], f); unpack16<float>(v[1], f + 4); }
+};
 template <typename T> __device__ __forceinline__ void st8(T* p, const float* f);
 template <> __device__ __forceinline__ void st8<float>(float* p, const float* f) { st4(p, f); st4(p + 4, f + 4); }
 template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float* f) { st16(p, pack16<bf16>(f)); }
@@ -311,7 +323,7 @@ template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float* f) {
 // read-back phase of the staged epilogue: `my` holds 32 rows x 64 fp32 columns of this wave (pass h)
 template <typename T>
 __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const unsigned char* my, int h, int i0, int j0, int xi0,
-                                                  int yj0, int lane, int g) {
+                                                  int yj0, int lane, int g, const float (&bv)[8]) {
   const GemmEpilogue& ep = p.ep;
   if (ep.atomic) {
     // weight gradients: one output row x 64 contiguous columns per wave instruction (256 B, the shape fp32 atomics like)
@@ -328,28 +340,85 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     }
     return;
   }
-  // a lane keeps ONE 8-column group j for all its rows: the bias vector, the column bound and the index bases are hoisted out of
-  // the row loop, and the row -> (batch, frame) map, the output offset and the dropout index advance incrementally (the integer
-  // division / modulo and the 64-bit multiplies of the straightforward form cost more VALU than the GELU for plain epilogues)
+  // A lane keeps ONE 8-column group j for all its rows: the column bound and the index bases are hoisted out of the row loop, and
+  // the row -> (batch, frame) map, the output offset and the dropout index advance incrementally.
+  // NO vector-memory LOAD may sit between the stores of a tile: vmcnt counts loads and stores in one in-order queue, so waiting
+  // for any load also waits for every older store to be acknowledged (~2.5 us under load) -- with the bias loaded inside each
+  // pass, a tile's four passes serialised behind each other's stores and the epilogue cost 10 us of a 256 x 256 tile.  The bias
+  // therefore comes in registers (epilogue_bias, before the first pass); passes that do need per-row operands (GELU' operand,
+  // residual, row lengths) issue all of them before their first store.
   const int j = j0 + yj0 + 8 * (lane & 7);
   if (j >= p.N) return;
   const int i_first = i0 + xi0 + 32 * h + (lane >> 3);
   if (i_first >= p.M) return;
-  float bv[8];
-  if (ep.bias) {
-    const float* bp = ep.bias + (long)g * ep.bias_gstride + (ep.bias_mod > 0 ? (j % ep.bias_mod) : j);
-    ld4(bp, bv);
-    ld4(bp + 4, bv + 4);
+  // Streamlined form for the common case -- rows contiguous in memory (no batch wrap), no row mask, bf16 / fp32 output as T, all
+  // four rows of the lane inside M: per row 2 LDS reads, the option math, the conversion and the store(s), with the output /
+  // operand offsets as base + constant stride.  The general form below executes ~150 instructions per row (option tests, 64-bit
+  // index updates, row wrap), which made a pass instruction-bound (~3000 cycles per 32 x 64 block, measured with s_memtime)
+  // rather than LDS-bound.
+  const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
+  const bool simple = !ep.row_len && !ep.out_f32 && (p.c_rpb <= 0 || wrap0 == 0);
+  if (simple && __builtin_amdgcn_readfirstlane(i0 + xi0 + 32 * h + 31 < p.M)) {
+    const long base = (long)g * p.c_gstride + (long)i_first * p.ldc + j;  // batch stride == rows x ldc
+    const long rstep = 8L * p.ldc;
+    T* cp = reinterpret_cast<T*>(p.C) + base;
+    const unsigned char* lp = my + (lane >> 3) * EPI_ROW + (lane & 7) * 32;
+    const bool gelu = ep.act == FH_ACT_GELU, drop = ep.drop.p > 0.f;
+    Raw8<T> aux[4], res[4];
+    if (ep.gelu_aux) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) aux[it].load(reinterpret_cast<const T*>(ep.gelu_aux) + base + it * rstep);
+    }
+    if (ep.residual) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) res[it].load(reinterpret_cast<const T*>(ep.residual) + base + it * rstep);
+    }
+    const unsigned long long d0 = ((unsigned long long)g * p.M + i_first) * (unsigned long long)p.N + j;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(lp + it * 8 * EPI_ROW);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(lp + it * 8 * EPI_ROW + 16);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaf(a[e], ep.alpha, bv[e]);
+        v[4 + e] = fmaf(b[e], ep.alpha, bv[4 + e]);
+      }
+      if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + base + it * rstep, v);
+      if (gelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      }
+      if (drop) drop_scale_vec<8>(ep.drop, d0 + (unsigned long long)(it * 8) * (unsigned long long)p.N, v);
+      if (ep.gelu_aux) {
+        float x[8];
+        aux[it].get(x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(x[e]);
+      }
+      if (ep.residual) {
+        float x[8];
+        res[it].get(x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += x[e];
+      }
+      st8<T>(cp + it * rstep, v);
+    }
+    return;
   }
   RowMap rm = map_row(i_first, p.c_rpb);
   long coff = (long)g * p.c_gstride + (long)rm.b * p.c_bstride + (long)rm.t * p.ldc + j;
   unsigned long long didx = ((unsigned long long)g * p.M + i_first) * (unsigned long long)p.N + j;
   const long wrap = p.c_bstride - (long)p.c_rpb * p.ldc;  // offset correction when a row step crosses into the next batch entry
+  long co[4];
+  unsigned long long di[4];
+  bool live[4], dead[4];
+  Raw8<T> aux[4], res[4];
+  const bool has_loads = ep.gelu_aux || ep.residual || ep.row_len;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int rl = it * 8 + (lane >> 3);
-    const int i = i_first + it * 8;
-    if (i >= p.M) break;
+    live[it] = i_first + it * 8 < p.M;
+    dead[it] = false;
     if (it > 0) {
       rm.t += 8;
       coff += 8L * p.ldc;
@@ -361,46 +430,66 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
           coff += wrap;
         }
     }
+    co[it] = coff;
+    di[it] = didx;
+    if (has_loads && live[it]) {
+      if (ep.gelu_aux) aux[it].load(reinterpret_cast<const T*>(ep.gelu_aux) + coff);
+      if (ep.residual) res[it].load(reinterpret_cast<const T*>(ep.residual) + coff);
+      if (ep.row_len) dead[it] = rm.t >= ep.row_len[rm.b];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (!live[it]) break;
+    const int rl = it * 8 + (lane >> 3);
     float v[8];
     {
       const f32x4 a = *reinterpret_cast<const f32x4*>(my + rl * EPI_ROW + (lane & 7) * 32);
       const f32x4 b = *reinterpret_cast<const f32x4*>(my + rl * EPI_ROW + (lane & 7) * 32 + 16);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = a[e] * ep.alpha;
-        v[4 + e] = b[e] * ep.alpha;
+        v[e] = fmaf(a[e], ep.alpha, bv[e]);
+        v[4 + e] = fmaf(b[e], ep.alpha, bv[4 + e]);
       }
     }
-    if (ep.bias) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bv[e];
-    }
-    if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + coff, v);
+    if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
     if (ep.act == FH_ACT_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
     }
-    if (ep.drop.p > 0.f) drop_scale_vec<8>(ep.drop, didx, v);
+    if (ep.drop.p > 0.f) drop_scale_vec<8>(ep.drop, di[it], v);
     if (ep.gelu_aux) {
       float a[8];
-      ld8<T>(reinterpret_cast<const T*>(ep.gelu_aux) + coff, a);
+      aux[it].get(a);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(a[e]);
     }
     if (ep.residual) {
       float rr[8];
-      ld8<T>(reinterpret_cast<const T*>(ep.residual) + coff, rr);
+      res[it].get(rr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rr[e];
     }
-    if (ep.row_len && rm.t >= ep.row_len[rm.b]) {
+    if (dead[it]) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
     if (ep.out_f32)
-      st8<float>(reinterpret_cast<float*>(p.C) + coff, v);
+      st8<float>(reinterpret_cast<float*>(p.C) + co[it], v);
     else
-      st8<T>(reinterpret_cast<T*>(p.C) + coff, v);
+      st8<T>(reinterpret_cast<T*>(p.C) + co[it], v);
+  }
+}
+// bias of the 8 columns a lane owns in epilogue_readback (zeros without a bias): loaded once per tile and column block, before
+// the first pass
+__device__ __forceinline__ void epilogue_bias(const GemmParams& p, int j0, int yj0, int lane, int g, float (&bv)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+  const int j = j0 + yj0 + 8 * (lane & 7);
+  if (p.ep.bias && !p.ep.atomic && j < p.N) {
+    const float* bp = p.ep.bias + (long)g * p.ep.bias_gstride + (p.ep.bias_mod > 0 ? (j % p.ep.bias_mod) : j);
+    ld4(bp, bv);
+    ld4(bp + 4, bv + 4);
   }
 }
 
@@ -409,6 +498,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
                                                      int j0, int xi0, int yj0, int lane, int wave, int g) {
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
+  float bv[8];
+  epilogue_bias(p, j0, yj0, lane, g, bv);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     __syncthreads();  // main-loop LDS reads (h = 0) / previous pass (h = 1) are finished in every wave
@@ -418,7 +509,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
       for (int n = 0; n < 4; ++n)
         *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
     __syncthreads();
-    epilogue_readback<T>(p, my, h, i0, j0, xi0, yj0, lane, g);
+    epilogue_readback<T>(p, my, h, i0, j0, xi0, yj0, lane, g, bv);
   }
 }
 
@@ -538,6 +629,8 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const GemmParams p) {
   }
   // staged epilogue: D[j_local][i_local] with i_local = lane & 31, j_local = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   unsigned char* my = lds + wave * EPI_WAVE;
+  float bv[8];
+  epilogue_bias(p, j0, yj0, lane, g, bv);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     __syncthreads();
@@ -549,7 +642,7 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const GemmParams p) {
         *reinterpret_cast<f32x4*>(my + (lane & 31) * EPI_ROW + (n * 32 + 8 * q4 + 4 * (lane >> 5)) * 4) = v;
       }
     __syncthreads();
-    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g);
+    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g, bv);
   }
 }
 
@@ -930,7 +1023,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-  for (int cb = 0; cb < TN / 64; ++cb)
+  for (int cb = 0; cb < TN / 64; ++cb) {
+    float bv[8];
+    epilogue_bias(p, j0, yj0 + 64 * cb, lane, g, bv);
 #pragma unroll
     for (int h = 0; h < TM / 32; ++h) {
 #pragma unroll
@@ -938,8 +1033,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
 #pragma unroll
         for (int n = 0; n < 4; ++n)
           *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[cb * 4 + n][2 * h + mm];
-      epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0 + 64 * cb, lane, g);
+      epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0 + 64 * cb, lane, g, bv);
     }
+  }
 }
 
 template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
@@ -1102,6 +1198,8 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tail DMA drained, every wave done with the ring
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
+  float bv[8];
+  epilogue_bias(p, j0, yj0, lane, g, bv);
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -1109,7 +1207,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
 #pragma unroll
       for (int n = 0; n < 4; ++n)
         *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
-    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g);
+    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g, bv);
   }
 }
 
@@ -1425,6 +1523,8 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
+  float bv[8];
+  epilogue_bias(p, j0, yj0, lane, g, bv);
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -1432,7 +1532,7 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
 #pragma unroll
       for (int n = 0; n < 4; ++n)
         *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
-    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g);
+    epilogue_readback<bf16>(p, my, h, i0, j0, xi0, yj0, lane, g, bv);
   }
 }
 

@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fithubert_amd import _lib as L
+L.LIB_PATH = os.environ.get('FH_LIB_PATH', L.LIB_PATH)  # A/B against another build of the library
 dev = "cuda"; lib = L.lib(); bf = torch.bfloat16
 st = lambda: torch.cuda.current_stream().cuda_stream
 PATHS = [int(x) for x in os.environ.get("PATHS", "7,5").split(",")]
