@@ -513,6 +513,91 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
   }
 }
 
+// bf16-staged epilogue for outputs without per-row operands (no GELU' operand, residual or row mask; bf16 output): bias, GELU and
+// dropout are applied in the accumulator layout (a lane holds 4 consecutive columns of a row), the result is converted ONCE and
+// staged as bf16 -- half the LDS bytes and half the LDS instructions of the fp32 staging -- and the read-back is a plain copy
+// (16-byte LDS read -> 16-byte store, 8 rows x 128 contiguous bytes per wave instruction).  A pre-activation output is staged and
+// copied the same way before the activation.  `acc` is this wave's [4 n-tiles][NM m-tiles] block, column block yj0 .. yj0 + 63.
+// Returns false (nothing written) when the tile does not qualify; the caller then runs the fp32-staged form.
+constexpr int EPB_ROW = 144;  // 64 bf16 columns + 16 B pad: conflict-free 8-byte writes (16 rows) and 16-byte reads (8 lanes / row)
+template <int NM, typename AccT>
+__device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& acc, int n_base, unsigned char* my, int i0, int j0,
+                                              int xi0, int yj0, int lane, int g) {
+  const GemmEpilogue& ep = p.ep;
+  const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
+  const bool ok = !ep.atomic && !ep.gelu_aux && !ep.residual && !ep.row_len && !ep.out_f32 && (p.c_rpb <= 0 || wrap0 == 0) &&
+                  i0 + xi0 + 16 * NM - 1 < p.M;
+  if (!__builtin_amdgcn_readfirstlane(ok)) return false;
+  const int r = lane & 15, q = lane >> 4;
+  float b4[4][4];
+  bool cv[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int j = j0 + yj0 + 16 * n + 4 * q;
+    cv[n] = j < p.N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b4[n][e] = 0.f;
+    if (ep.bias && cv[n]) ld4(ep.bias + (long)g * ep.bias_gstride + (ep.bias_mod > 0 ? (j % ep.bias_mod) : j), b4[n]);
+  }
+  const bool gelu = ep.act == FH_ACT_GELU, drop = ep.drop.p > 0.f;
+  // read-back side: row it * 8 + (lane >> 3) of the pass, 8 columns at (lane & 7) * 8
+  const int jr = j0 + yj0 + 8 * (lane & 7);
+  const bool jrv = jr < p.N;
+  const long rstep = 8L * p.ldc;
+  const unsigned char* lp = my + (lane >> 3) * EPB_ROW + (lane & 7) * 16;
+  unsigned char* wp = my + r * EPB_ROW + 8 * q;
+#pragma unroll
+  for (int h = 0; h < NM / 2; ++h) {
+    const long base = (long)g * p.c_gstride + (long)(i0 + xi0 + 32 * h + (lane >> 3)) * p.ldc + jr;
+    float v[2][4][4];
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[mm][n][e] = fmaf(acc[n_base + n][2 * h + mm][e], ep.alpha, b4[n][e]);
+    if (ep.preact) {
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          uint2 pk;
+          pk.x = bf16_bits(v[mm][n][0]) | (bf16_bits(v[mm][n][1]) << 16);
+          pk.y = bf16_bits(v[mm][n][2]) | (bf16_bits(v[mm][n][3]) << 16);
+          *reinterpret_cast<uint2*>(wp + mm * 16 * EPB_ROW + n * 32) = pk;
+        }
+      if (jrv) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          st16(reinterpret_cast<bf16*>(ep.preact) + base + it * rstep, ld16(lp + it * 8 * EPB_ROW));
+      }
+    }
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (gelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[mm][n][e] = gelu_f(v[mm][n][e]);
+        }
+        if (drop) {
+          const unsigned long long didx = ((unsigned long long)g * p.M + (i0 + xi0 + 16 * (2 * h + mm) + r)) * (unsigned long long)p.N +
+                                          (j0 + yj0 + 16 * n + 4 * q);
+          drop_scale_vec<4>(ep.drop, didx, v[mm][n]);
+        }
+        uint2 pk;
+        pk.x = bf16_bits(v[mm][n][0]) | (bf16_bits(v[mm][n][1]) << 16);
+        pk.y = bf16_bits(v[mm][n][2]) | (bf16_bits(v[mm][n][3]) << 16);
+        *reinterpret_cast<uint2*>(wp + mm * 16 * EPB_ROW + n * 32) = pk;
+      }
+    if (jrv) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) st16(reinterpret_cast<bf16*>(p.C) + base + it * rstep, ld16(lp + it * 8 * EPB_ROW));
+    }
+  }
+  return true;
+}
+
 // XCD-aware block remap (guide T1): blocks b and b+8 share an XCD (and its private L2).  Logical tiles are handed out so
 // that the tiles_j column tiles of one row tile -- which re-read the same X rows -- run back to back on ONE XCD; without
 // it every XCD fetched every X tile on its own (PMC: GEMM FETCH_SIZE was ~4x the algorithmic bytes).  Bijective for any
@@ -1523,6 +1608,7 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
+  if (epilogue_bf16<8>(p, acc, 0, my, i0, j0, xi0, yj0, lane, g)) return;
   float bv[8];
   epilogue_bias(p, j0, yj0, lane, g, bv);
 #pragma unroll
