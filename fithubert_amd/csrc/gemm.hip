@@ -1751,7 +1751,9 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
   if (red >= 256) {
     if (p.ep.atomic) {
       const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-      for (int target : {256, 512}) {
+      // the atomic epilogue costs ~9 us per extra split of a 12 x 480 x 480 gradient (tools/gemm_wgrad_sweep.py): fewer workgroups
+      // than CUs can win, so the candidates start below one wave of workgroups
+      for (int target : {64, 128, 192, 256, 512}) {
         const int sk = ring_splitk(p, 256, 256, target);
         for (int remap : {0, FH_SPLIT_REMAP}) {
           if (remap && (sk < 2 || tiles256 < 2)) continue;  // nothing to co-locate
