@@ -357,7 +357,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
   // index updates, row wrap), which made a pass instruction-bound (~3000 cycles per 32 x 64 block, measured with s_memtime)
   // rather than LDS-bound.
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
-  const bool simple = !ep.row_len && !ep.out_f32 && (p.c_rpb <= 0 || wrap0 == 0);
+  const bool simple = !ep.out_f32 && (p.c_rpb <= 0 || wrap0 == 0) && (!ep.row_len || p.c_rpb >= 8);
   if (simple && __builtin_amdgcn_readfirstlane(i0 + xi0 + 32 * h + 31 < p.M)) {
     const long base = (long)g * p.c_gstride + (long)i_first * p.ldc + j;  // batch stride == rows x ldc
     const long rstep = 8L * p.ldc;
@@ -372,6 +372,19 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     if (ep.residual) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) res[it].load(reinterpret_cast<const T*>(ep.residual) + base + it * rstep);
+    }
+    bool dead[4] = {false, false, false, false};
+    if (ep.row_len) {  // rows past an utterance's valid frames are written as zeros (padded batches)
+      int rb = i_first / p.c_rpb, rt = i_first - rb * p.c_rpb;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        dead[it] = rt >= ep.row_len[rb];
+        rt += 8;
+        if (rt >= p.c_rpb) {
+          rt -= p.c_rpb;
+          ++rb;
+        }
+      }
     }
     const unsigned long long d0 = ((unsigned long long)g * p.M + i_first) * (unsigned long long)p.N + j;
 #pragma unroll
@@ -401,6 +414,10 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
         res[it].get(x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += x[e];
+      }
+      if (dead[it]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
       }
       st8<T>(cp + it * rstep, v);
     }
