@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
 // dy_total = (dy [+ dy2]) [* dropmask(out_drop)]  is the gradient w.r.t. the LayerNorm output.
 // dx -> gradient w.r.t. the LayerNorm input; dx2 (optional) = dx * dropmask(in_drop).
 template <typename T, int NCH>
-__global__ void __launch_bounds__(1024) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+__global__ void __launch_bounds__(NCH == 1 ? 1024 : (NCH == 2 ? 512 : 256)) ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                      const T* __restrict__ x, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, T* __restrict__ dx2, float* __restrict__ dgamma,
@@ -301,7 +301,7 @@ int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const flo
   // workgroup set the atomic count (128 rows: 249 x 960 atomics for the student's 31872 x 480; 64 rows as 4 waves x 16 was 20 %
   // slower), while 8 rows per wave keep ~4000 waves in flight for the load -> shuffle-reduce -> store chain
   const int rpw = 8;
-  const int wpb = C <= 512 ? 16 : (C <= 1024 ? 8 : 4);  // [waves][2][C] floats of LDS stay <= 64 KiB
+  const int wpb = nch == 1 ? 16 : (nch == 2 ? 8 : 4);  // = the kernel's launch bound; [waves][2][C] floats of LDS stay <= 64 KiB
   const int waves = (M + rpw - 1) / rpw;
   dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
   const size_t smem = (size_t)2 * wpb * C * sizeof(float);
