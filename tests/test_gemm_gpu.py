@@ -206,3 +206,75 @@ def test_gemm_groups_dropout_rowmask(dt):
     d.C = out2.data_ptr()
     _run(d, dt)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("loop", [2, 3, 5, 6, 7])
+@pytest.mark.parametrize("opts", ["plain", "bias_gelu", "bias_preact_gelu_drop", "aux_residual", "rowmask_drop"])
+def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
+    """The bf16 epilogue has three forms (bf16-staged in the 8-phase kernel, streamlined and general fp32-staged read-back); which
+    one a row block takes depends on the options and on whether the block is full.  M = 600 gives every 256-row tile full 32- and
+    128-row blocks plus a ragged tail, N = 480 a partial column tile.  Outputs are checked against fp64 (dropout: the kept set is
+    the pure function of (seed, site, index) every form must reproduce -- compared with the register-staging loop 2)."""
+    dev = "cuda"
+    torch.manual_seed(11)
+    M, N, K = 600, 480, 256
+    B, T = 3, 200  # row = b * T + t, contiguous batch entries (c_rpb = T, c_bstride = T * N)
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    aux = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    row_len = torch.tensor([200, 150, 7], dtype=torch.int32, device=dev)
+
+    def run(path):
+        L.lib().fh_gemm_set_path(path)
+        Cout = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        pre = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        d = L.GemmDesc()
+        d.X = L.operand(X.data_ptr(), 0, K)
+        d.Y = L.operand(W.data_ptr(), 0, K)
+        d.C = Cout.data_ptr()
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+        d.c_rpb, d.c_bstride = T, T * N
+        kw = {}
+        if "bias" in opts: kw["bias"] = bias.data_ptr()
+        if "gelu" in opts: kw["act"] = L.ACT_GELU
+        if "preact" in opts: kw["preact"] = pre.data_ptr()
+        if "drop" in opts: kw["drop"] = (0.25, 17, 3)
+        if "aux" in opts: kw["gelu_aux"] = aux.data_ptr()
+        if "residual" in opts: kw["residual"] = res.data_ptr()
+        if "rowmask" in opts: kw["row_len"] = row_len.data_ptr()
+        d.ep = L.epilogue(**kw)
+        _run(d, L.DT_BF16)
+        return Cout, pre
+
+    try:
+        got, pre = run(loop)
+        base, _ = run(2)
+    finally:
+        L.lib().fh_gemm_set_path(9)
+    z = X.double() @ W.double().t()
+    if "bias" in opts: z = z + bias.double()
+    ref = torch.nn.functional.gelu(z) if "gelu" in opts else z.clone()
+    if "aux" in opts: 
+        a = aux.double()
+        ref = ref * (0.5 * (1 + torch.erf(a / 2 ** 0.5)) + a * torch.exp(-a * a / 2) / (2 * 3.141592653589793) ** 0.5)
+    if "residual" in opts: ref = ref + res.double()
+    assert not torch.isnan(got.float()).any()
+    scale = ref.abs().max().item()
+    if "preact" in opts:
+        assert (pre.double() - z).abs().max().item() <= 2e-2 * z.abs().max().item()
+    keep = torch.ones(M, N, dtype=torch.bool, device=dev)
+    if "drop" in opts:
+        keep = base != 0
+        assert torch.equal(got != 0, keep)                       # same mask from every epilogue form
+        assert abs(keep.double().mean().item() - (0.75 if "rowmask" not in opts else 0.75 * 357 / 600)) < 0.02
+        ref = ref / 0.75
+    if "rowmask" in opts:
+        t = torch.arange(M, device=dev) % T
+        b = torch.arange(M, device=dev) // T
+        valid = (t < row_len[b].long())[:, None]
+        assert torch.equal((got != 0) & ~valid, torch.zeros_like(keep))  # masked rows are exact zeros
+        keep = keep & valid
+    err = ((got.double() - ref) * keep).abs().max().item()
+    assert err <= 2e-2 * scale, (err, scale)
