@@ -448,10 +448,48 @@ inline int splitk_for(long tiles, long red) {
   return (int)sk;
 }
 
+// Side stream for weight / bias gradients whose only consumer is the optimizer: they read per-layer buffers that the rest of
+// the backward never rewrites and accumulate into the flat gradient buffer, so they can run beside the data-gradient chain --
+// whose short, single-wave GEMMs and latency-bound LayerNorm / attention kernels leave CUs idle -- instead of in front of it.
+// fork(): the side stream waits for everything queued on the main stream so far; join(): the main stream waits for the side
+// stream (end of backward: the workspace goes back to the allocator only after that).  Off while the GEMM tuner is timing
+// launches, and with FH_WGRAD_STREAM=0.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ev[32];
+  int next = 0, state = -1;  // -1 unknown, 0 off, 1 on
+  bool used = false;
+  bool on() {
+    if (state < 0) {
+      const char* e = getenv("FH_WGRAD_STREAM");
+      state = (e && e[0] == '0') ? 0 : 1;
+      if (state && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) state = 0;
+      for (int i = 0; state && i < 32; ++i)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) state = 0;
+    }
+    return state == 1 && !fh_gemm_tuning();
+  }
+  hipStream_t fork(hipStream_t main) {
+    if (!on()) return main;
+    hipEvent_t e = ev[next++ & 31];
+    if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(s, e, 0) != hipSuccess) return main;
+    used = true;
+    return s;
+  }
+  int join(hipStream_t main) {
+    if (!used) return 0;
+    used = false;
+    hipEvent_t e = ev[next++ & 31];
+    if (hipEventRecord(e, s) != hipSuccess) return -830;
+    return hipStreamWaitEvent(main, e, 0) == hipSuccess ? 0 : -830;
+  }
+};
+SideStream g_wside;
+
 // weight-gradient GEMM: dW[n][kk] += sum_m dC[m][n] * A(m)[kk]   (atomic accumulate into the fp32 grad buffer)
 inline int wgrad(const Ctx& x, const void* dC, long ld_dc, const GemmOperand& A, float* dW, int N, int Kout, long Mred,
                  int groups, long dc_g, long dw_g, int jdiv = 0, long sj1 = 0, long sj0 = 0, int idiv = 0, long si1 = 0,
-                 long si0 = 0, long ldc = -1) {
+                 long si0 = 0, long ldc = -1, hipStream_t st = nullptr) {
   GemmParams g = fh_gemm_params();
   g.X = fh_operand(dC, FH_R_STRIDED, ld_dc);
   g.X.gstride = dc_g;
@@ -466,7 +504,7 @@ inline int wgrad(const Ctx& x, const void* dC, long ld_dc, const GemmOperand& A,
   g.ep.idiv = idiv; g.ep.si1 = si1; g.ep.si0 = si0;
   const long tiles = (long)((N + 127) / 128) * ((Kout + 127) / 128) * groups;
   g.splitk = splitk_for(tiles, Mred);
-  return fh_gemm_launch(g, x.dt, x.st);
+  return fh_gemm_launch(g, x.dt, st ? st : x.st);
 }
 
 int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t st) {
@@ -878,6 +916,30 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     }
   }
 
+  // ---------------- grouped weight / bias gradients of layers [l0, l0 + nl): one launch per linear, on the side stream.  Issued
+  // once for all layers behind the layer loop (chunks of 4 layers from inside the loop were measured: the smaller groups lose more
+  // than the extra overlap gains).
+  auto layer_wgrads = [&](int l0, int nl) -> int {
+    const long lo = p.pl.layer0 + (long)l0 * p.pl.layer_stride, ls = p.pl.layer_stride;
+    const hipStream_t ws_ = g_wside.fork(x.st);
+    GemmOperand A = fh_operand(x.at(p.hbuf, (long)l0 * M2 * Fd), FH_R_STRIDED, Fd);
+    A.gstride = M2 * Fd;
+    RC(wgrad(x, x.at(p.df2, (long)l0 * M2 * D), D, A, grads + lo + p.pl.l_fc2_w, D, Fd, M2, nl, M2 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.df2, (long)l0 * M2 * D), grads + lo + p.pl.l_fc2_b, (int)M2, D, D, nl, M2 * D, ls, 0, 1.f, ws_));
+    A = fh_operand(x.at(p.xa, (long)l0 * M2 * D), FH_R_STRIDED, D);
+    A.gstride = M2 * D;
+    RC(wgrad(x, x.at(p.dz1, (long)l0 * M2 * Fd), Fd, A, grads + lo + p.pl.l_fc1_w, Fd, D, M2, nl, M2 * Fd, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.dz1, (long)l0 * M2 * Fd), grads + lo + p.pl.l_fc1_b, (int)M2, Fd, Fd, nl, M2 * Fd, ls, 0, 1.f, ws_));
+    A = fh_operand(x.at(p.attn, (long)l0 * M2 * D), FH_R_STRIDED, D);
+    A.gstride = M2 * D;
+    RC(wgrad(x, x.at(p.dao, (long)l0 * M2 * D), D, A, grads + lo + p.pl.l_o_w, D, D, M2, nl, M2 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.dao, (long)l0 * M2 * D), grads + lo + p.pl.l_o_b, (int)M2, D, D, nl, M2 * D, ls, 0, 1.f, ws_));
+    A = fh_operand(x.at(p.xo, (long)l0 * M2 * D), FH_R_STRIDED, D);  // layer inputs = slots 0..L-1
+    A.gstride = M2 * D;
+    RC(wgrad(x, x.at(p.dqkv, (long)l0 * M2 * 3 * D), 3 * D, A, grads + lo + p.pl.l_qkv_w, 3 * D, D, M2, nl, M2 * 3 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.dqkv, (long)l0 * M2 * 3 * D), grads + lo + p.pl.l_qkv_b, (int)M2, 3 * D, 3 * D, nl, M2 * 3 * D, ls, 0, 1.f, ws_));
+    return 0;
+  };
   // ---------------- transformer layers, last to first
   const void* dy_next = nullptr;  // gradient w.r.t. xo[l+1] coming from layer l+1
   for (int l = L - 1; l >= 0; --l) {
@@ -945,26 +1007,7 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     }
     dy_next = x.at(p.dxin, (long)(l & 1) * M2 * D);
   }
-  // ---------------- grouped weight gradients of all layers (one launch per linear)
-  {
-    const long lo = p.pl.layer0, ls = p.pl.layer_stride;
-    GemmOperand A = fh_operand(x.W(p.hbuf), FH_R_STRIDED, Fd);
-    A.gstride = M2 * Fd;
-    RC(wgrad(x, x.W(p.df2), D, A, grads + lo + p.pl.l_fc2_w, D, Fd, M2, L, M2 * D, ls));
-    RC(fh_colsum_launch(dt, x.W(p.df2), grads + lo + p.pl.l_fc2_b, (int)M2, D, D, L, M2 * D, ls, 0, 1.f, x.st));
-    A = fh_operand(x.W(p.xa), FH_R_STRIDED, D);
-    A.gstride = M2 * D;
-    RC(wgrad(x, x.W(p.dz1), Fd, A, grads + lo + p.pl.l_fc1_w, Fd, D, M2, L, M2 * Fd, ls));
-    RC(fh_colsum_launch(dt, x.W(p.dz1), grads + lo + p.pl.l_fc1_b, (int)M2, Fd, Fd, L, M2 * Fd, ls, 0, 1.f, x.st));
-    A = fh_operand(x.W(p.attn), FH_R_STRIDED, D);
-    A.gstride = M2 * D;
-    RC(wgrad(x, x.W(p.dao), D, A, grads + lo + p.pl.l_o_w, D, D, M2, L, M2 * D, ls));
-    RC(fh_colsum_launch(dt, x.W(p.dao), grads + lo + p.pl.l_o_b, (int)M2, D, D, L, M2 * D, ls, 0, 1.f, x.st));
-    A = fh_operand(x.W(p.xo), FH_R_STRIDED, D);  // layer inputs = slots 0..L-1
-    A.gstride = M2 * D;
-    RC(wgrad(x, x.W(p.dqkv), 3 * D, A, grads + lo + p.pl.l_qkv_w, 3 * D, D, M2, L, M2 * 3 * D, ls));
-    RC(fh_colsum_launch(dt, x.W(p.dqkv), grads + lo + p.pl.l_qkv_b, (int)M2, 3 * D, 3 * D, L, M2 * 3 * D, ls, 0, 1.f, x.st));
-  }
+  RC(layer_wgrads(0, L));
   // ---------------- time-reduction conv backward
   const void* d_x1;  // gradient w.r.t. the encoder LayerNorm(+dropout) output
   if (c.tr_factor > 0) {
@@ -1056,7 +1099,7 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     GemmOperand A = fh_operand(x.W(p.y[i - 1]), FH_R_STRIDED, (long)sd * cin);
     A.rpb = Ti; A.bstride = (long)Tin * cin;
     RC(wgrad(x, x.W(p.dz[i]), cout, A, grads + p.pl.conv_w[i], cout, kk * cin, Mi, 1, 0, 0, /*jdiv*/ cin, /*sj1*/ 1, /*sj0*/ kk,
-             0, 0, 0, /*ldc*/ (long)cin * kk));
+             0, 0, 0, /*ldc*/ (long)cin * kk, g_wside.fork(x.st)));  // dz[i] is final; y[i-1] is a forward activation
     // data gradient -> dz[i-1] = d(y[i-1]) * gelu'(z[i-1])   (for layer 0 the GELU' lives inside the conv0 backward)
     unsigned char* dst = x.W<unsigned char>(i - 1 >= 1 ? p.dz[i - 1] : p.dz[0]);
     const unsigned char* aux = i - 1 >= 1 ? x.W<unsigned char>(p.z[i - 1]) : nullptr;
@@ -1100,7 +1143,7 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
                          x.W<float>(p.c0_mean), x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch),
                          x.W<float2>(p.c0_scratch) + (long)B * fh_conv0_nchunk(s.T[0]) * c.conv_dim[0], grads + p.pl.conv_w[0],
                          grads + p.pl.gn_w, grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st));
-  return 0;
+  return g_wside.join(x.st);
 }
 
 }  // namespace

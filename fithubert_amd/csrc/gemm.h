@@ -18,6 +18,7 @@ typedef fh_gemm_epilogue GemmEpilogue;
 typedef fh_gemm_desc GemmParams;
 
 // dtype: 0 = float, 1 = bf16
+bool fh_gemm_tuning();
 int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream);
 
 static inline GemmOperand fh_operand(const void* p, int layout, long ld) {

@@ -1840,6 +1840,7 @@ extern "C" int fh_gemm_set_path(int path) {
   g_gemm_path = path;
   return 0;
 }
+bool fh_gemm_tuning() { return g_tune_mode != 0; }  // launches are being timed: callers keep everything on one stream
 extern "C" int fh_gemm_tune(int mode) {
   if (mode < 0) g_tune.clear();
   g_tune_mode = mode > 0;
