@@ -28,6 +28,25 @@ from .model import CustomStudentModel
 from .teacher import TeacherConfig, TeacherWrapper, build_teacher, freeze_model
 
 
+def _low_priority_stream(device: torch.device) -> "torch.cuda.Stream":
+    """Side stream for the frozen teacher's forward, at the LOWEST HIP stream priority: the student's chain of short, dependent
+    kernels then gets its CUs first and the teacher's large GEMMs fill what is left (+1 % over equal priorities; the reverse
+    order costs 1.5 %).  torch only exposes normal / high, so the stream is created through the HIP runtime torch has loaded and
+    wrapped; any failure falls back to an ordinary stream."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        lo, hi = ctypes.c_int(), ctypes.c_int()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi)) == 0 and lo.value > 0 and \
+                    hip.hipStreamCreateWithPriority(ctypes.byref(handle), 1, lo.value) == 0 and handle.value:  # 1 = hipStreamNonBlocking
+                return torch.cuda.ExternalStream(handle.value, device=device)
+    except Exception:
+        pass
+    return torch.cuda.Stream(device=device)
+
+
 class W2V2Distil:
     def __init__(self, cfg: dict, dtype: str = "bf16", device: str = "cuda", teacher: Optional[TeacherWrapper] = None,
                  teacher_cfg: Optional[TeacherConfig] = None, seed: int = 0, teacher_dtype=torch.bfloat16,
@@ -105,7 +124,7 @@ class W2V2Distil:
         self._next_teacher = None
         # the frozen teacher runs on its own HIP stream: its forward for batch i+1 overlaps the student's forward /
         # backward of batch i (and the gradient all-reduce), filling CUs the student's short kernels leave idle
-        self.teacher_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.teacher_stream = _low_priority_stream(self.device) if self.device.type == "cuda" else None
         if os.environ.get("FH_TEACHER_STREAM", "1") == "0":   # A/B: teacher serialised on the main stream
             self.teacher_stream = None
 
