@@ -463,7 +463,11 @@ struct SideStream {
     if (state < 0) {
       const char* e = getenv("FH_WGRAD_STREAM");
       state = (e && e[0] == '0') ? 0 : 1;
-      if (state && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) state = 0;
+      // lowest priority: the data-gradient chain (main stream) takes the CUs it can use, the weight gradients fill the rest
+      int lo = 0, hi = 0;
+      if (state && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+                    hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess))
+        state = 0;
       for (int i = 0; state && i < 32; ++i)
         if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) state = 0;
     }
