@@ -850,14 +850,17 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
         if (d_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)l0 * M2 * D * p.es;
         RC(fh_gemm_launch(g, dt, x.st));
       }
+      // The heads' PARAMETER gradients are a branch of their own -- d_pred and the layer outputs in, the gradient buffer out, nothing
+      // of the data-gradient chain reads them -- so the whole branch goes to the side stream (in order there).
+      const hipStream_t hs = g_wside.fork(x.st);
       // dWm[l][(j, p)][ci] = sum_m d_pred[l][m][(j, p)] * x[l][m][ci]   (fp32 scratch), this pass's column sums of d_pred
-      RC((int)hipMemsetAsync(x.W(p.dwm), 0, (long)Lh * fP * D * 4, x.st));
-      RC((int)hipMemsetAsync(x.W(p.dbl), 0, (long)Lh * P * 4, x.st));
+      RC((int)hipMemsetAsync(x.W(p.dwm), 0, (long)Lh * fP * D * 4, hs));
+      RC((int)hipMemsetAsync(x.W(p.dbl), 0, (long)Lh * P * 4, hs));
       {
         GemmOperand A = fh_operand(x.at(p.xo, (long)(l0 + 1) * M2 * D), FH_R_STRIDED, D);
         A.gstride = M2 * D;
-        RC(wgrad(x, d_pred, fP, A, x.W<float>(p.dwm), (int)fP, D, M2, Lh, M2 * fP, fP * D));
-        RC(fh_colsum_launch(dt, d_pred, x.W<float>(p.dbl), (int)(M2 * s.f), P, P, Lh, M2 * fP, P, 0, 1.f, x.st));
+        RC(wgrad(x, d_pred, fP, A, x.W<float>(p.dwm), (int)fP, D, M2, Lh, M2 * fP, fP * D, 0, 0, 0, 0, 0, 0, -1, hs));
+        RC(fh_colsum_launch(dt, d_pred, x.W<float>(p.dbl), (int)(M2 * s.f), P, P, Lh, M2 * fP, P, 0, 1.f, hs));
       }
       // chain rule onto the reference's parameters (fp32 GEMMs on the fp32 masters, accumulate into the gradient buffer)
       const float* wupf = (const float*)x.rel(p.wl.head_wupf) + (long)l0 * p.wl.head_wup_stride;
@@ -873,7 +876,7 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
           g.c_gstride = p.pl.head_stride;
           g.groups = Lh;
           g.ep.atomic = 1;
-          RC(fh_gemm_launch(g, 0, x.st));
+          RC(fh_gemm_launch(g, 0, hs));
         }
         {  // dWup[ci][co][j] += sum_p dWm[j][p][ci] * Wlin[p][co]
           GemmParams g = fh_gemm_params();
@@ -888,10 +891,10 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
           g.ep.atomic = 1;
           g.ep.idiv = 1; g.ep.si1 = (long)D * s.f; g.ep.si0 = 0;
           g.ep.jdiv = 1; g.ep.sj1 = s.f; g.ep.sj0 = 0;
-          RC(fh_gemm_launch(g, 0, x.st));
+          RC(fh_gemm_launch(g, 0, hs));
         }
       }
-      hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(Lh, (D + 15) / 16), dim3(256), 0, x.st, x.params, grads, hp0, p.pl.head_stride, p.pl.h_lin_w,
+      hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(Lh, (D + 15) / 16), dim3(256), 0, hs, x.params, grads, hp0, p.pl.head_stride, p.pl.h_lin_w,
                          p.pl.h_lin_b, p.pl.h_up_b, (const float*)x.W<float>(p.dbl), P, D);
       FH_CHECK_LAUNCH();
       dlin_in = nullptr;
