@@ -9,7 +9,9 @@
 // (S^T = K Q^T) so that a lane holds one query column: the softmax reductions are two wavefront shuffles, the
 // accumulator tiles of S^T are directly the B operand of the P.V product (no LDS round trip), and V^T / K^T come
 // from transposing LDS reads (ds_read_b64_tr_b16).  Head dim 40 is zero-padded to the MFMA K granularity in LDS only.
-// Backward recomputes P from the saved log-sum-exp: a dQ pass (same decomposition) and a dK/dV pass (wave owns keys).
+// Backward recomputes P from the saved log-sum-exp.  bf16, T <= 256 (the 10 s student): ONE fused pass per (batch, head) -- the
+// dK/dV decomposition (wave owns keys) plus a dQ contraction through an LDS scratch, attn_bwd_fused_kernel.  Otherwise: a dQ pass
+// (the forward's decomposition) and a dK/dV pass.  These kernels are VALU-bound (exp2 + dropout hash per score), not MFMA-bound.
 #include <cstdlib>
 
 #include "common.cuh"
