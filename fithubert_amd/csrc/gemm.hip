@@ -356,35 +356,44 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
   // operand offsets as base + constant stride.  The general form below executes ~150 instructions per row (option tests, 64-bit
   // index updates, row wrap), which made a pass instruction-bound (~3000 cycles per 32 x 64 block, measured with s_memtime)
   // rather than LDS-bound.
-  const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
-  const bool simple = !ep.out_f32 && (p.c_rpb <= 0 || wrap0 == 0) && (!ep.row_len || p.c_rpb >= 8);
+  const long wrap0 = p.c_rpb > 0 ? p.c_bstride - (long)p.c_rpb * p.ldc : 0;
+  // (batch entries of fewer than 8 rows -- more than one wrap per row step -- stay with the general form)
+  const bool simple = !ep.out_f32 && (p.c_rpb <= 0 || p.c_rpb >= 8);
   if (simple && __builtin_amdgcn_readfirstlane(i0 + xi0 + 32 * h + 31 < p.M)) {
-    const long base = (long)g * p.c_gstride + (long)i_first * p.ldc + j;  // batch stride == rows x ldc
-    const long rstep = 8L * p.ldc;
-    T* cp = reinterpret_cast<T*>(p.C) + base;
+    // offsets of the lane's four rows: constant stride, plus the batch-entry correction when a row step crosses into the next
+    // entry (the conv data gradients write every other frame of a longer sequence: batch stride != rows x ldc)
+    long co[4];
+    bool dead[4] = {false, false, false, false};
+    {
+      int rb = 0, rt = i_first;
+      if (p.c_rpb > 0 && (wrap0 != 0 || ep.row_len)) {
+        rb = i_first / p.c_rpb;
+        rt = i_first - rb * p.c_rpb;
+      }
+      long o = (long)g * p.c_gstride + (long)i_first * p.ldc + (long)rb * wrap0 + j;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        co[it] = o;
+        if (ep.row_len) dead[it] = rt >= ep.row_len[rb];  // rows past an utterance's valid frames are written as zeros
+        o += 8L * p.ldc;
+        rt += 8;
+        if (p.c_rpb > 0 && rt >= p.c_rpb) {
+          rt -= p.c_rpb;
+          ++rb;
+          o += wrap0;
+        }
+      }
+    }
     const unsigned char* lp = my + (lane >> 3) * EPI_ROW + (lane & 7) * 32;
     const bool gelu = ep.act == FH_ACT_GELU, drop = ep.drop.p > 0.f;
     Raw8<T> aux[4], res[4];
     if (ep.gelu_aux) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) aux[it].load(reinterpret_cast<const T*>(ep.gelu_aux) + base + it * rstep);
+      for (int it = 0; it < 4; ++it) aux[it].load(reinterpret_cast<const T*>(ep.gelu_aux) + co[it]);
     }
     if (ep.residual) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) res[it].load(reinterpret_cast<const T*>(ep.residual) + base + it * rstep);
-    }
-    bool dead[4] = {false, false, false, false};
-    if (ep.row_len) {  // rows past an utterance's valid frames are written as zeros (padded batches)
-      int rb = i_first / p.c_rpb, rt = i_first - rb * p.c_rpb;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        dead[it] = rt >= ep.row_len[rb];
-        rt += 8;
-        if (rt >= p.c_rpb) {
-          rt -= p.c_rpb;
-          ++rb;
-        }
-      }
+      for (int it = 0; it < 4; ++it) res[it].load(reinterpret_cast<const T*>(ep.residual) + co[it]);
     }
     const unsigned long long d0 = ((unsigned long long)g * p.M + i_first) * (unsigned long long)p.N + j;
 #pragma unroll
@@ -397,7 +406,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
         v[e] = fmaf(a[e], ep.alpha, bv[e]);
         v[4 + e] = fmaf(b[e], ep.alpha, bv[4 + e]);
       }
-      if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + base + it * rstep, v);
+      if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
       if (gelu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
@@ -419,7 +428,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
       }
-      st8<T>(cp + it * rstep, v);
+      st8<T>(reinterpret_cast<T*>(p.C) + co[it], v);
     }
     return;
   }

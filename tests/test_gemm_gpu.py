@@ -209,7 +209,8 @@ def test_gemm_groups_dropout_rowmask(dt):
 
 
 @pytest.mark.parametrize("loop", [2, 3, 5, 6, 7])
-@pytest.mark.parametrize("opts", ["plain", "bias_gelu", "bias_preact_gelu_drop", "aux_residual", "rowmask_drop"])
+@pytest.mark.parametrize("opts", ["plain", "bias_gelu", "bias_preact_gelu_drop", "aux_residual", "rowmask_drop",
+                                  "gapped_aux_residual", "gapped_bias_preact_gelu_drop_rowmask"])
 def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
     """The bf16 epilogue has three forms (bf16-staged in the 8-phase kernel, streamlined and general fp32-staged read-back); which
     one a row block takes depends on the options and on whether the block is full.  M = 600 gives every 256-row tile full 32- and
@@ -218,35 +219,42 @@ def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
     dev = "cuda"
     torch.manual_seed(11)
     M, N, K = 600, 480, 256
-    B, T = 3, 200  # row = b * T + t, contiguous batch entries (c_rpb = T, c_bstride = T * N)
+    B, T = 3, 200  # row = b * T + t; batch entries contiguous (c_bstride = T * N) or, "gapped", 230 rows apart in memory
+    TS = 230 if "gapped" in opts else T
     X = torch.randn(M, K, device=dev).to(torch.bfloat16)
     W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device=dev)
-    aux = torch.randn(M, N, device=dev).to(torch.bfloat16)
-    res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    aux_full = torch.randn(B * TS, N, device=dev).to(torch.bfloat16)
+    res_full = torch.randn(B * TS, N, device=dev).to(torch.bfloat16)
+    rows = (torch.arange(M, device=dev) // T) * TS + torch.arange(M, device=dev) % T   # memory row of logical row i
+    aux, res = aux_full[rows], res_full[rows]
     row_len = torch.tensor([200, 150, 7], dtype=torch.int32, device=dev)
 
     def run(path):
         L.lib().fh_gemm_set_path(path)
-        Cout = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
-        pre = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        Cout = torch.full((B * TS, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        pre = torch.full((B * TS, N), float("nan"), device=dev, dtype=torch.bfloat16)
         d = L.GemmDesc()
         d.X = L.operand(X.data_ptr(), 0, K)
         d.Y = L.operand(W.data_ptr(), 0, K)
         d.C = Cout.data_ptr()
         d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
-        d.c_rpb, d.c_bstride = T, T * N
+        d.c_rpb, d.c_bstride = T, TS * N
         kw = {}
         if "bias" in opts: kw["bias"] = bias.data_ptr()
         if "gelu" in opts: kw["act"] = L.ACT_GELU
         if "preact" in opts: kw["preact"] = pre.data_ptr()
         if "drop" in opts: kw["drop"] = (0.25, 17, 3)
-        if "aux" in opts: kw["gelu_aux"] = aux.data_ptr()
-        if "residual" in opts: kw["residual"] = res.data_ptr()
+        if "aux" in opts: kw["gelu_aux"] = aux_full.data_ptr()
+        if "residual" in opts: kw["residual"] = res_full.data_ptr()
         if "rowmask" in opts: kw["row_len"] = row_len.data_ptr()
         d.ep = L.epilogue(**kw)
         _run(d, L.DT_BF16)
-        return Cout, pre
+        if TS != T:  # rows between the entries must stay untouched
+            gap = torch.ones(B * TS, dtype=torch.bool, device=dev)
+            gap[rows] = False
+            assert torch.isnan(Cout[gap].float()).all()
+        return Cout[rows], pre[rows]
 
     try:
         got, pre = run(loop)
