@@ -1,5 +1,9 @@
 import ctypes as C, os, torch
-lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstore_pattern.so"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libstore_pattern.so")
+if not os.path.exists(SO):  # throw-away tool: built on demand
+    os.system(f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o {SO} {os.path.join(HERE, 'store_pattern.hip')}")
+lib = C.CDLL(SO)
 lib.run_store.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 st = lambda: torch.cuda.current_stream().cuda_stream
 def t(fn, n=10):
