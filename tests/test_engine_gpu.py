@@ -215,6 +215,7 @@ def test_forward_is_bitwise_deterministic_across_engines_and_calls():
             assert torch.equal(a, b), it
 
 
+@pytest.mark.skipif(bool(os.environ.get("FH_GEMM_PATH")), reason="a forced main loop bypasses the per-shape table")
 def test_gemm_autotune_table_changes_speed_not_results():
     """The per-shape main-loop table (fh_gemm_tune) may pick any of the bf16 loops and split-K factors; a training-mode
     forward + backward with the tuned table must agree with the same pass forced onto the default 128-tile loop."""
