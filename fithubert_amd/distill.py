@@ -33,6 +33,17 @@ def _low_priority_stream(device: torch.device) -> "torch.cuda.Stream":
     kernels then gets its CUs first and the teacher's large GEMMs fill what is left (+1 % over equal priorities; the reverse
     order costs 1.5 %).  torch only exposes normal / high, so the stream is created through the HIP runtime torch has loaded and
     wrapped; any failure falls back to an ordinary stream."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key in _TEACHER_STREAMS:  # one per device and process: HIP streams are multiplexed onto a few hardware queues, and every
+        return _TEACHER_STREAMS[key]  # extra stream risks sharing the student's queue (an external stream is never freed)
+    _TEACHER_STREAMS[key] = st = _make_low_priority_stream(device)
+    return st
+
+
+_TEACHER_STREAMS: dict = {}
+
+
+def _make_low_priority_stream(device: torch.device) -> "torch.cuda.Stream":
     try:
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")

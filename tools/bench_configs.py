@@ -58,6 +58,12 @@ ds = SyntheticLibriDataset(pick, batch_size=B, seed=0)
 order = rng.permutation(len(ds)).tolist()
 var = [{k: v.to(DEV) for k, v in ds[i].items()} for i in order[:4]]
 
+ONLY = os.environ.get("ONLY", "")  # e.g. ONLY=2,4a
+run_all = run
+def run(name, *a, **k):
+    tag = name.split()[1]
+    if not ONLY or tag in ONLY.split(","):
+        run_all(name, *a, **k)
 run("config 2  fithubert.yaml, HuBERT-Base, 10 s", "fithubert.yaml", TeacherConfig.base("hubert"), fixed)
 run("config 3  fithubert.yaml, bucketed variable length", "fithubert.yaml", TeacherConfig.base("hubert"), var)
 run("config 4a fitwav2vec2.yaml, wav2vec2-Base, 10 s", "fitwav2vec2.yaml", TeacherConfig.base("wav2vec2"), fixed)
