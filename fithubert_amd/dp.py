@@ -23,6 +23,10 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        # HIP streams are multiplexed onto GPU_MAX_HW_QUEUES hardware queues (default 4): the step already uses three (student,
+        # teacher, parameter-gradient side stream) and RCCL adds its own -- streams that share a queue serialise
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
