@@ -4,6 +4,13 @@ HIP/CDNA4 kernels + a native student engine (``csrc/``, built into ``libfithuber
 own Python surface: ``CustomStudentModelConfig`` / ``CustomStudentModel`` (modules/model.py), ``W2V2Distil`` (train.py),
 ``TeacherWrapper`` (utils/utils.py), ``UpstreamExpert`` / ``hubconf.fithubert`` (fithubert/).
 """
-from .config import CustomStudentModelConfig, load_yaml  # noqa: F401
+import os as _os
+
+# Kernel arguments in device memory: the HIP runtime then skips a host-memory fetch per launch.  A step is ~2000 mostly short
+# kernels, so this is worth +5 % at 16 utterances per GPU and +0.8 % at 128 (bench.py A/B).  Read when the runtime starts, so it is
+# set at import time -- before the first HIP call of the process; an explicit setting in the environment wins.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+from .config import CustomStudentModelConfig, load_yaml  # noqa: E402,F401
 
 __all__ = ["CustomStudentModelConfig", "load_yaml"]
