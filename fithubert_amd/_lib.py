@@ -89,6 +89,13 @@ class StudentGradsC(C.Structure):
     _fields_ = [("d_pred", C.c_void_p), ("d_hidden", C.c_void_p), ("d_cnn", C.c_void_p), ("d_qkv_last", C.c_void_p)]
 
 
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_long, C.c_long)
+
+
+class GradNotifyC(C.Structure):
+    _fields_ = [("comm_stream", C.c_void_p), ("ready", GRAD_READY_FN), ("user", C.c_void_p)]
+
+
 class StudentCallC(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("training", C.c_int), ("heads_on", C.c_int), ("seed", C.c_uint32)]
 
@@ -106,6 +113,8 @@ _ENGINE_SIGS = {
     "fh_student_backward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fh_student_backward_cnn": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fh_student_backward_ex": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, C.POINTER(StudentGradsC), _P]),
+    "fh_student_backward_notify": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, C.POINTER(StudentGradsC),
+                                        C.POINTER(GradNotifyC), _P]),
 }
 
 

@@ -490,6 +490,42 @@ struct SideStream {
 };
 SideStream g_wside;
 
+// Gradient-segment notification (fh_student_backward_notify): when a contiguous range of the flat gradient buffer is final, the
+// caller's communication stream is made to wait for the kernels that write it -- the main stream's position and, when the side
+// stream carried some of them, the side stream's -- and the caller is told the range.
+struct Notifier {
+  const fh_grad_notify* n = nullptr;
+  hipStream_t main = nullptr;
+  int seg = 0;
+  bool heads_done = false, layers_done = false;
+  hipEvent_t ev[16];
+  int next = 0, state = -1;
+  bool on() {
+    if (!n || !n->ready) return false;
+    if (state < 0) {
+      state = 1;
+      for (int i = 0; i < 16; ++i)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) state = 0;
+    }
+    return state == 1;
+  }
+  int wait_on(hipStream_t producer) {
+    hipStream_t comm = (hipStream_t)n->comm_stream;
+    if (comm == producer) return 0;
+    hipEvent_t e = ev[next++ & 15];
+    if (hipEventRecord(e, producer) != hipSuccess || hipStreamWaitEvent(comm, e, 0) != hipSuccess) return -831;
+    return 0;
+  }
+  int fire(long first, long count, bool with_side) {
+    if (!on() || count <= 0) return 0;
+    RC(wait_on(main));
+    if (with_side && g_wside.used) RC(wait_on(g_wside.s));
+    n->ready(n->user, seg, first, count);
+    return 0;
+  }
+};
+Notifier g_notify;
+
 // weight-gradient GEMM: dW[n][kk] += sum_m dC[m][n] * A(m)[kk]   (atomic accumulate into the fp32 grad buffer)
 inline int wgrad(const Ctx& x, const void* dC, long ld_dc, const GemmOperand& A, float* dW, int N, int Kout, long Mred,
                  int groups, long dc_g, long dw_g, int jdiv = 0, long sj1 = 0, long sj0 = 0, int idiv = 0, long si1 = 0,
@@ -770,8 +806,8 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
   return 0;
 }
 
-int backward(const Ctx& x, float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden,
-             const void* d_cnn = nullptr, const void* d_qkv_last = nullptr) {
+int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden,
+                  const void* d_cnn, const void* d_qkv_last) {
   const Plan& p = x.p;
   const fh_student_config& c = p.c;
   const Shapes& s = p.sh;
@@ -923,6 +959,12 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     }
   }
 
+  // the projection heads' parameter gradients are complete (as queued work): first segment of the data-parallel exchange
+  if (have_ghead && g_notify.on()) {
+    RC(g_notify.fire(p.pl.head0, p.pl.total - p.pl.head0, true));
+    g_notify.seg++;
+    g_notify.heads_done = true;
+  }
   // ---------------- grouped weight / bias gradients of layers [l0, l0 + nl): one launch per linear, on the side stream.  Issued
   // once for all layers behind the layer loop (chunks of 4 layers from inside the loop were measured: the smaller groups lose more
   // than the extra overlap gains).
@@ -1015,6 +1057,11 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     dy_next = x.at(p.dxin, (long)(l & 1) * M2 * D);
   }
   RC(layer_wgrads(0, L));
+  if (g_notify.on()) {  // every transformer layer's weights, biases and LayerNorm parameters
+    RC(g_notify.fire(p.pl.layer0, (long)L * p.pl.layer_stride, true));
+    g_notify.seg++;
+    g_notify.layers_done = true;
+  }
   // ---------------- time-reduction conv backward
   const void* d_x1;  // gradient w.r.t. the encoder LayerNorm(+dropout) output
   if (c.tr_factor > 0) {
@@ -1085,11 +1132,13 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     RC(wgrad(x, x.W(p.dfeat), D, A, grads + p.pl.post_w, D, E, s.Mp, 1, 0, 0));
     RC(fh_colsum_launch(dt, x.W(p.dfeat), grads + p.pl.post_b, (int)s.Mp, D, D, 1, 0, 0, 0, 1.f, x.st));
   }
-  if (c.feature_grad_mult <= 0.f) return 0;  // model.py:432-434: extractor under no_grad
+  // the LayerNorm behind the extractor sits OUTSIDE the reference's no_grad block (model.py:432-447): its weight / bias gradients
+  // exist even when the extractor is frozen
   const int nl = c.n_conv - 1;
   RC(fh_layernorm_bwd_launch(dt, x.W(p.dln0), nullptr, x.W(p.y[nl]), x.W<float>(p.ln0_mean), x.W<float>(p.ln0_rstd),
                              x.params + p.pl.ln_w, x.W(p.dylast), nullptr, grads + p.pl.ln_w, grads + p.pl.ln_b, (int)s.Mp, E,
                              x.drop(0.f, 0), x.drop(0.f, 0), x.st));
+  if (c.feature_grad_mult <= 0.f) return 0;  // model.py:432-434: extractor under no_grad
   // ---------------- conv frontend backward (GradMultiply: model.py:430-431 scales the gradient entering it)
   const void* dy0 = nullptr;
   if (nl == 0) {
@@ -1150,7 +1199,36 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
                          x.W<float>(p.c0_mean), x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch),
                          x.W<float2>(p.c0_scratch) + (long)B * fh_conv0_nchunk(s.T[0]) * c.conv_dim[0], grads + p.pl.conv_w[0],
                          grads + p.pl.gn_w, grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st));
-  return g_wside.join(x.st);
+  return 0;
+}
+
+// The parameter-gradient side stream is joined on EVERY exit of the backward -- the frozen-extractor return (feature_grad_mult == 0,
+// model.py:432-434) and every error return included: the caller's next work on the main stream (gradient all-reduce, AdamW, the
+// allocator handing the workspace out again) must be ordered behind the side stream's atomics into `grads` and its reads of `ws`.
+int backward(const Ctx& x, float* grads, const float* wave, const int* lens, const void* d_pred, const void* d_hidden,
+             const void* d_cnn = nullptr, const void* d_qkv_last = nullptr, const fh_grad_notify* nt = nullptr) {
+  g_notify.n = nt;
+  g_notify.main = x.st;
+  g_notify.seg = 0;
+  g_notify.heads_done = g_notify.layers_done = false;
+  int rc = backward_body(x, grads, wave, lens, d_pred, d_hidden, d_cnn, d_qkv_last);
+  const int j = g_wside.join(x.st);
+  if (!rc) rc = j;
+  if (!rc && g_notify.on()) {
+    // everything not reported yet, in buffer order (the main stream has joined the side stream: one wait covers all of it)
+    const ParamLayout& pl = x.p.pl;
+    const long lay_end = pl.layer0 + (long)x.p.c.layers * pl.layer_stride;
+    long a = 0;
+    auto flush_to = [&](long b) -> int {
+      if (b > a) RC(g_notify.fire(a, b - a, false));
+      return 0;
+    };
+    if (g_notify.layers_done) { rc = flush_to(pl.layer0); a = lay_end; }
+    if (!rc && g_notify.heads_done) { rc = flush_to(pl.head0); a = pl.total; }
+    if (!rc) rc = flush_to(pl.total);
+  }
+  g_notify.n = nullptr;
+  return rc;
 }
 
 }  // namespace
@@ -1265,6 +1343,17 @@ int fh_student_backward_ex(const fh_student_config* c, const fh_student_call* k,
   if (p.ok != 0) return p.ok;
   Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
   return backward(x, grads, wave, lens, g->d_pred, g->d_hidden, g->d_cnn, g->d_qkv_last);
+}
+
+int fh_student_backward_notify(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
+                               float* grads, const float* wave, const int* lens, const fh_student_grads* g, const fh_grad_notify* n,
+                               fh_stream_t stream) {
+  if (!c || !k || !g) return -1;
+  RC(validate(*c));
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
+  return backward(x, grads, wave, lens, g->d_pred, g->d_hidden, g->d_cnn, g->d_qkv_last, n);
 }
 
 }  // extern "C"

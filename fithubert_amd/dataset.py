@@ -65,7 +65,14 @@ def collate(waves: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
     for i, w in enumerate(waves):
         x[i, : len(w)] = w
     mask = ~(torch.arange(S)[None, :] < lens[:, None])
-    return {"x": x, "padding_mask": mask}
+    # host-side facts about the batch, so that the training step never has to read them back from the device (``x`` and
+    # ``padding_mask`` are the reference's keys; underscore keys are ours and stay on the host when the batch moves)
+    return {"x": x, "padding_mask": mask, "_lengths": [int(v) for v in lens], "_any_pad": bool(int(lens.min()) < S)}
+
+
+def to_device(batch: Dict[str, object], device, non_blocking: bool = True) -> Dict[str, object]:
+    """Move a batch's tensors to `device`; host-side keys (``_lengths``, ``_any_pad``) stay where they are."""
+    return {k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
 class SyntheticLibriDataset:
@@ -93,7 +100,8 @@ class SyntheticLibriDataset:
 def fixed_length_batch(batch_size: int, samples: int, seed: int = 0, rms: float = 0.1, device="cpu") -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     x = rms * torch.randn(batch_size, samples, generator=g)
-    return {"x": x.to(device), "padding_mask": torch.zeros(batch_size, samples, dtype=torch.bool, device=device)}
+    return {"x": x.to(device), "padding_mask": torch.zeros(batch_size, samples, dtype=torch.bool, device=device),
+            "_lengths": [samples] * batch_size, "_any_pad": False}
 
 
 def draw_lengths(table: np.ndarray, n: int, seed: int = 0) -> List[int]:

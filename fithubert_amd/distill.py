@@ -61,10 +61,16 @@ def _make_low_priority_stream(device: torch.device) -> "torch.cuda.Stream":
 class W2V2Distil:
     def __init__(self, cfg: dict, dtype: str = "bf16", device: str = "cuda", teacher: Optional[TeacherWrapper] = None,
                  teacher_cfg: Optional[TeacherConfig] = None, seed: int = 0, teacher_dtype=torch.bfloat16,
-                 teacher_native_frontend: bool = False):
+                 teacher_native_frontend: bool = False, student_model=None, dump_dir: Optional[str] = None):
+        """``student_model``: an already built student (tests inject a stub with the engine's interface to drive the
+        accumulation / gradient-exchange ordering on CPU).  ``dump_dir``: write the effective yaml there on rank 0, as the
+        reference's constructor does (train.py:47, utils/utils.py:153-180)."""
+        import torch.distributed as dist
         self.yaml_cfg = cfg
         self.train_cfg = cfg["train"]
         self.device = torch.device(device)
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.seed = seed
         # ---- teacher (train.py:35-37): frozen, eval
         if teacher is None:
             name = str(cfg.get("teacher", {}).get("teacher_model", "hubert"))
@@ -78,8 +84,11 @@ class W2V2Distil:
         student_config = CustomStudentModelConfig(**self.model_cfg)
         student_config._teacher_task_agnostic = True
         student_config._cnn_weight = self.train_cfg["cnn_loss_weight"]
-        self.student_model = CustomStudentModel(student_config, teacher_model=self.teacher_model, dtype=dtype, device=device,
-                                                init_seed=seed)
+        self.student_config = student_config
+        if dump_dir is not None and self.rank == 0:
+            self.dump_yaml(dump_dir)
+        self.student_model = student_model if student_model is not None else \
+            CustomStudentModel(student_config, teacher_model=self.teacher_model, dtype=dtype, device=device, init_seed=seed)
         self.engine = self.student_model.engine
         # ---- loss settings (train.py:55-62)
         t = self.train_cfg
@@ -106,7 +115,10 @@ class W2V2Distil:
         if t.get("specaug"):
             raise NotImplementedError("specaug applies to the mel branch only, which is out of scope")
         self.num_encoders = self.model_cfg["encoder_layers"]
-        self._rng = random.Random(seed)  # the reference samples with the unseeded global RNG per process (train.py:91)
+        # The reference samples rand_l with the unseeded global RNG of each DDP process (train.py:91,174).  Here the stream is
+        # seeded and IDENTICAL on every rank on purpose: the per-layer loss weights must agree across ranks or the all-reduced
+        # gradient mixes different objectives; it is part of the checkpoint, so a resumed run continues the sequence.
+        self._rng = random.Random(seed)
         if t["distil_random_layer"] > 0:
             self.all_enc = range(self.num_encoders - 1)
             self.rand_l = self._rng.sample(self.all_enc, t["distil_random_layer"])
@@ -217,6 +229,7 @@ class W2V2Distil:
 
     def training_epoch_end(self, training_step_outputs=None):
         """train.py:172-174."""
+        self._next_teacher = None   # a prefetched teacher forward never crosses an epoch boundary (the order is reshuffled)
         if self.train_cfg["distil_random_layer"] > 0:
             self.rand_l = self._rng.sample(self.all_enc, self.train_cfg["distil_random_layer"])
             self._set_loss_tables()
@@ -238,18 +251,39 @@ class W2V2Distil:
         return lr * max(0.0, (self.num_training_steps - step) / max(1, self.num_training_steps - warm))
 
     # ------------------------------------------------------------------ hot path
+    @staticmethod
+    def _host_lengths(batch) -> Optional[List[int]]:
+        """Valid samples per utterance as a host list when some utterance is padded, else None.  ``dataset.collate`` supplies
+        ``_lengths`` / ``_any_pad`` from the CPU, so the step never reads the mask back; a foreign batch dict (the reference's two
+        keys only) costs one blocking device-to-host copy here."""
+        pm = batch.get("padding_mask")
+        if pm is None:
+            return None
+        lengths, any_pad = batch.get("_lengths"), batch.get("_any_pad")
+        if any_pad is None:
+            any_pad = (min(int(n) for n in lengths) < pm.shape[1]) if lengths is not None else bool(pm.any())
+        if not any_pad:
+            return None
+        if lengths is None:
+            lengths = (~pm).sum(-1).tolist()
+        return [int(n) for n in lengths]
+
     @torch.no_grad()
     def teacher_hiddens(self, batch) -> torch.Tensor:
         self.teacher_model.eval()  # train.py:131
         pm = batch.get("padding_mask")
-        if pm is not None and not bool(batch.get("_any_pad", True)) and self.teacher_model.model.cfg.model_type != "hubert":
-            pm = None
+        lengths = batch.get("_lengths")
+        if pm is not None and lengths is None and "_any_pad" not in batch:
+            pass          # foreign batch: the teacher derives its frame mask from the device mask
+        elif pm is not None and self._host_lengths(batch) is None and self.teacher_model.model.cfg.model_type != "hubert":
+            pm = None     # wav2vec 2.0 rule: no mask at all when nothing is padded
         if self.cnn_loss_weight > 0 or self._attn_transfer:
-            hid, post, _ = self.teacher_model.model.run(batch["x"], pm)
+            hid, post, _ = self.teacher_model.model.run(batch["x"], pm, lengths=lengths)
             hid._fh_post = post.contiguous()   # CNN loss target: the teacher's post_extract_proj output (utils/utils.py:71-73 hook)
             hid._fh_qkv = self.teacher_model.model.last_qkv   # attention transfer: the last layer's q|k|v projection
+            hid._fh_key_len = self.teacher_model.model.last_key_len
             return hid
-        return self.teacher_model.hidden_stack(batch["x"], pm)
+        return self.teacher_model.hidden_stack(batch["x"], pm, lengths=lengths)
 
     def _teacher_async(self, batch):
         """Enqueue the teacher forward on the side stream; returns (hidden stack, event that marks it ready)."""
@@ -262,7 +296,7 @@ class W2V2Distil:
             ev = torch.cuda.Event()
             ev.record(self.teacher_stream)
         hid.record_stream(main)  # consumed by the loss kernel on the main stream
-        for extra in ("_fh_post", "_fh_qkv"):
+        for extra in ("_fh_post", "_fh_qkv", "_fh_key_len"):
             t = getattr(hid, extra, None)
             if t is not None:
                 t.record_stream(main)
@@ -274,19 +308,24 @@ class W2V2Distil:
         gradient all-reduce, (next batch's teacher forward), AdamW.  Returns the fp64 device vector
         [per-layer means..., total] (no host sync)."""
         x = batch["x"]
-        pm = batch.get("padding_mask")
-        lengths = None
-        if pm is not None and bool(batch.get("_any_pad", pm.any())):
-            lengths = batch.get("_lengths")
-            if lengths is None:
-                lengths = (~pm).sum(-1).tolist()
-        hid, ev = self._next_teacher if self._next_teacher is not None else self._teacher_async(batch)
+        lengths = self._host_lengths(batch)
+        # a prefetched teacher forward is used only for the batch it was computed on (identity of the waveform tensor): a skipped
+        # batch, an exception between steps or a caller that passes another batch recomputes instead of distilling against
+        # the wrong utterances
+        pre = self._next_teacher
+        if pre is not None and pre[0] is x:
+            hid, ev = pre[1], pre[2]
+        else:
+            hid, ev = self._teacher_async(batch)
         # the NEXT batch's teacher forward goes to the side stream now: it runs under this step's student fwd/bwd,
         # the gradient all-reduce and the optimizer
-        self._next_teacher = self._teacher_async(next_batch) if next_batch is not None else None
+        self._next_teacher = ((next_batch["x"],) + self._teacher_async(next_batch)) if next_batch is not None else None
         if self._micro == 0:
             self.engine.grads.zero_()
-        step_seed = seed if seed is not None else (self.opt_step * 7919 + self._micro * 104729 + batch_idx + 1)
+        # dropout masks are a pure function of (seed, site, index): the rank term gives every data-parallel rank its own masks,
+        # as the reference's per-process RNG streams do
+        step_seed = seed if seed is not None else \
+            ((self.opt_step * 7919 + self._micro * 104729 + batch_idx + 1 + self.rank * 0x9E3779B1) & 0xFFFFFFFF)
         ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed)
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
@@ -312,6 +351,7 @@ class W2V2Distil:
             D3 = 3 * self.engine.c.embed_dim
             s_qkv = ws.view("qkv")[-1].view(x.shape[0], -1, D3)
             key_len = ws.lens[1] if ws.lens is not None else None
+            t_key_len = getattr(hid, "_fh_key_len", None)
             with torch.enable_grad():
                 tot, parts, d_qkv = transfer(s_qkv, hid._fh_qkv, self.engine.c.heads, self.teacher_model.model.cfg.encoder_attention_heads,
                                              key_len, float(self.attn_loss_weight), self.attn_loss_type, float(self.v_rel_loss_weight))
@@ -319,11 +359,20 @@ class W2V2Distil:
             self.last_transfer_losses = parts
             feat_total = out[-1] if (self._rows_loss or self.cnn_loss_weight > 0) else float(self.rec_loss_weight) * out[-1]
             out = torch.cat([out[:-1], (feat_total + tot.double()).reshape(1)])
-        self.engine.backward(ws, d_pred=d_pred, d_cnn=d_cnn, d_qkv_last=d_qkv)
+        last_micro = self._micro + 1 >= self.accumulate
+        if last_micro and self.sync.active:
+            # the gradient exchange starts INSIDE the backward: the heads' bucket goes on the wire when the head branch is queued,
+            # the layers' bucket behind the layer loop, the rest at the end -- each ordered (device side) behind its producers
+            self.sync.begin()
+            self.engine.backward(ws, d_pred=d_pred, d_cnn=d_cnn, d_qkv_last=d_qkv, on_segment=self.sync.on_segment,
+                                 comm_stream=self.sync.comm_handle)
+            if not self.sync.covered():
+                raise RuntimeError("gradient segments reported by the backward do not tile the gradient buffer")
+        else:
+            self.engine.backward(ws, d_pred=d_pred, d_cnn=d_cnn, d_qkv_last=d_qkv)
         self._micro += 1
-        if self._micro >= self.accumulate:
-            self.sync.launch()                      # async all-reduce of the flat gradients (RCCL / xGMI)
-            self.sync.wait()
+        if last_micro:
+            self.sync.wait()                        # the student stream (not the host) waits for the reduced gradients
             self.optimizer_step()
         return out
 
@@ -333,23 +382,21 @@ class W2V2Distil:
         b1, b2 = [float(v) for v in o.get("betas", (0.9, 0.999))]
         self.opt_step += 1
         t = self.opt_step
-        L.check(L.lib().fh_adamw(self.engine.params.data_ptr(), self.engine.grads.data_ptr(), self.opt_m.data_ptr(),
-                                 self.opt_v.data_ptr(), self.engine.n_params, self.lr_at(t - 1), b1, b2, float(o.get("eps", 1e-8)),
-                                 float(o.get("weight_decay", 0.0)), 1.0 - b1 ** t, 1.0 - b2 ** t,
-                                 self.sync.scale / self.accumulate, None, self.engine.stream()), "fh_adamw")
+        self.engine.adamw(self.opt_m, self.opt_v, self.lr_at(t - 1), b1, b2, float(o.get("eps", 1e-8)),
+                          float(o.get("weight_decay", 0.0)), t, self.sync.scale / self.accumulate)
         self._micro = 0
         self.student_model.mark_params_updated()
-        self.student_model._flat_version = self.student_model.flat._version
+        if hasattr(self.student_model, "flat"):
+            self.student_model._flat_version = self.student_model.flat._version
 
     # ------------------------------------------------------------------ validation / epoch loop (train.py:179-199, 475-501)
     @torch.no_grad()
     def validation_step(self, batch, batch_idx: int = 0) -> Dict[str, torch.Tensor]:
         """train.py:179-199: the loss on a held-out bucket, dropout off; with random-layer distillation the monitored value is
         the LAST layer's loss (train.py:194-195)."""
-        x, pm = batch["x"], batch.get("padding_mask")
-        lengths = None
-        if pm is not None and bool(pm.any()):
-            lengths = (~pm).sum(-1).tolist()
+        x = batch["x"]
+        lengths = self._host_lengths(batch)
+        self._next_teacher = None
         hid = self.teacher_hiddens(batch)
         ws = self.engine.forward(x, lengths, training=False, heads_on=self.student_model._heads_on)
         if self._rows_loss:
@@ -371,15 +418,20 @@ class W2V2Distil:
         save_top_k=3, monitor v_loss) and EarlyStopping(patience 15).  Datasets index whole buckets (``LibriDataset`` /
         ``SyntheticLibriDataset``)."""
         import os as _os
-        from .dataset import rank_buckets
+        from .dataset import rank_buckets, to_device
         num_epochs = int(num_epochs if num_epochs is not None else self.train_cfg["num_epochs"])
         steps_per_epoch = max(1, len(train_data) // max(1, world)) // max(1, self.accumulate)
         if not self.num_training_steps:
             self.configure_optimizers(max(1, steps_per_epoch * num_epochs))
-        to_dev = lambda b: {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+        first_epoch = 0
+        ck = self.train_cfg.get("checkpoint")
+        if ck and output_dir and _os.path.exists(_os.path.join(output_dir, str(ck))):
+            # train.py:466,506-509: trainer.fit(ckpt_path=output_dir/checkpoint) restores weights, optimizer and loop position
+            first_epoch = self.load_checkpoint(_os.path.join(output_dir, str(ck))) + 1
+        to_dev = lambda b: to_device(b, self.device)
         best: List[tuple] = []
         history, bad_epochs, best_v = [], 0, float("inf")
-        for epoch in range(num_epochs):
+        for epoch in range(first_epoch, num_epochs):
             order = rank_buckets(len(train_data), epoch, rank, world, seed=0, shuffle=True)
             nxt = to_dev(train_data[order[0]])
             tl = None
@@ -428,8 +480,58 @@ class W2V2Distil:
         return sd
 
     def save_checkpoint(self, path: str, epoch: int = 0) -> None:
+        """Lightning's checkpoint convention (train.py:475-483): ``state_dict`` with ``student_model.`` / ``teacher_model.model.``
+        prefixes -- what ``fithubert/expert.py:40-45`` loads -- plus everything an exact resume needs (train.py:466,506-509:
+        ``trainer.fit(ckpt_path=...)`` restores optimizer, schedule position and loop state): AdamW moments, the optimizer step,
+        the schedule length, the accumulation phase, the current random-layer draw and its RNG state."""
         torch.save({"state_dict": {k: v.cpu() for k, v in self.state_dict().items()}, "epoch": epoch,
-                    "global_step": self.opt_step, "hyper_parameters": {"cfg": self.yaml_cfg}}, path)
+                    "global_step": self.opt_step, "hyper_parameters": {"cfg": self.yaml_cfg},
+                    "optimizer_states": [{"exp_avg": self.opt_m.cpu(), "exp_avg_sq": self.opt_v.cpu(), "step": self.opt_step}],
+                    "fithubert_amd": {"num_training_steps": self.num_training_steps, "micro": self._micro,
+                                      "rand_l": list(self.rand_l), "rng_state": self._rng.getstate(),
+                                      "grads": self.engine.grads.cpu() if self._micro else None}}, path)
+
+    def load_checkpoint(self, path: str, strict: bool = True) -> int:
+        """Restore a checkpoint written by ``save_checkpoint`` (or any Lightning-convention ``.ckpt`` of this student: then only the
+        weights).  Returns the epoch stored in it."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        sd = {k[len("student_model."):]: v for k, v in ck["state_dict"].items() if k.startswith("student_model.")}
+        self.student_model.load_state_dict(sd, strict=strict)
+        self.student_model.mark_params_updated()
+        opt = ck.get("optimizer_states")
+        if opt:
+            self.opt_m.copy_(opt[0]["exp_avg"].to(self.opt_m.device))
+            self.opt_v.copy_(opt[0]["exp_avg_sq"].to(self.opt_v.device))
+            self.opt_step = int(opt[0]["step"])
+        ex = ck.get("fithubert_amd")
+        if ex:
+            self.num_training_steps = ex["num_training_steps"]
+            self._micro = int(ex["micro"])
+            self.rand_l = list(ex["rand_l"])
+            st = ex["rng_state"]
+            self._rng.setstate((st[0], tuple(st[1]), st[2]))
+            if ex.get("grads") is not None:
+                self.engine.grads.copy_(ex["grads"].to(self.engine.grads.device))
+            self._set_loss_tables()
+        self._next_teacher = None
+        return int(ck.get("epoch", 0))
+
+    def dump_yaml(self, dump_dir: str, name: Optional[str] = None) -> dict:
+        """utils/utils.py:153-180: the yaml with the ``distiller`` section overwritten by the effective student config (every
+        public dataclass field, defaults included), written as ``<dump_dir>/<time tag>.yaml``.  The reference calls it from every
+        process (train.py:45-47 carries a TODO about that); here only rank 0 does."""
+        import copy
+        import datetime
+        import yaml
+        d = copy.deepcopy(self.yaml_cfg)
+        for k, v in self.student_config.public_dict().items():
+            d["distiller"][k] = str(v) if k in ("activation_fn", "extractor_mode", "layer_type") else v
+        os.makedirs(dump_dir, exist_ok=True)
+        if name is None:   # utils/utils.py:183-184: Asia/Seoul wall clock
+            name = (datetime.datetime.utcnow() + datetime.timedelta(hours=9)).strftime("%Y-%m-%d_%Hh%Mm%Ss")
+        with open(os.path.join(dump_dir, name + ".yaml"), "w") as f:
+            yaml.dump(d, f, sort_keys=False)
+        return d
 
 
 class _L1Fn(torch.autograd.Function):

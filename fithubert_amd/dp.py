@@ -42,24 +42,60 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
 
 
 class GradSync:
-    """Asynchronous bucketed all-reduce (sum) of a flat gradient buffer."""
+    """Asynchronous bucketed all-reduce (sum) of a flat gradient buffer.
+
+    Two ways to start it: ``launch()`` -- the whole buffer, behind everything queued on the current stream; or, from inside the
+    native backward (``fh_student_backward_notify``), ``begin()`` then one ``on_segment(seg, first, count)`` per gradient range as
+    it becomes final (projection heads first, transformer layers next, encoder front last): the library has already made
+    ``comm_stream`` wait for the kernels that write the range, and the collective is enqueued under that stream -- so the heads'
+    and the layers' buckets are on the wire while the conv frontend is still in backward.  ``wait()`` makes the current stream
+    (not the host) wait for every bucket."""
 
     def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 48 << 20, group=None):
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.per = max(1, bucket_bytes // flat_grads.element_size())
         n = flat_grads.numel()
-        per = max(1, bucket_bytes // flat_grads.element_size())
-        self.bounds: List[tuple] = [(i, min(n, i + per)) for i in range(0, n, per)]
+        self.bounds: List[tuple] = [(i, min(n, i + self.per)) for i in range(0, n, self.per)]
         self._works = []
+        self.launched: List[tuple] = []   # (first, last) element ranges of the current exchange, in launch order
+        self.comm_stream = None
+        if flat_grads.is_cuda and dist.is_initialized():
+            self.comm_stream = torch.cuda.Stream(device=flat_grads.device)
+
+    @property
+    def active(self) -> bool:
+        return dist.is_initialized()
+
+    @property
+    def comm_handle(self) -> Optional[int]:
+        return self.comm_stream.cuda_stream if self.comm_stream is not None else None
+
+    def begin(self) -> None:
+        self._works = []
+        self.launched = []
+
+    def on_segment(self, segment: int, first: int, count: int) -> None:
+        """All-reduce flat[first : first + count] in buckets; ordered behind ``comm_stream`` when there is one."""
+        if not dist.is_initialized():
+            self.launched.append((first, first + count))
+            return
+        ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _NullCtx()
+        with ctx:
+            for a in range(first, first + count, self.per):
+                b = min(first + count, a + self.per)
+                self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.launched.append((a, b))
 
     def launch(self) -> None:
-        """Enqueue the reduction behind everything already queued on the current stream; returns immediately."""
-        self._works = []
+        """Enqueue the reduction of the whole buffer behind everything already queued on the current stream; returns at once."""
+        self.begin()
         if not dist.is_initialized():
             return  # single process without a group; a 1-rank group still runs the (trivial) collective
-        for a, b in self.bounds:
-            self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        self.on_segment(0, 0, self.flat.numel())
 
     def wait(self) -> None:
         """Make the current stream (not the host) wait for the reduction."""
@@ -67,10 +103,27 @@ class GradSync:
             w.wait()
         self._works = []
 
+    def covered(self) -> bool:
+        """True when the ranges launched since ``begin()`` tile the whole buffer exactly once."""
+        pos = 0
+        for a, b in sorted(self.launched):
+            if a != pos:
+                return False
+            pos = b
+        return pos == self.flat.numel()
+
     @property
     def scale(self) -> float:
         """all_reduce sums; the optimizer kernel folds the 1/world mean in (no extra pass over the gradients)."""
         return 1.0 / self.world
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None) -> None:

@@ -257,17 +257,44 @@ class StudentEngine:
 
     def backward(self, ws: Workspace, d_pred: Optional[torch.Tensor] = None, d_hidden: Optional[torch.Tensor] = None,
                  grads: Optional[torch.Tensor] = None, d_cnn: Optional[torch.Tensor] = None,
-                 d_qkv_last: Optional[torch.Tensor] = None) -> None:
+                 d_qkv_last: Optional[torch.Tensor] = None, on_segment=None, comm_stream: Optional[int] = None) -> None:
+        """``on_segment(segment, first, count)``: called (on this thread, during the call) each time the range
+        [first, first + count) of the flat gradient buffer is final; ``comm_stream`` (raw HIP stream) has by then been made to
+        wait for the kernels that write it (fh_student_backward_notify) -- the data-parallel exchange hooks in here."""
         grads = self.grads if grads is None else grads
         for t in (d_pred, d_hidden, d_cnn, d_qkv_last):
             if t is not None:
                 assert t.is_cuda and t.is_contiguous() and t.dtype == self.elem
         ptr = lambda t: t.data_ptr() if t is not None else None
         g = L.StudentGradsC(ptr(d_pred), ptr(d_hidden), ptr(d_cnn), ptr(d_qkv_last))
-        L.check(self.lib.fh_student_backward_ex(
+        lens = ws.lens.data_ptr() if ws.lens is not None else None
+        if on_segment is None:
+            L.check(self.lib.fh_student_backward_ex(
+                C.byref(self.c), C.byref(ws.call), self.params.data_ptr(), self.wc.data_ptr(), ws.buf.data_ptr(), grads.data_ptr(),
+                ws.wave.data_ptr(), lens, C.byref(g), self.stream()), "fh_student_backward")
+            return
+        errors = []
+
+        def _ready(_user, seg, first, count):   # an exception must not unwind through the C frames
+            try:
+                on_segment(int(seg), int(first), int(count))
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        cb = L.GRAD_READY_FN(_ready)
+        n = L.GradNotifyC(comm_stream if comm_stream is not None else self.stream(), cb, None)
+        rc = self.lib.fh_student_backward_notify(
             C.byref(self.c), C.byref(ws.call), self.params.data_ptr(), self.wc.data_ptr(), ws.buf.data_ptr(), grads.data_ptr(),
-            ws.wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None, C.byref(g), self.stream()),
-            "fh_student_backward")
+            ws.wave.data_ptr(), lens, C.byref(g), C.byref(n), self.stream())
+        if errors:
+            raise errors[0]
+        L.check(rc, "fh_student_backward_notify")
+
+    def adamw(self, m: torch.Tensor, v: torch.Tensor, lr: float, b1: float, b2: float, eps: float, wd: float, step: int,
+              grad_scale: float) -> None:
+        """One fused AdamW update of the flat fp32 parameters (bias-corrected; ``grad_scale`` folds 1/world and 1/accumulation)."""
+        L.check(self.lib.fh_adamw(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(), self.n_params, lr, b1, b2,
+                                  eps, wd, 1.0 - b1 ** step, 1.0 - b2 ** step, grad_scale, None, self.stream()), "fh_adamw")
 
     def kd_loss_rows(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
                      loss_type: int = 1, rec_weight: float = 1.0, sim_weight: float = 1.0, want_grad: bool = True):

@@ -359,11 +359,33 @@ class TeacherModel(nn.Module):
         self._native = None
         return self
 
-    def _frame_mask(self, padding_mask, T):
+    def frame_lengths(self, sample_lengths, S: int, T: int):
+        """Valid frames per utterance from HOST sample lengths (right-padded batch), the same rule as ``_frame_mask`` without
+        touching the device: HuBERT -- a frame is padding iff all samples of its S // T chunk are (fairseq
+        forward_padding_mask); wav2vec 2.0 -- the conv-length formula."""
+        if self.cfg.model_type == "hubert":
+            chunk = (S - S % T) // T
+            return [min(T, -(-int(n) // chunk)) for n in sample_lengths]
+        out = []
+        for n in sample_lengths:
+            n = int(n)
+            for (_, k, s) in self.feature_extractor.spec:
+                n = (n - k) // s + 1
+            out.append(max(0, min(T, n)))
+        return out
+
+    def _frame_mask(self, padding_mask, T, lengths=None):
         """True = padded frame.  HuBERT: all samples of the frame are padding (fairseq forward_padding_mask);
-        wav2vec 2.0: conv-length formula, and None when nothing is padded."""
+        wav2vec 2.0: conv-length formula, and None when nothing is padded.  With ``lengths`` (host list of valid samples of a
+        right-padded batch) the mask is built from them -- no device-to-host synchronisation."""
         if padding_mask is None:
             return None
+        if lengths is not None:
+            S = int(padding_mask.size(1))
+            if self.cfg.model_type != "hubert" and min(int(n) for n in lengths) >= S:
+                return None
+            fl = torch.tensor(self.frame_lengths(lengths, S, T), dtype=torch.int64).to(padding_mask.device, non_blocking=True)
+            return torch.arange(T, device=padding_mask.device)[None, :] >= fl[:, None]
         if self.cfg.model_type == "hubert":
             extra = padding_mask.size(1) % T
             pm = padding_mask[:, :-extra] if extra > 0 else padding_mask
@@ -376,8 +398,9 @@ class TeacherModel(nn.Module):
         return torch.arange(T, device=padding_mask.device)[None, :] >= lens[:, None]
 
     @torch.no_grad()
-    def run(self, source, padding_mask=None, want_fc2: bool = False):
-        """-> (hidden [L][B][T][C], post_extract_proj [B][T][C], fc2 list or None)"""
+    def run(self, source, padding_mask=None, want_fc2: bool = False, lengths=None):
+        """-> (hidden [L][B][T][C], post_extract_proj [B][T][C], fc2 list or None).  ``lengths``: optional host list of valid
+        samples per utterance (right-padded batch), see ``_frame_mask``."""
         dt = self.post_extract_proj.weight.dtype
         native = None
         if self.native_frontend:
@@ -394,7 +417,7 @@ class TeacherModel(nn.Module):
                 torch.cuda.synchronize(source.device)
                 native.lib.fh_gemm_tune(1)
                 try:
-                    return self.run(source, padding_mask, want_fc2)
+                    return self.run(source, padding_mask, want_fc2, lengths)
                 finally:
                     native.lib.fh_gemm_tune(0)
             x = native.features(self, source)
@@ -402,7 +425,7 @@ class TeacherModel(nn.Module):
             x = self.feature_extractor(source.to(dt)).transpose(1, 2)
         x = self.layer_norm(x)
         B, T, _ = x.shape
-        fm = self._frame_mask(padding_mask, T)
+        fm = self._frame_mask(padding_mask, T, lengths)
         post = self.post_extract_proj(x)
         x = post
         if fm is not None:
@@ -464,8 +487,8 @@ class TeacherWrapper(nn.Module):
             layer_results[-1] = (layer_results[-1][0], (extras, layer_results[-1][1][1]))
         return {"layer_results": layer_results, "x": hidden[-1], "features": [post]}
 
-    def hidden_stack(self, source, padding_mask=None):
-        return self.model.run(source, padding_mask)[0]
+    def hidden_stack(self, source, padding_mask=None, lengths=None):
+        return self.model.run(source, padding_mask, lengths=lengths)[0]
 
 
 def freeze_model(model: nn.Module) -> None:

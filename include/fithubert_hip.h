@@ -273,6 +273,23 @@ typedef struct {
 int fh_student_backward_ex(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
                            void* ws, float* grads, const float* wave, const int* lens, const fh_student_grads* g,
                            fh_stream_t stream);
+/* Backward that REPORTS gradient segments as they become final, so that the data-parallel exchange (the reference gets it from
+ * DDP's bucketed all-reduce hooks under Lightning strategy='ddp', train.py:494) starts while earlier layers are still in backward.
+ * Each time a contiguous range [first, first + count) of the flat gradient buffer has received its last contribution, the library
+ * (1) makes `comm_stream` wait -- hipStreamWaitEvent, device side only -- for every kernel that writes the range, on whichever of
+ * its streams they were queued, and (2) calls `ready(user, segment, first, count)` synchronously on the calling host thread; the
+ * callee enqueues its collective for that range on `comm_stream` (or on a stream ordered behind it).  Segments arrive in completion
+ * order: projection heads, transformer layers, then the encoder front (time reduction, positional conv, projection, conv
+ * frontend); together the ranges cover the whole buffer exactly once.  n == NULL: same as fh_student_backward_ex. */
+typedef void (*fh_grad_ready_fn)(void* user, int segment, long first, long count);
+typedef struct {
+  fh_stream_t comm_stream;
+  fh_grad_ready_fn ready;
+  void* user;
+} fh_grad_notify;
+int fh_student_backward_notify(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
+                               void* ws, float* grads, const float* wave, const int* lens, const fh_student_grads* g,
+                               const fh_grad_notify* n, fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frozen-teacher conv frontend on the student's kernels.  The teacher (fairseq HubertModel /

@@ -3,6 +3,7 @@ import os
 
 import pytest
 import torch
+from fithubert_amd.dataset import to_device
 import yaml
 
 pytestmark = pytest.mark.gpu
@@ -159,8 +160,8 @@ def test_baseline_configs_3_4_5_plumbing():
         assert int(task.teacher_layer[-1]) == 3  # the last student layer is distilled from the teacher's LAST layer
         vals = []
         for i in range(4):
-            b = {k: v.to(DEV) for k, v in ds[i % 2].items()}
-            out = task.training_step(b, batch_idx=i, next_batch={k: v.to(DEV) for k, v in ds[(i + 1) % 2].items()})
+            b = to_device(ds[i % 2], DEV)
+            out = task.training_step(b, batch_idx=i, next_batch=to_device(ds[(i + 1) % 2], DEV))
             vals.append(out[-1].item())
         assert all(v == v and v < 1e4 for v in vals), vals      # finite
         assert task.opt_step == 2                                # accumulate_grad_batches = 2
@@ -199,7 +200,7 @@ def test_ex_yaml_distilhubert_recipe_end_to_end():
         assert torch.equal(ssd[k].float().cpu(), tsd[k].float().cpu()), k
     assert [int(v) for v in task.teacher_layer.tolist()] == [3, 7, 11]
     ds = SyntheticLibriDataset([16000, 14000, 12000, 9000], batch_size=2, seed=2)
-    b = {k: v.to(DEV) for k, v in ds[0].items()}
+    b = to_device(ds[0], DEV)
     # module-API path: forward -> calculate_loss (autograd) against the oracle on the same weights
     sm.train()
     sres, tres = task(b["x"], b["padding_mask"])
@@ -219,8 +220,8 @@ def test_ex_yaml_distilhubert_recipe_end_to_end():
     task.configure_optimizers(num_training_steps=20)
     vals = []
     for i in range(6):
-        bi = {k: v.to(DEV) for k, v in ds[i % 2].items()}
-        vals.append(task.training_step(bi, batch_idx=i, next_batch={k: v.to(DEV) for k, v in ds[(i + 1) % 2].items()})[-1].item())
+        bi = to_device(ds[i % 2], DEV)
+        vals.append(task.training_step(bi, batch_idx=i, next_batch=to_device(ds[(i + 1) % 2], DEV))[-1].item())
     assert all(v == v and v < 1e3 for v in vals), vals
     assert min(vals[-2:]) < vals[0] + 1e-3, vals          # l1 + cosine goes down on a repeated pair of batches
 
@@ -251,7 +252,7 @@ def test_cnn_distillation_loss(recipe):
     # with a head and dropout_input == 0 the reference itself cannot back-propagate a padded batch (in-place zeroing of the GELU's
     # saved input), so that recipe is checked on an unpadded pair
     ds = SyntheticLibriDataset([12000, 10000] if recipe == "ex" else [12000, 12000], batch_size=2, seed=4)
-    b = {k: v.to(DEV) for k, v in ds[0].items()}
+    b = to_device(ds[0], DEV)
     sm.train()
     sres, tres = task(b["x"], b["padding_mask"])
     assert sres["features"].shape[-1] == 768
@@ -306,7 +307,7 @@ def test_attention_and_value_relation_transfer(attn_type):
     # mse: a padded pair (padded keys are -inf in both logits and scrubbed, train.py:336-340); kldiv: unpadded -- on -inf logits
     # the reference's kl-div is NaN (log_softmax(-inf) * 0), a behaviour the oracle shares and tests/test_oracle.py pins
     ds = SyntheticLibriDataset([9000, 7000] if attn_type == "mse" else [9000, 9000], batch_size=2, seed=5)
-    b = {k: v.to(DEV) for k, v in ds[0].items()}
+    b = to_device(ds[0], DEV)
     sm.train()
     sres, tres = task(b["x"], b["padding_mask"])
     s_logits, s_vrel = sres["layer_results"][-1][1]
@@ -356,7 +357,7 @@ def test_fit_loop_validation_checkpoints_and_early_stopping(tmp_path):
     task = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=tc, seed=0, teacher_native_frontend=True)
     train = SyntheticLibriDataset([16000, 15000, 14000, 12000, 11000, 9000], batch_size=2, seed=1)
     held = SyntheticLibriDataset([13000, 10000], batch_size=2, seed=2)
-    v0 = task.validation_step({k: v.to(DEV) for k, v in held[0].items()})["v_loss"].item()
+    v0 = task.validation_step(to_device(held[0], DEV))["v_loss"].item()
     res = task.fit(train, held, num_epochs=4, output_dir=str(tmp_path), patience=15, save_top_k=2)
     hist = res["history"]
     assert len(hist) == 4 and all("v_loss" in h for h in hist)
@@ -368,3 +369,52 @@ def test_fit_loop_validation_checkpoints_and_early_stopping(tmp_path):
     # early stopping: patience 0 stops as soon as v_loss fails to improve
     res2 = task.fit(train, held, num_epochs=50, output_dir=None, patience=1)
     assert res2["stopped_early"] and len(res2["history"]) < 50
+
+
+def test_checkpoint_resume_continues_the_run(tmp_path):
+    """train.py:466,506-509 (``trainer.fit(ckpt_path=...)``): 3 steps -> save -> a fresh task loads -> step 4 and 5 equal an
+    uninterrupted run's.  Weight gradients accumulate with fp32 atomics, so two runs of the SAME process differ in the last bits;
+    the resumed run must sit inside that run-to-run noise (measured here by repeating the uninterrupted run), and everything that
+    is exact -- optimizer step, schedule position, random-layer draw, dropout seeds -- must be equal."""
+    from fithubert_amd.dataset import fixed_length_batch
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+
+    y = _cfg(encoder_layers=3)
+    y["train"].update(distil_random_layer=1, accumulate_grad_batches=1)
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 3
+    batches = [fixed_length_batch(3, 24000, seed=i, device=DEV) for i in range(5)]
+
+    def make(seed=0):
+        t = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=tc, seed=seed)
+        t.configure_optimizers(num_training_steps=20)
+        return t
+
+    def run(t, lo, hi):
+        out = None
+        for i in range(lo, hi):
+            out = t.training_step(batches[i], batch_idx=i)
+            if i == 2:
+                t.training_epoch_end()     # a re-draw of rand_l sits between save and resume
+        return out
+
+    full = []
+    for _ in range(2):
+        t = make()
+        l5 = run(t, 0, 5)[-1].item()
+        full.append((t.engine.params.clone(), l5, list(t.rand_l)))
+    noise = (full[0][0] - full[1][0]).abs().max().item()
+    a = make()
+    run(a, 0, 3)
+    ck = str(tmp_path / "last.ckpt")
+    a.save_checkpoint(ck, epoch=7)
+    b = make(seed=5)                        # different init and RNG stream: everything must come from the checkpoint
+    assert b.load_checkpoint(ck) == 7
+    assert b.opt_step == 3 and b.rand_l == a.rand_l and torch.equal(b.engine.params, a.engine.params)
+    assert torch.equal(b.opt_m, a.opt_m) and torch.equal(b.opt_v, a.opt_v)
+    l5 = run(b, 3, 5)[-1].item()
+    assert b.opt_step == 5 and b.rand_l == full[0][2]
+    d = (b.engine.params - full[0][0]).abs().max().item()
+    assert d <= max(4 * noise, 1e-6), (d, noise)
+    assert abs(l5 - full[0][1]) <= max(4 * abs(full[0][1] - full[1][1]), 2e-3 * abs(full[0][1]))

@@ -41,6 +41,32 @@ dist.barrier()
 assert all(v == v for v in vals), vals
 assert not torch.equal(before, task.engine.params)
 assert_replicas_equal(task.engine.params)
+# the exchange was launched from INSIDE the native backward (fh_student_backward_notify): heads first, then the layers, then
+# the encoder front, on the library-ordered communication stream; the ranges tile the gradient buffer exactly once
+assert task.sync.comm_stream is not None and task.sync.covered(), task.sync.launched
+views = task.engine.param_views(torch.arange(task.engine.n_params))
+first_head = int(views["proj_head.0.upsampler.weight"].reshape(-1)[0])
+first_layer = int(views["encoder.layers.1.self_attn.q_proj.weight"].reshape(-1)[0])
+assert task.sync.launched[0][0] == first_head and any(a == first_layer for a, _ in task.sync.launched), task.sync.launched
+assert task.sync.launched[-1][1] <= first_head
+# same step with the exchange launched after the backward instead: same parameters up to the fp32-atomic noise of two runs
+def fresh():
+    t = W2V2Distil(y, dtype="bf16", device="cuda:0", teacher_cfg=tc, seed=0, teacher_native_frontend=True)
+    t.configure_optimizers(num_training_steps=10)
+    return t
+a, b = fresh(), fresh()
+orig = b.engine.backward
+def late(ws, **kw):
+    kw.pop("on_segment"); kw.pop("comm_stream")
+    orig(ws, **kw)
+    b.sync.launch()
+b.engine.backward = late
+for i in range(2):
+    a.training_step(pool[i %% 2], batch_idx=i)
+    b.training_step(pool[i %% 2], batch_idx=i)
+torch.cuda.synchronize()
+d = (a.engine.params - b.engine.params).abs().max().item()
+assert d < 1e-5, d
 dist.destroy_process_group()
 print("DP_OK", vals)
 ''' % (ROOT, ROOT)

@@ -8,6 +8,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch, yaml
+from fithubert_amd.dataset import to_device
 from fithubert_amd.dataset import SyntheticLibriDataset, fixed_length_batch
 from fithubert_amd.distill import W2V2Distil
 from fithubert_amd.teacher import TeacherConfig
@@ -56,7 +57,7 @@ rng = np.random.default_rng(0)
 pick = rng.choice(lens, size=B * 6, replace=False).tolist()
 ds = SyntheticLibriDataset(pick, batch_size=B, seed=0)
 order = rng.permutation(len(ds)).tolist()
-var = [{k: v.to(DEV) for k, v in ds[i].items()} for i in order[:4]]
+var = [to_device(ds[i], DEV) for i in order[:4]]
 
 ONLY = os.environ.get("ONLY", "")  # e.g. ONLY=2,4a
 run_all = run
