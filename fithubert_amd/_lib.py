@@ -24,7 +24,7 @@ class GemmOperand(C.Structure):
     _fields_ = [
         ("p", C.c_void_p), ("layout", C.c_int), ("ld", C.c_long), ("rpb", C.c_int), ("bstride", C.c_long),
         ("gstride", C.c_long), ("nseg", C.c_int), ("tshift", C.c_int * 2), ("tvalid", C.c_int),
-        ("segoff", C.c_long * 2),
+        ("segoff", C.c_long * 2), ("seg1_limit", C.c_int),
     ]
 
 
@@ -34,7 +34,7 @@ class GemmEpilogue(C.Structure):
         ("preact", C.c_void_p), ("act", C.c_int), ("drop", Drop), ("gelu_aux", C.c_void_p),
         ("residual", C.c_void_p), ("row_len", C.c_void_p), ("out_f32", C.c_int), ("atomic", C.c_int),
         ("idiv", C.c_int), ("si1", C.c_long), ("si0", C.c_long), ("jdiv", C.c_int), ("sj1", C.c_long),
-        ("sj0", C.c_long),
+        ("sj0", C.c_long), ("tail_cols", C.c_int),
     ]
 
 
@@ -147,6 +147,9 @@ SIGNATURES = {
     "fh_kd_loss": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _P]),
     "fh_kd_loss_rows_nblk": (_I, [_I, _I]),
     "fh_kd_loss_rows": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _F, _P]),
+    "fh_relation_tensor": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fh_relation_kd_nblk": (_I, [_I, _I, _I]),
+    "fh_relation_kd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "fh_conv1d_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fh_posconv_wide_prepare": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fh_posconv_wide_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -184,7 +187,7 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed with code {rc}")
 
 
-def operand(t_ptr, layout, ld, rpb=0, bstride=0, gstride=0, nseg=1, tshift=(0, 0), tvalid=0, segoff=(0, 0)):
+def operand(t_ptr, layout, ld, rpb=0, bstride=0, gstride=0, nseg=1, tshift=(0, 0), tvalid=0, segoff=(0, 0), seg1_limit=0):
     o = GemmOperand()
     o.p = t_ptr
     o.layout = layout
@@ -196,6 +199,7 @@ def operand(t_ptr, layout, ld, rpb=0, bstride=0, gstride=0, nseg=1, tshift=(0, 0
     o.tshift[0], o.tshift[1] = tshift
     o.tvalid = tvalid
     o.segoff[0], o.segoff[1] = segoff
+    o.seg1_limit = seg1_limit
     return o
 
 

@@ -130,6 +130,43 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x, pdf, cdf);
 }
 
+// bf16 mode: a cheaper erf-GELU.  The outputs are rounded to bf16 (relative step 2^-8), so 1.5e-7 of absolute accuracy costs VALU
+// that nothing downstream can see -- and the kernels that evaluate GELU per element (conv0 apply, the K = 128 conv epilogue, the
+// teacher's GELU pass) are VALU-bound on it, not HBM-bound.  Form:  gelu(x) ~= x * sigmoid(w(x)),  w = x (a + b x^2 + c x^4)
+// with (a, b, c) a minimax fit to the exact erf form over |x| <= 9: |error| <= 2.6e-5 absolute (the common tanh form, same
+// structure with c = 0, is off by 4.7e-4), derivative error <= 1.1e-4.  |x| is clamped to 8 inside w only (the quartic term turns
+// over beyond |x| ~ 10; sigmoid(w(8)) is 1 to 1e-12).  9 VALU issues, two of them transcendental, against 16 / 2 for the exact form.
+// The fp32 parity mode keeps the exact form everywhere.
+#define FH_GELU_A 1.59501577f
+#define FH_GELU_B 7.40112923e-02f
+#define FH_GELU_C (-7.03033628e-04f)
+__device__ __forceinline__ float gelu_fast_sig(float x, float& x2c) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  x2c = xc * xc;
+  const float pw = fmaf(fmaf(FH_GELU_C, x2c, FH_GELU_B), x2c, FH_GELU_A);
+  // sigmoid(w) = 1 / (1 + 2^(-w log2 e)); the raw v_exp_f32 / v_rcp_f32 (no denormal fix-up, 1 ulp)
+  const float e = __builtin_amdgcn_exp2f(xc * pw * -1.4426950408889634f);
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  float x2;
+  return x * gelu_fast_sig(x, x2);
+}
+__device__ __forceinline__ float gelu_fast_grad_f(float x) {
+  float x2;
+  const float s = gelu_fast_sig(x, x2);
+  // d/dx [x s(w)] = s + x s (1 - s) w'(x),  w' = a + 3 b x^2 + 5 c x^4   (in the clamped range s (1 - s) is 0 to fp32)
+  const float wp = fmaf(fmaf(5.0f * FH_GELU_C, x2, 3.0f * FH_GELU_B), x2, FH_GELU_A);
+  return fmaf(x * s * (1.0f - s), wp, s);
+}
+// element-type dispatch: exact for the fp32 parity mode, fast for bf16
+template <typename T> __device__ __forceinline__ float gelu_t(float x) {
+  if constexpr (ElemTraits<T>::DT == 0) return gelu_f(x); else return gelu_fast_f(x);
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
+  if constexpr (ElemTraits<T>::DT == 0) return gelu_grad_f(x); else return gelu_fast_grad_f(x);
+}
+
 // ---------------------------------------------------------------- counter-based dropout
 // mask(seed, site, idx) is a pure function, so backward regenerates the forward's mask.
 __device__ __forceinline__ uint32_t fh_mix32(uint32_t x) {

@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
     float v[CV];
     conv4_at<KT>(sw, w, t, a.stride, v);
 #pragma unroll
-    for (int e = 0; e < CV; ++e) v[e] = gelu_f(fmaf(v[e], sc[e], sh[e]));
+    for (int e = 0; e < CV; ++e) v[e] = gelu_t<T>(fmaf(v[e], sc[e], sh[e]));
     st4(yp + (long)t * a.C0, v);
   }
 }
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_onepass_kernel(Conv0Args a, con
 #pragma unroll
       for (int e = 0; e < CV; ++e) {
         const float xh = (v[e] - mu[e]) * rs[e];
-        const float g = d[e] * gelu_grad_f(fmaf(xh, ga[e], be[e]));
+        const float g = d[e] * gelu_grad_t<T>(fmaf(xh, ga[e], be[e]));
         v[e] = g;
         acc[e][KT] += g;
         acc[e][KT + 1] = fmaf(g, xh, acc[e][KT + 1]);

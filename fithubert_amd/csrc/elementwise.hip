@@ -78,7 +78,7 @@ __global__ void mul_gelu_grad_kernel(const T* __restrict__ src, const T* __restr
     unpack16<T>(ld16(src + i * VEC), a);
     unpack16<T>(ld16(aux + i * VEC), z);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) a[e] *= gelu_grad_f(z[e]) * scale;
+    for (int e = 0; e < VEC; ++e) a[e] *= gelu_grad_t<T>(z[e]) * scale;
     st16(dst + i * VEC, pack16<T>(a));
   }
 }
@@ -107,7 +107,7 @@ __global__ void unary_kernel(const T* src, T* dst, long nvec, int mode) {
       unpack16<T>(raw[u], a);
       if (mode == 0) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) a[e] = gelu_f(a[e]);
+        for (int e = 0; e < VEC; ++e) a[e] = gelu_t<T>(a[e]);
       } else {
         float d[VEC];
         unpack16<T>(rawd[u], d);

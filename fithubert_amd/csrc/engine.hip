@@ -1170,9 +1170,9 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.ep.gelu_aux = aux;
       RC(fh_gemm_launch(g, dt, x.st));
       RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, sd * (Ti - 1) + kk, x.st));
-    } else {  // k = 3, s = 2
+    } else if (getenv("FH_DGRAD_SPLIT")) {  // A/B aid: the two-product form (odd frames, then even frames with two segments)
       const int n_even = (2 * Ti <= Tin - 1) ? Ti + 1 : Ti;
-      GemmParams g = fh_gemm_params();  // odd rows: dx[2u+1] = dz[u] . W_1
+      GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
       g.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
       g.Y.segoff[0] = cin;
@@ -1181,7 +1181,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.ldc = 2L * cin; g.c_rpb = Ti; g.c_bstride = (long)Tin * cin;
       g.ep.gelu_aux = aux ? aux + (long)cin * p.es : nullptr;
       RC(fh_gemm_launch(g, dt, x.st));
-      GemmParams e = fh_gemm_params();  // even rows: dx[2u] = dz[u] . W_0 + dz[u-1] . W_2
+      GemmParams e = fh_gemm_params();
       e.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
       e.X.rpb = n_even; e.X.bstride = (long)Ti * cout; e.X.nseg = 2; e.X.tshift[0] = 0; e.X.tshift[1] = -1; e.X.tvalid = Ti;
       e.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
@@ -1192,6 +1192,24 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       e.ep.gelu_aux = aux;
       RC(fh_gemm_launch(e, dt, x.st));
       RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, n_even == Ti + 1 ? 2 * Ti + 1 : 2 * Ti, x.st));
+    } else {  // k = 3, s = 2: dx[2u] = dz[u] . W_0 + dz[u-1] . W_2,  dx[2u+1] = dz[u] . W_1
+      // ONE product: output row u holds the frame pair (2u, 2u+1) -- 2*Cin contiguous columns --, reduction segment 0 is dz[u]
+      // against [W_0 | W_1], segment 1 is dz[u-1] against [W_2 | 0]: the zero half is never multiplied (Y.seg1_limit: the column
+      // tiles of the odd frames run one segment), dz is read once and every output row is written whole.  When the input has an
+      // odd number of frames the last pair's odd frame does not exist (ep.tail_cols).
+      const int n_even = (2 * Ti <= Tin - 1) ? Ti + 1 : Ti;
+      GemmParams e = fh_gemm_params();
+      e.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
+      e.X.rpb = n_even; e.X.bstride = (long)Ti * cout; e.X.nseg = 2; e.X.tshift[0] = 0; e.X.tshift[1] = -1; e.X.tvalid = Ti;
+      e.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
+      e.Y.nseg = 2; e.Y.segoff[0] = 0; e.Y.segoff[1] = 2L * cin; e.Y.seg1_limit = cin;
+      e.C = dst;
+      e.M = B * n_even; e.N = 2 * cin; e.Kseg = cout;
+      e.ldc = 2L * cin; e.c_rpb = n_even; e.c_bstride = (long)Tin * cin;
+      e.ep.gelu_aux = aux;
+      e.ep.tail_cols = 2 * n_even > Tin ? cin : 0;
+      RC(fh_gemm_launch(e, dt, x.st));
+      if (2 * n_even < Tin) RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, 2 * n_even, x.st));
     }
     if (i - 1 == 0) dy0 = dst;
   }

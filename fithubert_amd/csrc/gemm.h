@@ -24,14 +24,14 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream);
 static inline GemmOperand fh_operand(const void* p, int layout, long ld) {
   GemmOperand o;
   o.p = p; o.layout = layout; o.ld = ld; o.rpb = 0; o.bstride = 0; o.gstride = 0; o.nseg = 1;
-  o.tshift[0] = o.tshift[1] = 0; o.tvalid = 0; o.segoff[0] = o.segoff[1] = 0;
+  o.tshift[0] = o.tshift[1] = 0; o.tvalid = 0; o.segoff[0] = o.segoff[1] = 0; o.seg1_limit = 0;
   return o;
 }
 static inline GemmEpilogue fh_epilogue() {
   GemmEpilogue e;
   e.alpha = 1.0f; e.bias = nullptr; e.bias_gstride = 0; e.bias_mod = 0; e.preact = nullptr; e.act = FH_ACT_NONE;
   e.drop.p = 0.f; e.drop.seed = 0; e.drop.site = 0; e.gelu_aux = nullptr; e.residual = nullptr; e.row_len = nullptr;
-  e.out_f32 = 0; e.atomic = 0; e.idiv = 0; e.si1 = 0; e.si0 = 0; e.jdiv = 0; e.sj1 = 0; e.sj0 = 0;
+  e.out_f32 = 0; e.atomic = 0; e.idiv = 0; e.si1 = 0; e.si0 = 0; e.jdiv = 0; e.sj1 = 0; e.sj0 = 0; e.tail_cols = 0;
   return e;
 }
 static inline GemmParams fh_gemm_params() {

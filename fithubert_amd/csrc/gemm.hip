@@ -28,6 +28,14 @@ template <> struct StridedCfg<float> { static constexpr int STRIDE = 528; };  //
 struct RowMap {
   int b, t;
 };
+// segment 1 of an operand with a seg1_limit reads zeros at indices beyond it
+__device__ __forceinline__ bool seg_live(const GemmOperand& o, int seg, int idx) {
+  return seg == 0 || o.seg1_limit <= 0 || idx < o.seg1_limit;
+}
+// reduction segments of the output tile whose first column is j0 (tiles entirely beyond Y's seg1_limit have one)
+__device__ __forceinline__ int tile_nseg(const GemmParams& p, int j0) {
+  return (p.X.nseg == 2 && p.Y.seg1_limit > 0 && j0 >= p.Y.seg1_limit) ? 1 : p.X.nseg;
+}
 __device__ __forceinline__ RowMap map_row(int idx, int rpb) {
   RowMap r;
   if (rpb > 0) {
@@ -66,7 +74,7 @@ template <typename T> struct Loader<T, FH_R_CONTIG> {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int ts = rm.t + o.tshift[s];
-        const bool v = rv && (s < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid));
+        const bool v = rv && (s < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid)) && seg_live(o, s, idx);
         vmask |= (v ? 1u : 0u) << (2 * u + s);
       }
     }
@@ -110,7 +118,7 @@ template <typename T> struct Loader<T, FH_R_STRIDED> {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = k0 + rbase + u * RSTEP;
-      if (colvalid && r < Kseg) {
+      if (colvalid && r < Kseg && seg_live(o, seg, col)) {
         RowMap rm = map_row(r, o.rpb);
         regs[u] = ld16(base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col);
       } else {
@@ -239,6 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
     for (int n = 0; n < 4; ++n) {
       const int j = j0 + yj0 + 16 * n + jq;
       if (j >= p.N) continue;
+      if (ep.tail_cols > 0 && rm.t == p.c_rpb - 1 && j >= ep.tail_cols) continue;
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[n][m][e] * ep.alpha;
@@ -262,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
       if (ep.preact) st4(reinterpret_cast<T*>(ep.preact) + coff, v);
       if (ep.act == FH_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
       }
       if (ep.drop.p > 0.f) {
         const unsigned long long didx = ((unsigned long long)g * p.M + i) * (unsigned long long)p.N + j;
@@ -272,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
         float a[4];
         ld4(reinterpret_cast<const T*>(ep.gelu_aux) + coff, a);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_t<T>(a[e]);
       }
       if (ep.residual) {
         float r[4];
@@ -364,9 +373,10 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     // entry (the conv data gradients write every other frame of a longer sequence: batch stride != rows x ldc)
     long co[4];
     bool dead[4] = {false, false, false, false};
+    bool skip[4] = {false, false, false, false};
     {
       int rb = 0, rt = i_first;
-      if (p.c_rpb > 0 && (wrap0 != 0 || ep.row_len)) {
+      if (p.c_rpb > 0 && (wrap0 != 0 || ep.row_len || ep.tail_cols > 0)) {
         rb = i_first / p.c_rpb;
         rt = i_first - rb * p.c_rpb;
       }
@@ -374,6 +384,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         co[it] = o;
+        if (ep.tail_cols > 0) skip[it] = rt == p.c_rpb - 1 && j >= ep.tail_cols;  // the item's last row is narrower
         if (ep.row_len) dead[it] = rt >= ep.row_len[rb];  // rows past an utterance's valid frames are written as zeros
         o += 8L * p.ldc;
         rt += 8;
@@ -389,15 +400,18 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     Raw8<T> aux[4], res[4];
     if (ep.gelu_aux) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) aux[it].load(reinterpret_cast<const T*>(ep.gelu_aux) + co[it]);
+      for (int it = 0; it < 4; ++it)
+        if (!skip[it]) aux[it].load(reinterpret_cast<const T*>(ep.gelu_aux) + co[it]);
     }
     if (ep.residual) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) res[it].load(reinterpret_cast<const T*>(ep.residual) + co[it]);
+      for (int it = 0; it < 4; ++it)
+        if (!skip[it]) res[it].load(reinterpret_cast<const T*>(ep.residual) + co[it]);
     }
     const unsigned long long d0 = ((unsigned long long)g * p.M + i_first) * (unsigned long long)p.N + j;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
+      if (skip[it]) continue;
       const f32x4 a = *reinterpret_cast<const f32x4*>(lp + it * 8 * EPI_ROW);
       const f32x4 b = *reinterpret_cast<const f32x4*>(lp + it * 8 * EPI_ROW + 16);
       float v[8];
@@ -409,14 +423,14 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
       if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
       if (gelu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
       }
       if (drop) drop_scale_vec<8>(ep.drop, d0 + (unsigned long long)(it * 8) * (unsigned long long)p.N, v);
       if (ep.gelu_aux) {
         float x[8];
         aux[it].get(x);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(x[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_t<T>(x[e]);
       }
       if (ep.residual) {
         float x[8];
@@ -458,6 +472,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     }
     co[it] = coff;
     di[it] = didx;
+    if (ep.tail_cols > 0 && rm.t == p.c_rpb - 1 && j >= ep.tail_cols) live[it] = false;  // (rows are only ever skipped, never reordered)
     if (has_loads && live[it]) {
       if (ep.gelu_aux) aux[it].load(reinterpret_cast<const T*>(ep.gelu_aux) + coff);
       if (ep.residual) res[it].load(reinterpret_cast<const T*>(ep.residual) + coff);
@@ -466,7 +481,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
   }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    if (!live[it]) break;
+    if (!live[it]) continue;
     const int rl = it * 8 + (lane >> 3);
     float v[8];
     {
@@ -481,14 +496,14 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
     if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
     if (ep.act == FH_ACT_GELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
     }
     if (ep.drop.p > 0.f) drop_scale_vec<8>(ep.drop, di[it], v);
     if (ep.gelu_aux) {
       float a[8];
       aux[it].get(a);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(a[e]);
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_t<T>(a[e]);
     }
     if (ep.residual) {
       float rr[8];
@@ -551,7 +566,7 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
                                               int xi0, int yj0, int lane, int g) {
   const GemmEpilogue& ep = p.ep;
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
-  const bool ok = !ep.atomic && !ep.gelu_aux && !ep.residual && !ep.row_len && !ep.out_f32 && (p.c_rpb <= 0 || wrap0 == 0) &&
+  const bool ok = !ep.atomic && !ep.gelu_aux && !ep.residual && !ep.row_len && !ep.out_f32 && !ep.tail_cols && (p.c_rpb <= 0 || wrap0 == 0) &&
                   i0 + xi0 + 16 * NM - 1 < p.M;
   if (!__builtin_amdgcn_readfirstlane(ok)) return false;
   const int r = lane & 15, q = lane >> 4;
@@ -604,7 +619,7 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
       for (int n = 0; n < 4; ++n) {
         if (gelu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[mm][n][e] = gelu_f(v[mm][n][e]);
+          for (int e = 0; e < 4; ++e) v[mm][n][e] = gelu_fast_f(v[mm][n][e]);
         }
         if (drop) {
           const unsigned long long didx = ((unsigned long long)g * p.M + (i0 + xi0 + 16 * (2 * h + mm) + r)) * (unsigned long long)p.N +
@@ -687,7 +702,7 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const GemmParams p) {
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * BM, j0 = tj * BN;
   const int tiles_per_seg = (p.Kseg + BK - 1) / BK;
-  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int ntiles = tiles_per_seg * tile_nseg(p, j0);
   const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
   const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
@@ -775,7 +790,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   const int i0 = ti * BM, j0 = tj * BN;
 
   const int tiles_per_seg = (p.Kseg + BK - 1) / BK;
-  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int ntiles = tiles_per_seg * tile_nseg(p, j0);
   const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
   const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
@@ -900,7 +915,7 @@ template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_CONTIG, ROWS, BK_, N
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg) {
         const int ts = rm.t + o.tshift[sg];
-        const bool v = rv && (sg < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid));
+        const bool v = rv && (sg < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid)) && seg_live(o, sg, idx);
         vmask |= (v ? 1u : 0u) << (2 * ur + sg);
       }
     }
@@ -980,7 +995,7 @@ template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_STRIDED, ROWS, BK_, 
       const int r = k0 + kt[u];
       ptr[u] = (const unsigned char*)g_zero_chunk;
       tcur[u] = -1;  // < 0: this lane stays on the zero chunk
-      if (((cvalid >> u) & 1u) && r < Kseg) {
+      if (((cvalid >> u) & 1u) && r < Kseg && seg_live(o, seg, col[u])) {
         RowMap rm = map_row(r, o.rpb);
         ptr[u] = (const unsigned char*)(base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col[u]);
         tcur[u] = rm.t;
@@ -1042,7 +1057,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * BM_, j0 = tj * BN_;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
-  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int ntiles = tiles_per_seg * tile_nseg(p, j0);
   const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
   const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
@@ -1206,7 +1221,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(const GemmParams p) {
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * BM_, j0 = tj * BN_;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
-  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int ntiles = tiles_per_seg * tile_nseg(p, j0);
   const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
   const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
@@ -1382,7 +1397,7 @@ template <> struct QuarterLoader<FH_R_CONTIG> {  // 256 rows x 64 k, image = 16-
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg) {
         const int ts = rm.t + o.tshift[sg];
-        const bool v = rv && (sg < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid));
+        const bool v = rv && (sg < o.nseg) && (o.tvalid == 0 || (ts >= 0 && ts < o.tvalid)) && seg_live(o, sg, idx);
         vmask |= (v ? 1u : 0u) << (2 * h + sg);
       }
     }
@@ -1465,7 +1480,7 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
         const int r = k0 + kt[h][u];
         ptr[h][u] = (const unsigned char*)g_zero_chunk;
         tcur[h][u] = -1;
-        if (((cvalid >> (2 * h + u)) & 1u) && r < Kseg) {
+        if (((cvalid >> (2 * h + u)) & 1u) && r < Kseg && seg_live(o, seg, col[h][u])) {
           RowMap rm = map_row(r, o.rpb);
           ptr[h][u] = (const unsigned char*)(base + o.segoff[seg] + (long)rm.b * o.bstride + (long)rm.t * o.ld + col[h][u]);
           tcur[h][u] = rm.t;
@@ -1520,7 +1535,7 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * 256, j0 = tj * 256;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
-  const int ntiles = tiles_per_seg * p.X.nseg;
+  const int ntiles = tiles_per_seg * tile_nseg(p, j0);
   const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
   const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
@@ -1751,6 +1766,7 @@ unsigned long long tune_key(const GemmParams& p) {
   mix(qoct(p.M)); mix(qoct(p.N)); mix(qoct(p.Kseg)); mix(p.X.nseg); mix(p.X.layout); mix(p.Y.layout); mix(p.groups);
   mix(p.ep.atomic); mix(p.ep.atomic ? 0 : p.splitk);
   mix(p.ep.preact != nullptr); mix(p.ep.act); mix(p.ep.gelu_aux != nullptr); mix(p.ep.residual != nullptr);
+  if (p.Y.seg1_limit > 0) mix(7919 + p.Y.seg1_limit);
   return h;
 }
 int ring_splitk(const GemmParams& p, int tm, int tn, int target) {
@@ -1916,6 +1932,7 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   if (!p.ep.atomic && (p.ldc % 8 || p.c_bstride % 8 || p.c_gstride % 8)) return -108;
   if (p.ep.row_len && p.c_rpb <= 0) return -109;
   if ((p.X.segoff[0] | p.X.segoff[1] | p.Y.segoff[0] | p.Y.segoff[1] | p.X.gstride | p.Y.gstride) % vec) return -110;
+  if (p.X.seg1_limit % 8 || p.Y.seg1_limit % 8 || p.ep.tail_cols % 8 || (p.ep.tail_cols > 0 && (p.c_rpb <= 0 || p.ep.atomic))) return -111;
   if (!g_prof_on) return dtype == 0 ? launch_t<float>(p, stream) : launch_bf16(p, stream);
   ProfRec r;
   if (!g_pool.empty()) {

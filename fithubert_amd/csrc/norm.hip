@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
         for (int e = 0; e < VEC; ++e) o[e] = fmaf((v[rr][u][e] - mean[rr]) * rstd[rr], gm[u][e], bt[u][e]);
         if (gelu) {  // conv -> LayerNorm -> GELU blocks of a layer_norm-mode feature extractor (HuBERT Large)
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) o[e] = gelu_f(o[e]);
+          for (int e = 0; e < VEC; ++e) o[e] = gelu_t<T>(o[e]);
         }
         if (drop.p > 0.f) drop_scale_vec<VEC>(drop, (unsigned long long)row * C + ch * VEC, o);
         st16(y + (long)row * C + ch * VEC, pack16<T>(o));

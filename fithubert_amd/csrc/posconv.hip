@@ -154,8 +154,8 @@ __device__ __forceinline__ void stage_rows(unsigned char* lds, const T* src, con
       if (GP) {
         float z[2];
         ld2(zc + off, z);
-        f[0] *= gelu_grad_f(z[0]);
-        f[1] *= gelu_grad_f(z[1]);
+        f[0] *= gelu_grad_t<T>(z[0]);
+        f[1] *= gelu_grad_t<T>(z[1]);
         if (row >= own0 && row < own1) st2(dz + off, f);
       }
     }
@@ -236,8 +236,8 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
           st2(out1 + off, v);
           float xv[2];
           ld2(reinterpret_cast<const T*>(lds + (tl + pad_left) * PC<T, CP>::RS) + co, xv);
-          v[0] = xv[0] + gelu_f(v[0]);
-          v[1] = xv[1] + gelu_f(v[1]);
+          v[0] = xv[0] + gelu_t<T>(v[0]);
+          v[1] = xv[1] + gelu_t<T>(v[1]);
           st2(out2 + off, v);
         } else {
           float dv[2];

@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
         float v[2] = {acc[cb][tt][2 * h] + bias[g * cg + co], acc[cb][tt][2 * h + 1] + bias[g * cg + co + 1]};
         float xv[2];
         ld2w(reinterpret_cast<const T*>(lds + (tl + pad_left) * RS) + co, xv);
-        v[0] = xv[0] + gelu_f(v[0]);
-        v[1] = xv[1] + gelu_f(v[1]);
+        v[0] = xv[0] + gelu_t<T>(v[0]);
+        v[1] = xv[1] + gelu_t<T>(v[1]);
         st2w(y + off, v);
       }
     }

@@ -346,19 +346,18 @@ class W2V2Distil:
             feat_total = out[-1] if self._rows_loss else float(self.rec_loss_weight) * out[-1]
             out = torch.cat([out[:-1], (feat_total + float(self.cnn_loss_weight) * cout[0]).reshape(1)])  # [-1] = train.py:372-378
         d_qkv = None
-        if self._attn_transfer:   # train.py:327-370 on the last layers' q|k|v projections (fithubert_amd/attn_transfer.py)
-            from .attn_transfer import transfer
+        if self._attn_transfer:   # train.py:327-370 on the last layers' q|k|v projections: one fused HIP kernel per term
+            from .attn_transfer import relation_losses
             D3 = 3 * self.engine.c.embed_dim
             s_qkv = ws.view("qkv")[-1].view(x.shape[0], -1, D3)
             key_len = ws.lens[1] if ws.lens is not None else None
-            t_key_len = getattr(hid, "_fh_key_len", None)
-            with torch.enable_grad():
-                tot, parts, d_qkv = transfer(s_qkv, hid._fh_qkv, self.engine.c.heads, self.teacher_model.model.cfg.encoder_attention_heads,
-                                             key_len, float(self.attn_loss_weight), self.attn_loss_type, float(self.v_rel_loss_weight))
+            tot, parts, d_qkv = relation_losses(s_qkv, hid._fh_qkv, self.engine.c.heads, self.teacher_model.model.cfg.encoder_attention_heads,
+                                                key_len, getattr(hid, "_fh_key_len", None), float(self.attn_loss_weight),
+                                                self.attn_loss_type, float(self.v_rel_loss_weight))
             d_qkv = d_qkv.view(-1, D3)
             self.last_transfer_losses = parts
             feat_total = out[-1] if (self._rows_loss or self.cnn_loss_weight > 0) else float(self.rec_loss_weight) * out[-1]
-            out = torch.cat([out[:-1], (feat_total + tot.double()).reshape(1)])
+            out = torch.cat([out[:-1], (feat_total + tot).reshape(1)])
         last_micro = self._micro + 1 >= self.accumulate
         if last_micro and self.sync.active:
             # the gradient exchange starts INSIDE the backward: the heads' bucket goes on the wire when the head branch is queued,
@@ -498,6 +497,11 @@ class W2V2Distil:
         sd = {k[len("student_model."):]: v for k, v in ck["state_dict"].items() if k.startswith("student_model.")}
         self.student_model.load_state_dict(sd, strict=strict)
         self.student_model.mark_params_updated()
+        tsd = {k[len("teacher_model.model."):]: v for k, v in ck["state_dict"].items() if k.startswith("teacher_model.model.")}
+        own = self.teacher_model.model.state_dict()
+        if tsd and set(tsd) == set(own) and all(tuple(tsd[k].shape) == tuple(own[k].shape) for k in own):
+            self.teacher_model.model.load_state_dict({k: v.to(own[k].dtype) for k, v in tsd.items()})   # Lightning restores the frozen teacher too
+            self.teacher_model.model._native = None    # prepared native copies of the old weights
         opt = ck.get("optimizer_states")
         if opt:
             self.opt_m.copy_(opt[0]["exp_avg"].to(self.opt_m.device))

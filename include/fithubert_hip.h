@@ -45,6 +45,9 @@ typedef struct {
   int tshift[2];  /* R_CONTIG: per-segment shift of the mapped row; rows outside [0, tvalid) read as 0 */
   int tvalid;     /* 0 = no check */
   long segoff[2]; /* per-segment element offset */
+  int seg1_limit; /* > 0: operand indices >= seg1_limit read as 0 in segment 1, and output tiles that lie entirely beyond it skip
+                     the segment (Y operand: the k = 3, s = 2 conv data gradient as ONE product whose odd output rows have a
+                     single tap); multiple of 8; 0 = no limit */
 } fh_gemm_operand;
 
 typedef struct {
@@ -62,6 +65,8 @@ typedef struct {
   int atomic;           /* C (fp32) [map(i,j)] += alpha*acc : weight-gradient accumulation / split-K */
   int idiv; long si1, si0; /* map(i,j) = (i/idiv)*si1 + (i%idiv)*si0 + (j/jdiv)*sj1 + (j%jdiv)*sj0 */
   int jdiv; long sj1, sj0; /* (idiv == 0: i*ldc ; jdiv == 0: j) */
+  int tail_cols;           /* > 0: the LAST mapped row of every batch item (t == c_rpb - 1) is written in columns < tail_cols only
+                              (an output row that packs two frames when the item has an odd number of them); multiple of 8 */
 } fh_gemm_epilogue;
 
 typedef struct {
@@ -290,6 +295,29 @@ typedef struct {
 int fh_student_backward_notify(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
                                void* ws, float* grads, const float* wave, const int* lens, const fh_student_grads* g,
                                const fh_grad_notify* n, fh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention-logit and value-relation transfer, loss fused with its gradient.  Replaces the relation tensors of the reference's
+ * patched last layer (utils/utils.py:244-278: attn = (q d^-1/2) k^T with padded keys at -inf, v_rel = (v d^-1/2) v^T, both
+ * (B H) x T x T) and their losses (train.py:327-352 attention mse with inf / nan scrubbing or kl-div; train.py:358-367 value-
+ * relation kl-div) -- without materialising anything of size T x T.
+ *   s_qkv [B][T][3*Ds] (dtype), t_qkv [B][T][3*Dt] (teacher_dtype): the packed q|k|v projections of the two last layers
+ *   which : 0 = attention logits (q, k; key masks apply), 1 = value relation (v, v; unmasked, kl-div only)
+ *   mode  : 0 = mse over the entries that are finite in the reference, 1 = kl_div(log_softmax(student), softmax(teacher)) summed
+ *           over keys, mean over rows.  (Padded batch + kl-div: the reference's arithmetic gives nan; masked keys contribute 0 here.)
+ *   s_len / t_len : int32 [B] valid keys of student / teacher (a key is masked when either masks it), or NULL
+ *   d_qkv : fp32 [B][T][3*Ds], ACCUMULATES weight * dLoss/d s_qkv (zero it first; several calls may add into it), or NULL
+ *   partials : fp32 scratch, fh_relation_kd_nblk(B, T, H) floats;  loss_out : double[1] <- the (unweighted) loss
+ * ------------------------------------------------------------------------------------------ */
+/* The relation tensor itself, for the module API (the reference's patched layer RETURNS attn / v_rel, utils/utils.py:263-265,278):
+ * out != NULL: out[(b h)][q][k] = (A_q . B_k) d^-1/2 fp32, masked keys (k >= key_len[b], which = 0 only) = -inf;
+ * grad_out != NULL: its backward, d_qkv (fp32 [B][T][3*D]) += d out / d qkv contracted with grad_out.  Exactly one of the two. */
+int fh_relation_tensor(int dtype, const void* qkv, float* out, const float* grad_out, float* d_qkv, const int* key_len, int B,
+                       int T, int H, int D, int which, fh_stream_t stream);
+int fh_relation_kd_nblk(int B, int T, int H);
+int fh_relation_kd(int dtype, int teacher_dtype, const void* s_qkv, const void* t_qkv, float* d_qkv, float* partials,
+                   double* loss_out, const int* s_len, const int* t_len, int B, int T, int H, int Ds, int Dt, int which,
+                   int mode, float weight, fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frozen-teacher conv frontend on the student's kernels.  The teacher (fairseq HubertModel /

@@ -259,6 +259,65 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "student_full_2s.npz"), **fx)
     report.append(("full2s/loss", abs(lr_v.item() - lo_v.item())))
 
+    # ------------------------------------------------------------------ 2b. full fithubert.yaml at BASELINE.json's utterance size (10 s)
+    # and at LibriSpeech train-clean-100's longest / median lengths (392,400 / 223,920 samples, right-padded pair): sub-sampled
+    # activations, the reference's loss on a seeded stand-in teacher, and the gradient norm of every parameter from the
+    # reference's own autograd (eval mode => dropout off).
+    def full_size_fixture(name, S_, lens, seed, rms):
+        g = torch.Generator().manual_seed(seed)
+        w = rms * torch.randn(2, S_, generator=g)
+        pm_ = torch.arange(S_)[None, :] >= torch.tensor(lens)[:, None]
+        w[pm_] = 0
+        padded = bool(pm_.any())
+        reff.zero_grad()
+        rf_ = reff(w.clone(), padding_mask=pm_.clone())
+        sd_g = {k: v.clone().requires_grad_(True) for k, v in sdf.items()}
+        of_ = S.student_forward(sd_g, full, w.clone(), pm_.clone() if padded else None)
+        worst = _compare_outputs(name, rf_, of_)
+        Tp_ = rf_["features"].shape[1]
+        tg = torch.Generator().manual_seed(seed + 100)
+        t_layers = [(torch.randn(Tp_, 2, 768, generator=tg), (None, None)) for _ in range(12)]
+        teacher_results = {"layer_results": t_layers, "x": t_layers[-1][0].transpose(0, 1), "features": [None]}
+        rl = [3, 8, 0, 10, 5, 1, 7, 2, 9, 6, 4]
+        ns = SimpleNamespace(
+            cnn_loss_weight=0, rec_loss_weight=1.0, rec_loss_type="mse", sim_loss_weight=0, attn_loss_weight=0,
+            attn_loss_type="kldiv", v_rel_loss_weight=0, random_layer_weight=0.1, train_cfg=dict(fit["train"]),
+            rand_l=rl, num_encoders=12, task_agnostic=True, model_cfg=full, student_model=reff)
+        lv, ld = ref_train.W2V2Distil.calculate_loss(ns, rf_, teacher_results)
+        lv.backward()
+        lo, _ = L.calculate_loss(of_, teacher_results, fit["train"], rand_l=rl, num_encoders=12)
+        lo.backward()
+        assert abs(lv.item() - lo.item()) < 1e-6 * abs(lv.item()), (lv.item(), lo.item())
+        fx_ = dict(cfg_yaml=np.array(yaml.dump(full)), weight_seed=np.array(12), wav_seed=np.array(seed), wav_rms=np.array(rms),
+                   samples=np.array(S_), lengths=np.array(lens), teacher_seed=np.array(seed + 100), teacher_T=np.array(Tp_),
+                   rand_l=np.array(rl), loss=np.array(lv.item(), dtype=np.float64),
+                   layer_losses=np.array([ld[f"rand_l{i}"].item() for i in range(11)] + [ld["l11"].item()]),
+                   wav_head=_to_np(w[:, :64]), features_sub=_to_np(rf_["features"][:, ::7, ::8]),
+                   tr_sub=_to_np(rf_["tr_layer_results"][0][::7, :, ::8]))
+        if rf_["padding_mask"] is not None:
+            fx_["valid_frames"] = np.array((~rf_["padding_mask"]).sum(-1).tolist())
+        for i in range(12):
+            fx_[f"layer{i}_sub"] = _to_np(rf_["layer_results"][i][0][::7, :, ::8])
+            fx_[f"proj{i}_sub"] = _to_np(rf_["projections"][i][:, ::11, ::16])
+            fx_[f"proj{i}_l2"] = np.array(rf_["projections"][i].double().norm().item())
+        gw = 0.0
+        for k, p_ in reff.named_parameters():
+            if p_.grad is None:
+                continue
+            go = sd_g[k].grad
+            e = (go - p_.grad).abs().max().item() / max(1e-3, p_.grad.abs().max().item())
+            gw = max(gw, e)
+            assert e < 5e-4, (name, k, e)
+            fx_["gradnorm/" + k] = np.array(p_.grad.double().norm().item(), dtype=np.float64)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx_)
+        report.append((name + "/forward", worst))
+        report.append((name + "/loss", abs(lv.item() - lo.item())))
+        report.append((name + "/grads(rel)", gw))
+
+    full_size_fixture("student_full_10s", 160000, [160000, 160000], 21, 0.1)
+    full_size_fixture("student_full_libri_max", 392400, [392400, 223920], 22, 0.1)
+    reff.zero_grad()
+
     # ------------------------------------------------------------------ 3. heads disabled (UpstreamExpert path)
     reff._disable_projection_heads()
     sd_dis = {k: v for k, v in reff.state_dict().items()}

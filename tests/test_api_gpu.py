@@ -339,6 +339,23 @@ def test_attention_and_value_relation_transfer(attn_type):
     task.configure_optimizers(num_training_steps=10)
     out = task.training_step(b, batch_idx=0)
     assert abs(out[-1].item() - lo.item()) < 2e-3 * abs(lo.item()), (out[-1].item(), lo.item())
+    # the hot path's transfer terms come from the fused HIP relation kernel (no T x T tensor, no torch.bmm): same per-term
+    # losses, and the gradients the optimizer consumed equal the oracle's autograd
+    for k in ("attn_loss", "v_rel_loss"):
+        assert abs(task.last_transfer_losses[k].item() - ld[k].item()) < 3e-4 * abs(ld[k].item()), k
+    hot = task.engine.param_views(task.engine.grads)
+    bad = []
+    for k, gv in hot.items():
+        rg = sd[k].grad
+        if rg is None or rg.norm().item() < 1e-7:
+            continue
+        e = _rel_l2(gv.float(), rg)
+        if e > 4e-3:
+            bad.append((k, e))
+    assert not bad, bad
+    import inspect
+    from fithubert_amd import attn_transfer, distill
+    assert "bmm" not in inspect.getsource(attn_transfer) and "bmm" not in inspect.getsource(distill)
 
 
 def test_fit_loop_validation_checkpoints_and_early_stopping(tmp_path):
@@ -386,8 +403,11 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
     tc.encoder_layers = 3
     batches = [fixed_length_batch(3, 24000, seed=i, device=DEV) for i in range(5)]
 
+    from fithubert_amd.teacher import build_teacher
+    teacher = build_teacher(tc, seed=1, dtype=torch.bfloat16, device=DEV)   # the frozen teacher comes from its own checkpoint file
+
     def make(seed=0):
-        t = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=tc, seed=seed)
+        t = W2V2Distil(y, dtype="bf16", device=DEV, teacher=teacher, seed=seed)
         t.configure_optimizers(num_training_steps=20)
         return t
 

@@ -57,16 +57,17 @@ def fresh():
 a, b = fresh(), fresh()
 orig = b.engine.backward
 def late(ws, **kw):
-    kw.pop("on_segment"); kw.pop("comm_stream")
+    seg = kw.pop("on_segment", None); kw.pop("comm_stream", None)
     orig(ws, **kw)
-    b.sync.launch()
+    if seg is not None:
+        b.sync.launch()
 b.engine.backward = late
-for i in range(2):
-    a.training_step(pool[i %% 2], batch_idx=i)
-    b.training_step(pool[i %% 2], batch_idx=i)
+a.training_step(pool[0], batch_idx=0)
+b.training_step(pool[0], batch_idx=0)
 torch.cuda.synchronize()
-d = (a.engine.params - b.engine.params).abs().max().item()
-assert d < 1e-5, d
+ga, gb = a.engine.grads.double(), b.engine.grads.double()   # the reduced gradients the optimizer consumed
+d = ((ga - gb).norm() / ga.norm()).item()
+assert ga.norm().item() > 0 and d < 1e-4, d
 dist.destroy_process_group()
 print("DP_OK", vals)
 ''' % (ROOT, ROOT)
@@ -75,4 +76,6 @@ print("DP_OK", vals)
 def test_training_step_over_a_one_rank_rccl_group():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=280, env=env)
-    assert r.returncode == 0 and "DP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    if r.returncode != 0 or "DP_OK" not in r.stdout:
+        tb = r.stderr[r.stderr.rfind("Traceback"):] if "Traceback" in r.stderr else r.stderr[-3000:]
+        raise AssertionError("1-rank RCCL training step failed:\n" + r.stdout[-1500:] + "\n" + tb[-4000:])

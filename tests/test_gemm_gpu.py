@@ -286,3 +286,50 @@ def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
         keep = keep & valid
     err = ((got.double() - ref) * keep).abs().max().item()
     assert err <= 2e-2 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("dt,path", [(L.DT_F32, 9), (L.DT_BF16, 0), (L.DT_BF16, 2), (L.DT_BF16, 3), (L.DT_BF16, 4), (L.DT_BF16, 5),
+                                     (L.DT_BF16, 6), (L.DT_BF16, 7)])
+@pytest.mark.parametrize("cin,cout,T", [(256, 256, 399), (256, 256, 400), (512, 512, 263), (64, 128, 38)])
+def test_conv1d_k3s2_dgrad_as_one_gemm(dt, path, cin, cout, T):
+    """The k = 3, s = 2 conv data gradient as ONE product (engine.hip): output row u = frame pair (2u, 2u+1), segment 0 =
+    dy[u] against [W_0 | W_1], segment 1 = dy[u-1] against [W_2 | 0] (Y.seg1_limit: never multiplied), times gelu'(aux); with
+    an odd number of input frames the last pair's odd frame does not exist (ep.tail_cols) -- the buffer is NaN-poisoned around
+    it, the neighbouring batch item's first row must survive.  Every bf16 main loop."""
+    dev = "cuda"
+    torch.manual_seed(cin + T)
+    B, k, s = 3, 3, 2
+    Tout = (T - k) // s + 1
+    w = (torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5).to(_tdt(dt))
+    wf = w.permute(0, 2, 1).contiguous().view(cout, k * cin)
+    dy = torch.randn(B, Tout, cout, device=dev).to(_tdt(dt))
+    aux = torch.randn(B, T, cin, device=dev).to(_tdt(dt))
+    xr = torch.zeros(B, cin, T, device=dev, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv1d(xr, w.double(), stride=s).backward(dy.double().permute(0, 2, 1))
+    a = aux.double()
+    gp = 0.5 * (1 + torch.erf(a / 2 ** 0.5)) + a * torch.exp(-a * a / 2) / (2 * torch.pi) ** 0.5
+    ref = xr.grad.permute(0, 2, 1) * gp
+    n_even = Tout + 1 if 2 * Tout <= T - 1 else Tout
+    guard = 64
+    buf = torch.full((B * T * cin + guard,), float("nan"), device=dev, dtype=_tdt(dt))
+    dx = buf[: B * T * cin].view(B, T, cin)
+    d = L.GemmDesc()
+    d.X = L.operand(dy.data_ptr(), 0, cout, rpb=n_even, bstride=Tout * cout, nseg=2, tshift=(0, -1), tvalid=Tout)
+    d.Y = L.operand(wf.data_ptr(), 1, k * cin, nseg=2, segoff=(0, 2 * cin), seg1_limit=cin)
+    d.C = dx.data_ptr()
+    d.M, d.N, d.Kseg, d.groups, d.splitk = B * n_even, 2 * cin, cout, 1, 1
+    d.ldc, d.c_rpb, d.c_bstride = 2 * cin, n_even, T * cin
+    d.ep = L.epilogue(gelu_aux=aux.data_ptr(), tail_cols=cin if 2 * n_even > T else 0)
+    lib = L.lib()
+    try:
+        lib.fh_gemm_set_path(path)
+        _run(d, dt)
+    finally:
+        lib.fh_gemm_set_path(9)
+    assert torch.isnan(buf[B * T * cin:].float()).all()            # nothing past the buffer
+    covered = min(2 * n_even, T)
+    assert not torch.isnan(dx[:, :covered].float()).any()
+    assert torch.isnan(dx[:, covered:].float()).all()               # rows past the last pair are left to the caller
+    rtol, atol = _tol(dt, 2 * cout)
+    tol = (atol + rtol) * ref.abs().max().item() * (1.0 if dt == L.DT_F32 else 1.5)   # bf16: the fast gelu' adds <= 1.1e-4
+    assert (dx[:, :covered].double() - ref[:, :covered]).abs().max().item() <= tol

@@ -238,7 +238,10 @@ def _attn_ref(qkv, H, dh, key_len):
 
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
 @pytest.mark.parametrize("dh", [40, 64])
-@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (2, 249, True), (1, 130, False), (3, 70, True), (2, 300, True), (1, 499, False)])
+@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (2, 249, True), (1, 130, False), (3, 70, True), (2, 300, True), (1, 499, False),
+                                        # LibriSpeech train-clean-100 lengths (max 392,400 samples): T2 = 613 for the student, T' = 1226 for
+                                        # the teacher -- past the resident-K/V limit (512 bf16 / 320 fp32), i.e. the tiled kernels
+                                        (2, 613, True), (2, 880, True), (2, 1226, True), (1, 1225, False)])
 def test_attention_fwd_bwd(dt, B, T, masked, dh):
     torch.manual_seed(B * 7 + T)
     H = 12
@@ -269,7 +272,7 @@ def test_attention_fwd_bwd(dt, B, T, masked, dh):
         assert _rel(dqkv[..., sl], qr.grad[..., sl]) < tol, name
 
 
-@pytest.mark.parametrize("B,T,masked", [(2, 499, True), (1, 96, False), (2, 200, True)])
+@pytest.mark.parametrize("B,T,masked", [(2, 499, True), (1, 96, False), (2, 200, True), (2, 699, True), (2, 1226, True)])
 def test_attention_forward_64_wide_heads(B, T, masked):
     """bf16 forward-only build for the frozen teacher's 64-wide heads (HuBERT Base / Large)."""
     torch.manual_seed(T)
@@ -324,7 +327,7 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(dt):
 
 
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
-@pytest.mark.parametrize("T,masked", [(200, False), (249, True), (300, False)])  # <= 256 bf16: the fused backward; 300: the two-pass one
+@pytest.mark.parametrize("T,masked", [(200, False), (249, True), (300, False), (613, True)])  # <= 256 bf16: the fused backward; 300: the two-pass one; 613: tiled
 def test_attention_dropout_backward_matches_autograd_with_the_forward_mask(dt, T, masked):
     """Reads the forward's complete dropout mask of one head through one-hot V probes, then checks dq / dk / dv of that head
     against autograd with that mask held fixed (the backward kernels regenerate the mask from (seed, site, index))."""
@@ -466,3 +469,93 @@ def test_cast_permute_adamw():
         L.check(lib.fh_adamw(_p(p), _p(g * step), _p(m), _p(v), n, 5e-4, 0.9, 0.98, 1e-6, 1e-2, 1 - 0.9 ** step,
                              1 - 0.98 ** step, 1.0, None, _st()), "adamw")
     assert _rel(p, pr.detach()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ attention / value-relation transfer
+def _relation_ref(qkv, H, which, key_len):
+    """(B H) x T x T relation tensor as the reference's patched layer returns it (utils/utils.py:245-265), fp64."""
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // H
+    q, k, v = qkv.double().split(D, dim=-1)
+    sh = lambda t: t.reshape(B, T, H, dh).permute(0, 2, 1, 3).reshape(B * H, T, dh)
+    if which == 0:
+        s = torch.bmm(sh(q) * dh ** -0.5, sh(k).transpose(1, 2))
+        if key_len is not None:
+            pad = torch.arange(T, device=qkv.device)[None, :] >= key_len.long()[:, None]
+            s = s.view(B, H, T, T).masked_fill(pad[:, None, None, :], float("-inf")).view(B * H, T, T)
+        return s
+    return torch.bmm(sh(v) * dh ** -0.5, sh(v).transpose(1, 2))
+
+
+def _relation_loss_ref(s, t, mode):
+    """train.py:327-367 on materialised tensors.  kl-div: masked keys (-inf in both) carry zero probability and contribute
+    nothing (the reference's own arithmetic is nan there; see relation.hip)."""
+    if mode == 0:
+        l = (s - t) ** 2
+        inf_c = torch.any(l.isinf(), 1).count_nonzero() * l.size(-1)
+        nan_c = torch.any(l.isnan(), 1).count_nonzero() * l.size(-1)
+        l = torch.where(l.isinf() | l.isnan(), torch.zeros_like(l), l)
+        return l.sum() / (l.numel() - inf_c - nan_c)
+    ls, lt = torch.log_softmax(s, -1), torch.log_softmax(t, -1)
+    term = torch.where(torch.isinf(lt), torch.zeros_like(lt), lt.exp() * (lt - torch.where(torch.isinf(ls), torch.zeros_like(ls), ls)))
+    return term.sum(-1).mean()
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("which,mode", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (3, 130, True), (2, 200, True)])
+def test_relation_transfer_loss_and_gradient(dt, which, mode, B, T, masked):
+    """fh_relation_kd: attention-logit mse / kl-div and value-relation kl-div against the materialised fp64 form and its
+    autograd gradient; student 40-wide heads, teacher 64-wide heads (fithubert.yaml vs HuBERT Base), the teacher masking one
+    more key than the student on one utterance (the two padding rules differ)."""
+    torch.manual_seed(T + which * 3 + mode)
+    H, dhs, dht = 12, 40, 64
+    lib = L.lib()
+    sq = (torch.randn(B, T, 3 * H * dhs, device=DEV) * 0.8).to(_tdt(dt))
+    tq = (torch.randn(B, T, 3 * H * dht, device=DEV) * 0.8).to(torch.bfloat16)
+    s_len = t_len = None
+    if masked:
+        s_len = torch.tensor([T, T * 3 // 4, T // 2][:B], device=DEV, dtype=torch.int32)
+        t_len = s_len.clone()
+        t_len[1] -= 1
+    d = torch.zeros(B, T, 3 * H * dhs, device=DEV)
+    partials = torch.empty(lib.fh_relation_kd_nblk(B, T, H), device=DEV)
+    out = torch.empty(1, device=DEV, dtype=torch.float64)
+    w = 0.7
+    L.check(lib.fh_relation_kd(dt, L.DT_BF16, _p(sq), _p(tq), _p(d), _p(partials), _p(out), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
+                               which, mode, w, _st()), "fh_relation_kd")
+    leaf = sq.double().requires_grad_(True)
+    both = None if s_len is None else torch.minimum(s_len, t_len)
+    ref = _relation_loss_ref(_relation_ref(leaf, H, which, both), _relation_ref(tq, H, which, both), mode)
+    (g,) = torch.autograd.grad(w * ref, leaf)
+    assert abs(out.item() - ref.item()) < (2e-5 if dt == L.DT_F32 else 1e-4) * max(1.0, abs(ref.item())), (out.item(), ref.item())
+    assert _rel(d, g) < 2e-4
+    # a second call ACCUMULATES into d_qkv
+    L.check(lib.fh_relation_kd(dt, L.DT_BF16, _p(sq), _p(tq), _p(d), _p(partials), _p(out), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
+                               which, mode, w, _st()), "fh_relation_kd")
+    assert _rel(d, 2 * g) < 2e-4
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("which", [0, 1])
+def test_relation_tensor_and_its_backward(dt, which):
+    """fh_relation_tensor (module API: the reference's layer RETURNS attn / v_rel): values incl. -inf key padding, and the
+    backward against autograd."""
+    torch.manual_seed(which)
+    B, T, H, dh = 2, 77, 12, 64
+    lib = L.lib()
+    qkv = torch.randn(B, T, 3 * H * dh, device=DEV).to(_tdt(dt))
+    kl = torch.tensor([T, 50], device=DEV, dtype=torch.int32)
+    out = torch.full((B * H, T, T), float("nan"), device=DEV)
+    L.check(lib.fh_relation_tensor(dt, _p(qkv), _p(out), None, None, _p(kl), B, T, H, H * dh, which, _st()), "fh_relation_tensor")
+    leaf = qkv.double().requires_grad_(True)
+    ref = _relation_ref(leaf, H, which, kl if which == 0 else None)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isinf(out), ~fin) and not torch.isnan(out).any()
+    assert _rel(torch.where(fin, out.double(), torch.zeros_like(ref)), torch.where(fin, ref, torch.zeros_like(ref))) < 1e-5
+    g = torch.randn(B * H, T, T, device=DEV)
+    (gr,) = torch.autograd.grad((torch.where(fin, ref, torch.zeros_like(ref)) * g.double()).sum(), leaf)
+    d = torch.zeros(B, T, 3 * H * dh, device=DEV)
+    L.check(lib.fh_relation_tensor(dt, _p(qkv), None, _p(g), _p(d), _p(kl), B, T, H, H * dh, which, _st()), "fh_relation_tensor bwd")
+    assert _rel(d, gr) < 1e-5

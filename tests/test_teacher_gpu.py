@@ -51,3 +51,29 @@ def test_native_transformer_layers_match_torch_path(dtype, tol):
         for (xr, (_, fr)), (xg, (_, fg)) in zip(ref["layer_results"], got["layer_results"]):
             assert ((xg.float() - xr.float()).norm() / xr.float().norm()).item() < tol
             assert ((fg.float() - fr.float()).norm() / fr.float().norm()).item() < tol
+
+
+def test_native_teacher_at_the_longest_librispeech_utterance():
+    """train-clean-100's longest utterance (392,400 samples -> T' = 1226 frames) beside its median (223,920), right-padded: the
+    bf16 teacher's native path (conv GEMMs, 64-wide-head attention past the resident-K/V limit, add+LayerNorm) against the stock
+    PyTorch path on the same weights, with the frame mask derived from HOST lengths on one side and from the device mask on the
+    other."""
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 3
+    w = build_teacher(tc, seed=7, dtype=torch.bfloat16, device=DEV)
+    S, lens = 392400, [392400, 223920]
+    g = torch.Generator().manual_seed(2)
+    wav = (0.1 * torch.randn(2, S, generator=g)).to(DEV)
+    pm = torch.arange(S, device=DEV)[None, :] >= torch.tensor(lens, device=DEV)[:, None]
+    wav[pm] = 0
+    w.model.enable_native_frontend(False)
+    ref = w.hidden_stack(wav, pm).float()
+    w.model.enable_native_frontend(True)
+    got = w.hidden_stack(wav, pm, lengths=lens).float()
+    Tt = ref.shape[2]
+    assert ref.shape == (3, 2, 1226, 768)
+    valid = [Tt, w.model.frame_lengths(lens, S, Tt)[1]]
+    for b in range(2):
+        a, r = got[:, b, :valid[b]], ref[:, b, :valid[b]]
+        err = ((a - r).norm() / r.norm()).item()
+        assert err < 4e-2, (b, err)
