@@ -349,8 +349,13 @@ def main():
                 pmc = json.load(f)
             ent = pmc.get("variants", {}).get(roof["kernel"])
             if ent and pmc.get("batch") == B:
-                roof["traffic"] = ent["bytes_per_launch"]
+                roof["traffic"] = ent.get("bytes_per_launch")
                 roof["traffic_note"] = pmc.get("note")
+                # MFMA-busy of the same kernel (SQ_VALU_MFMA_BUSY_CYCLES over the chip's matrix-pipe cycles) and the launch's
+                # algorithmic bytes beside the measured ones, from the same committed rocprofv3 summary
+                roof["mfma_busy"] = ent.get("mfma_busy")
+                roof["mfma_busy_over_sq_busy"] = ent.get("mfma_busy_over_sq_busy")
+                roof["algorithmic_bytes"] = ent.get("algorithmic_bytes_per_launch")
         except Exception:
             pass
 
