@@ -10,6 +10,8 @@
 // chunk-local (mean, M2) with a pivot (no catastrophic cancellation), a tiny kernel merges chunks with
 // Chan's formula in fp64, pass 2 recomputes the conv (10 FMA/elem) and writes GELU(GN(.)) once.
 // Backward is ONE pass over dy (by linearity, below) + a tiny combine; the waveform needs no grad.
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -112,12 +114,12 @@ constexpr int CV = 4;
 
 struct ChanMap {
   int ngrp, nlan, cg, tl, c0;
-  __device__ __forceinline__ ChanMap(int C0) {
-    ngrp = C0 / CV;           // <= 256 and divides 256 (checked on the host)
+  __device__ __forceinline__ ChanMap(int C0, int cv = CV) {
+    ngrp = C0 / cv;           // <= 256 and divides 256 (checked on the host)
     nlan = 256 / ngrp;
     cg = threadIdx.x % ngrp;
     tl = threadIdx.x / ngrp;
-    c0 = cg * CV;
+    c0 = cg * cv;
   }
 };
 
@@ -145,18 +147,22 @@ __device__ __forceinline__ void conv4_at(const float* sw, const float (&w)[CV][K
 }
 
 // ---------------------------------------------------------------- forward pass 2: conv + GN + GELU -> y
-template <typename T, int KT>
+// CW channels per thread: 4, or 8 (bf16 16-byte stores, half the LDS broadcasts per output; an experiment, see the launcher).
+template <typename T, int KT, int CW>
 __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const float* mean, const float* rstd, T* y) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw = smem;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int nt = stage_wave(a, b, chunk, sw);
-  const ChanMap m(a.C0);
-  float w[CV][KT];
-  load_w4<KT>(a, m.c0, w);
-  float sc[CV], sh[CV];
+  const ChanMap m(a.C0, CW);
+  float w[CW][KT];
 #pragma unroll
-  for (int e = 0; e < CV; ++e) {
+  for (int e = 0; e < CW; ++e)
+#pragma unroll
+    for (int j = 0; j < KT; ++j) w[e][j] = j < a.K ? a.w[(m.c0 + e) * a.K + j] : 0.f;
+  float sc[CW], sh[CW];
+#pragma unroll
+  for (int e = 0; e < CW; ++e) {
     const int c = m.c0 + e;
     const float rs = rstd[b * a.C0 + c];
     sc[e] = rs * a.gamma[c];
@@ -165,11 +171,20 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
   T* yp = y + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + m.c0;
 #pragma unroll 2
   for (int t = m.tl; t < nt; t += m.nlan) {
-    float v[CV];
-    conv4_at<KT>(sw, w, t, a.stride, v);
+    const float* x = sw + t * a.stride;
+    float xs[KT], v[CW];
 #pragma unroll
-    for (int e = 0; e < CV; ++e) v[e] = gelu_t<T>(fmaf(v[e], sc[e], sh[e]));
-    st4(yp + (long)t * a.C0, v);
+    for (int j = 0; j < KT; ++j) xs[j] = x[j];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int e = 0; e < CW; ++e) v[e] = fmaf(w[e][j], xs[j], v[e]);
+#pragma unroll
+    for (int e = 0; e < CW; ++e) v[e] = gelu_t<T>(fmaf(v[e], sc[e], sh[e]));
+    if constexpr (CW == 8) st16(yp + (long)t * a.C0, pack16<T>(v));
+    else st4(yp + (long)t * a.C0, v);
   }
 }
 
@@ -317,10 +332,15 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
   hipLaunchKernelGGL(conv0_stats_final_kernel, dim3(B), dim3(256), 0, st, (const float*)part, w, mean, rstd, B, a.nchunk, C0, K,
                      a.T0, eps);
   FH_CHECK_LAUNCH();
-#define FH_C0_APPLY(T, KT) \
-  hipLaunchKernelGGL((conv0_apply_kernel<T, KT>), grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (T*)y)
-  if (dtype == 0) { if (K == 10) FH_C0_APPLY(float, 10); else FH_C0_APPLY(float, MAXK); }
-  else { if (K == 10) FH_C0_APPLY(bf16, 10); else FH_C0_APPLY(bf16, MAXK); }
+#define FH_C0_APPLY(T, KT, CW) \
+  hipLaunchKernelGGL((conv0_apply_kernel<T, KT, CW>), grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (T*)y)
+  // 8 channels per thread (16-byte bf16 stores) measured SLOWER: 674 vs 416 us (B = 128, C0 = 128) -- the pass is bound by the latency
+  // of its dependent LDS reads, and the wider thread halves the waves that hide it; FH_CONV0_WIDE=1 selects it for experiments
+  static const bool wide_env = getenv("FH_CONV0_WIDE") && getenv("FH_CONV0_WIDE")[0] == '1';
+  const bool wide = wide_env && C0 / 8 <= 256 && 256 % (C0 / 8) == 0;
+  if (dtype == 0) { if (K == 10) FH_C0_APPLY(float, 10, 4); else FH_C0_APPLY(float, MAXK, 4); }
+  else if (wide) { if (K == 10) FH_C0_APPLY(bf16, 10, 8); else FH_C0_APPLY(bf16, MAXK, 8); }
+  else { if (K == 10) FH_C0_APPLY(bf16, 10, 4); else FH_C0_APPLY(bf16, MAXK, 4); }
 #undef FH_C0_APPLY
   FH_CHECK_LAUNCH();
   return 0;

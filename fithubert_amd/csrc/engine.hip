@@ -439,7 +439,7 @@ struct Ctx {
 };
 
 enum { SITE_INPUT = 1, SITE_ENC = 2, SITE_LAYER0 = 16 };
-int g_fused_layer = -1;  // -1: FH_FUSED_LAYER (default on), 0 / 1: fh_student_fused_layers()
+int g_fused_layer = -1;  // -1: FH_FUSED_LAYER (default off), 0 / 1: fh_student_fused_layers()
 
 inline int splitk_for(long tiles, long red) {
   long sk = (512 + tiles - 1) / tiles;
@@ -678,7 +678,9 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
   const long M2 = s.M2;
   const float scale = 1.0f / sqrtf((float)(D / H));
   // full-row fused kernels (layer_fused.hip): out-proj + residual + LayerNorm, and fc1 + GELU + fc2 + residual + LayerNorm
-  if (g_fused_layer < 0) g_fused_layer = (getenv("FH_FUSED_LAYER") && getenv("FH_FUSED_LAYER")[0] == '0') ? 0 : 1;
+  // OFF by default: measured slower than the five-launch form at every batch size (B = 4 / 16 / 32 / 128: 6.26 / 8.15 / 11.2 / 32.5 ms
+  // per student step against 5.57 / 7.49 / 10.5 / 31.2) -- see layer_fused.hip and DESIGN.md section 7
+  if (g_fused_layer < 0) g_fused_layer = (getenv("FH_FUSED_LAYER") && getenv("FH_FUSED_LAYER")[0] == '1') ? 1 : 0;
   const bool fused = g_fused_layer == 1 && fh_layer_fused_ok(dt, D, Fd);
   for (int l = 0; l < L; ++l) {
     const float* lp = prm + p.pl.layer0 + (long)l * p.pl.layer_stride;

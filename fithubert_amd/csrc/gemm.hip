@@ -1790,7 +1790,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
     cand.push_back({path, sk});
   };
   const long red = (long)p.Kseg * p.X.nseg;
-  if (red >= 256) {
+  if (red >= 128) {   // (from two 64-deep K tiles on: the K = 128 conv layer is worth a look for the lean bf16 epilogue of loop 7)
     if (p.ep.atomic) {
       const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
       // the atomic epilogue costs ~9 us per extra split of a 12 x 480 x 480 gradient (tools/gemm_wgrad_sweep.py): fewer workgroups

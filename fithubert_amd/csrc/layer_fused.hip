@@ -16,10 +16,17 @@
 // Arithmetic mirrors the unfused path (gemm.hip epilogue + norm.hip): dropout masks are the same function of (seed, site,
 // element index), GELU is the bf16-mode fast form, the pre-LayerNorm sum is rounded to bf16 before its statistics are taken
 // (the unfused LayerNorm reads the stored bf16 tensor; the backward re-derives x-hat from that tensor with these statistics).
+#include <cstdlib>
+
 #include "kernels.h"
 #include "common.cuh"
 
 namespace {
+
+// Out-of-range rows / reduction indices LOAD from this chunk instead of being skipped: a conditional load compiles to a branch
+// whose join waits for the load (s_waitcnt vmcnt(0)), which serialised the 16 loads of a weight slice -- each paying a full L2
+// round trip -- and made a K slice cost 11 K cycles instead of 1.5 K.
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
 constexpr int FM = 64;     // rows per workgroup
 constexpr int FBK = 64;    // reduction slice
@@ -45,6 +52,7 @@ struct FusedArgs {
   fh_drop drop_act;     // after the GELU (activation_dropout), index i * F + j
   fh_drop drop_out;     // on the second product before the residual, index i * N + j
   float eps;
+  int dbg;              // timing ablations (FH_FUSED_DBG; results are then wrong): 1 no weight fetch, 2 no MFMA, 4 no global stores / fills, 8 no LDS commit
 };
 
 // ---- LDS images
@@ -65,6 +73,7 @@ struct Smem {
   unsigned char* ht;    // hidden tile   [64 rows][F k]      F * 128 bytes (feed-forward only)
   float* red;           // [64 rows][4 waves] x 2
   int stg_stride;       // row-major staging tile over wst + xst: N * 2 + 16 bytes per row
+  int dbg;
 };
 
 // one product: acc[n][m] += A(64 rows x K) . W(N x K)^T for this wave's column tiles.  A streams from global (a_glob) or sits in LDS
@@ -72,24 +81,27 @@ struct Smem {
 template <bool A_LDS>
 __device__ __forceinline__ void product(const Smem& sm, const bf16* __restrict__ a_glob, int lda, int row0, int M,
                                         const unsigned char* a_lds, int KSa, const bf16* __restrict__ W, int N, int K, int wave, int lane,
-                                        int nt_w, f32x4 (&acc)[FNT][4]) {
+                                        int nt_w, f32x4 (&acc)[FNT][4], int dbg = 0) {
   const int tid = wave * 64 + lane;
   constexpr int WIT = 512 * 8 / 256;   // 16-byte chunks of the widest weight slice per thread
   V16 wreg[WIT], xreg[2];
   const int nwchunks = N * 8;
+  const bf16* zc = reinterpret_cast<const bf16*>(g_zero16);
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
       const int c = it * 256 + tid;
       const int n = c >> 3, kc = c & 7, k = k0 + kc * 8;
-      wreg[it] = (c < nwchunks && k < K) ? ld16(W + (long)n * K + k) : v16_zero();
+      const bf16* src = (c < nwchunks && k < K) ? W + (long)n * K + k : zc;
+      wreg[it] = ld16(src);
     }
     if (!A_LDS) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int c = it * 256 + tid;
         const int r = c >> 3, kc = c & 7, k = k0 + kc * 8;
-        xreg[it] = (row0 + r < M && k < K) ? ld16(a_glob + (long)(row0 + r) * lda + k) : v16_zero();
+        const bf16* src = (row0 + r < M && k < K) ? a_glob + (long)(row0 + r) * lda + k : zc;
+        xreg[it] = ld16(src);
       }
     }
   };
@@ -110,9 +122,10 @@ __device__ __forceinline__ void product(const Smem& sm, const bf16* __restrict__
   fetch(0);
   for (int k0 = 0; k0 < K; k0 += FBK) {
     __syncthreads();   // the previous slice's fragment reads are done
-    commit();
+    if (!(dbg & 8)) commit();
     __syncthreads();
-    if (k0 + FBK < K) fetch(k0 + FBK);   // in flight while this slice is in the MFMAs
+    if (k0 + FBK < K && !(dbg & 1)) fetch(k0 + FBK);   // in flight while this slice is in the MFMAs
+    if (dbg & 2) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (k0 + 32 * ks >= K) break;
@@ -120,15 +133,14 @@ __device__ __forceinline__ void product(const Smem& sm, const bf16* __restrict__
 #pragma unroll
       for (int m = 0; m < 4; ++m)
         fx[m] = A_LDS ? sub_frag(a_lds, 16 * m, (k0 >> 5) + ks, KSa, lane) : sub_frag(sm.xst, 16 * m, ks, 2, lane);
+      // (column tiles beyond N -- the last wave's when N < 512 -- multiply whatever lies behind the weight slice in LDS: branch-free,
+      //  their accumulators are never read)
+#pragma unroll
+      for (int n = 0; n < FNT; ++n) fy[n] = sub_frag(sm.wst, (wave * FNT + n) * 16, ks, 2, lane);
 #pragma unroll
       for (int n = 0; n < FNT; ++n)
-        if (n < nt_w) fy[n] = sub_frag(sm.wst, (wave * FNT + n) * 16, ks, 2, lane);
 #pragma unroll
-      for (int n = 0; n < FNT; ++n)
-        if (n < nt_w) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
-        }
+        for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[n][m], 0, 0, 0);
     }
   }
   __syncthreads();   // every wave is done with wst / xst: they become the staging tile
@@ -144,6 +156,7 @@ __device__ __forceinline__ float bf16_round(float x) { return __uint_as_float(bf
 
 // staging tile (row-major, 64 rows x ncols bf16) -> global rows [row0, row0 + 64): 16-byte chunks, contiguous rows
 __device__ __forceinline__ void flush_rows(const Smem& sm, bf16* __restrict__ dst, int ldd, int ncols, int row0, int M, int tid) {
+  if (sm.dbg & 4) return;
   const int cpr = ncols >> 3;
   for (int c = tid; c < FM * cpr; c += 256) {
     const int r = c / cpr, cc = c - r * cpr;
@@ -152,10 +165,12 @@ __device__ __forceinline__ void flush_rows(const Smem& sm, bf16* __restrict__ ds
 }
 // global rows -> staging tile
 __device__ __forceinline__ void fill_rows(const Smem& sm, const bf16* __restrict__ src, int lds_, int ncols, int row0, int M, int tid) {
+  if (sm.dbg & 4) return;
   const int cpr = ncols >> 3;
   for (int c = tid; c < FM * cpr; c += 256) {
     const int r = c / cpr, cc = c - r * cpr;
-    st16(sm.wst + r * sm.stg_stride + cc * 16, row0 + r < M ? ld16(src + (long)(row0 + r) * lds_ + cc * 8) : v16_zero());
+    const bf16* p = row0 + r < M ? src + (long)(row0 + r) * lds_ + cc * 8 : reinterpret_cast<const bf16*>(g_zero16);
+    st16(sm.wst + r * sm.stg_stride + cc * 16, ld16(p));
   }
 }
 
@@ -172,6 +187,7 @@ __global__ void __launch_bounds__(256) layer_rows_kernel(FusedArgs a) {
   sm.ht = sm.xst + 8192;
   sm.red = reinterpret_cast<float*>(sm.ht + (FFN ? F * 128 : 0));
   sm.stg_stride = wcols * 2 + 16;
+  sm.dbg = a.dbg;
   const int row0 = blockIdx.x * FM;
 
   f32x4 acc[FNT][4];
@@ -186,7 +202,7 @@ __global__ void __launch_bounds__(256) layer_rows_kernel(FusedArgs a) {
     // ---------------- fc1: z1 = A W1^T + b1 ; h = drop(gelu(z1))
     const int nt_w = max(0, min(FNT, F / 16 - wave * FNT));
     zero_acc();
-    product<false>(sm, a.A, a.K1, row0, a.M, nullptr, 0, a.W1, F, a.K1, wave, lane, nt_w, acc);
+    product<false>(sm, a.A, a.K1, row0, a.M, nullptr, 0, a.W1, F, a.K1, wave, lane, nt_w, acc, a.dbg);
     const DropKeySpan dks = drop_key_span(a.drop_act, (unsigned long long)row0 * F);
     // pass 1: z1 (bf16) -> staging -> global ; h -> LDS hidden tile (operand image) and kept in acc (as floats) for pass 2
 #pragma unroll
@@ -240,8 +256,8 @@ __global__ void __launch_bounds__(256) layer_rows_kernel(FusedArgs a) {
   // ---------------- second product + residual + LayerNorm
   const int nt_w = max(0, min(FNT, N / 16 - wave * FNT));
   zero_acc();
-  if (FFN) product<true>(sm, nullptr, 0, row0, a.M, sm.ht, F >> 5, a.W2, N, F, wave, lane, nt_w, acc);
-  else product<false>(sm, a.A, a.K1, row0, a.M, nullptr, 0, a.W2, N, a.K1, wave, lane, nt_w, acc);
+  if (FFN) product<true>(sm, nullptr, 0, row0, a.M, sm.ht, F >> 5, a.W2, N, F, wave, lane, nt_w, acc, a.dbg);
+  else product<false>(sm, a.A, a.K1, row0, a.M, nullptr, 0, a.W2, N, a.K1, wave, lane, nt_w, acc, a.dbg);
 
   // product + bias; optional store of it (fc2's "layer result")
 #pragma unroll
@@ -394,6 +410,7 @@ int fh_rows_linear_ln_launch(const void* A, const void* W, const float* b, const
   a.mean = mean; a.rstd = rstd; a.M = M; a.K1 = K; a.F = K; a.N = N;
   a.drop_act.p = 0.f; a.drop_act.seed = 0; a.drop_act.site = 0;
   a.drop_out = drop; a.eps = eps;
+  a.dbg = getenv("FH_FUSED_DBG") ? atoi(getenv("FH_FUSED_DBG")) : 0;
   const size_t smem = fused_smem(N, K, false);
   static bool attr = false;
   if (!attr) {
@@ -415,6 +432,7 @@ int fh_rows_ffn_ln_launch(const void* A, const void* W1, const float* b1, const 
   a.gamma = gamma; a.beta = beta; a.z1 = (bf16*)z1; a.h = (bf16*)h; a.pre = (bf16*)f2; a.s = (bf16*)s; a.y = (bf16*)y;
   a.mean = mean; a.rstd = rstd; a.M = M; a.K1 = D; a.F = F; a.N = D;
   a.drop_act = drop_act; a.drop_out = drop_out; a.eps = eps;
+  a.dbg = getenv("FH_FUSED_DBG") ? atoi(getenv("FH_FUSED_DBG")) : 0;
   const size_t smem = fused_smem(D, F, true);
   static bool attr = false;
   if (!attr) {

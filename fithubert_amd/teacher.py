@@ -203,7 +203,10 @@ class _NativeFrontend:
         self.layers_native = self.dh <= 64 and self.dh % 8 == 0   # head widths the attention kernel is built for
         # fc1 + GELU: hipBLASLt GEMM + PyTorch GELU kernel measured 0.9 ms / forward faster (B = 128) than the HIP GEMM with the
         # GELU epilogue on this K = 768, N = 3072 shape; FH_TEACHER_FC1=native selects the fused kernel
-        self.fc1_native = os.environ.get("FH_TEACHER_FC1", "torch") == "native"
+        self.fc1_native = os.environ.get("FH_TEACHER_FC1", "native") == "native"
+        # the other three Linear products of a layer (q|k|v, out-proj, fc2): hipBLASLt through F.linear ('torch') or the library's
+        # own MFMA GEMM through fh_conv1d_forward ('native'); FH_TEACHER_LINEAR selects
+        self.linear_native = os.environ.get("FH_TEACHER_LINEAR", "torch") == "native"
         self.tl = []
         if self.layers_native:
             f32 = lambda t: t.detach().float().contiguous()
@@ -213,6 +216,8 @@ class _NativeFrontend:
                     wqkv=torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().to(self.tdt).contiguous(),
                     bqkv=torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).detach().to(self.tdt).contiguous(),
                     wo=a.out_proj.weight.detach(), bo=a.out_proj.bias.detach(),
+                    bqkv32=f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)), bo32=f32(a.out_proj.bias),
+                    c232=f32(lyr.fc2.bias),
                     g1=f32(lyr.self_attn_layer_norm.weight), b1=f32(lyr.self_attn_layer_norm.bias),
                     w1=lyr.fc1.weight.detach().to(self.tdt).contiguous(), c1=f32(lyr.fc1.bias), c1t=lyr.fc1.bias.detach(),
                     w2=lyr.fc2.weight.detach(), c2=lyr.fc2.bias.detach(),
@@ -220,6 +225,16 @@ class _NativeFrontend:
 
     def _st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, b32: torch.Tensor, gelu: bool = False) -> torch.Tensor:
+        """y = x w^T + b over the last dim: hipBLASLt (F.linear) or the library's own GEMM (fh_conv1d_forward with k = 1)."""
+        if not self.linear_native:
+            return F.linear(x, w, b)
+        B, T, K = x.shape
+        y = torch.empty(B, T, w.shape[0], device=self.dev, dtype=self.tdt)
+        self.L.check(self.lib.fh_conv1d_forward(self.dt, x.data_ptr(), w.data_ptr(), b32.data_ptr(), y.data_ptr(), B, T, K, w.shape[0],
+                                                1, 1, 1 if gelu else 0, self._st()), "fh_conv1d_forward")
+        return y
 
     def gelu_(self, x: torch.Tensor) -> torch.Tensor:
         """exact GELU in place (one 16-byte-vector streaming kernel; 137 vs 201 us for the ATen kernel on the B = 128 fc1 output)"""
@@ -278,12 +293,12 @@ class _NativeFrontend:
         pairs and fc1 + bias + GELU are HIP kernels.  ``key_len``: int32 [B] valid frames (right-padded batch) or None."""
         L, lib, w = self.L, self.lib, self.tl[i]
         B, T, D = x.shape
-        qkv = F.linear(x, w["wqkv"], w["bqkv"])
+        qkv = self.linear(x, w["wqkv"], w["bqkv"], w["bqkv32"])
         attn = torch.empty(B, T, D, device=self.dev, dtype=self.tdt)
         L.check(lib.fh_attention_forward(self.dt, qkv.data_ptr(), attn.data_ptr(), None, key_len.data_ptr() if key_len is not None else None,
                                          B, T, self.heads, self.dh, float(self.dh) ** -0.5, L.Drop(0.0, 0, 0), self._st()),
                 "fh_attention_forward")
-        o = F.linear(attn, w["wo"], w["bo"])
+        o = self.linear(attn, w["wo"], w["bo"], w["bo32"])
         x1 = self.add_ln(o, x, w["g1"], w["b1"], torch.empty_like(x))
         if self.fc1_native:
             Fd = w["w1"].shape[0]
@@ -292,7 +307,7 @@ class _NativeFrontend:
                                           1, 1, 1, self._st()), "fh_conv1d_forward")
         else:
             h = self.gelu_(F.linear(x1, w["w1"], w["c1t"]))
-        lr = F.linear(h, w["w2"], w["c2"])
+        lr = self.linear(h, w["w2"], w["c2"], w["c232"])
         self.add_ln(lr, x1, w["g2"], w["b2"], out)
         return out, lr
 

@@ -603,6 +603,8 @@ def test_fused_layer_kernels_equal_the_unfused_path(padded, training):
     finally:
         lib.fh_student_fused_layers(-1)
     for n in names:
+        if n == "z1" and not training:
+            continue                       # the five-launch eval forward does not save the pre-activation
         a, b = res[1][0][n], res[0][0][n]
         assert torch.isfinite(a).all(), n
         # same bf16 inputs, fp32 accumulation in a different order, one bf16 rounding: a few ulp on a few elements; errors of the
