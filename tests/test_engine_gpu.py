@@ -3,7 +3,8 @@ captured from the reference.
 
 Tolerances: dtype float (exact-fp32 MFMA): hidden states <= 2e-4 of the tensor scale, KD loss <= 1e-4 absolute
 (the north star's parity figure), gradients <= 2e-3 relative.  dtype bf16: hidden states rel-L2 <= 2e-2, KD loss
-<= 2e-2 relative, gradient norms <= 5e-2 relative (bf16 keeps 8 significant bits)."""
+<= 1.5e-3 relative on the full config (measured 0.7-2.5e-4; 2.3-5.6e-4 of it is the rounding of the WEIGHTS to bf16 alone,
+DESIGN.md section 2), gradient norms <= 6e-2 relative (bf16 keeps 8 significant bits)."""
 import os
 
 import numpy as np
@@ -128,7 +129,7 @@ def test_small_config_loss_and_gradients(dtype, golden_dir):
         want[L - 1] = fx["layer_losses"][-1]
         np.testing.assert_allclose(per_layer, want, rtol=2e-4)
     else:
-        assert abs(loss - ref_loss) < 2e-2 * ref_loss, (loss, ref_loss)
+        assert abs(loss - ref_loss) < 4e-3 * ref_loss, (loss, ref_loss)   # 3-layer model, loss ~2.2: measured 2e-4 relative
     grads = eng.param_views(eng.grads)
     tol = 3e-3 if dtype == "float32" else 6e-2
     no_grad = set(str(s) for s in fx["no_grad_params"])
@@ -170,7 +171,7 @@ def test_full_fithubert_config_2s(dtype, tol_l2, golden_dir):
     out, _ = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(12, dtype=torch.int32, device=DEV), want_grad=False)
     loss = out[12].item()
     ref = float(fx["loss"])
-    assert abs(loss - ref) < (1e-4 if dtype == "float32" else 2e-2 * ref), (loss, ref)
+    assert abs(loss - ref) < (1e-4 if dtype == "float32" else 1.5e-3 * ref), (loss, ref)   # bf16 measured 2.4e-4 relative
     # padded pair
     lens = [int(n) for n in fx["pad_from"]]
     wav_p = wav.clone()
@@ -499,7 +500,7 @@ def test_frozen_extractor_feature_grad_mult_zero_gradients_are_complete_and_stab
 
 # bf16 KD-loss deviation from the reference (eval forward, identical weights / inputs): the test bound per fixture.  Measured values
 # are printed by the test (pytest -s) and recorded in DESIGN.md section 2.
-BF16_LOSS_TOL = {"student_full_10s": 4e-3, "student_full_libri_max": 4e-3}
+BF16_LOSS_TOL = {"student_full_10s": 1.5e-3, "student_full_libri_max": 1.5e-3}   # measured 2.5e-4 / 1.6e-4 (tools/bf16_delta.py)
 
 
 @pytest.mark.parametrize("name", ["student_full_10s", "student_full_libri_max"])
