@@ -33,7 +33,7 @@ GF_STUDENT_FWD, GF_TEACHER_BASE = 35.23, 148.1
 GF_STEP = 3 * GF_STUDENT_FWD + GF_TEACHER_BASE  # 253.8
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 LAYOUTS = {0: "0, 0", 1: "0, 1", 2: "1, 0", 3: "1, 1"}  # <X layout, Y layout>: 0 = R_CONTIG, 1 = R_STRIDED
-LOOPS = {0: "gemm_kernel<bf16, {l}>", 2: "gemm32_kernel<{l}>", 3: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 64, 2>",
+LOOPS = {0: "gemm_kernel<bf16, {l}>", 1: "gemm_small_kernel<0>", 2: "gemm32_kernel<{l}>", 3: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 64, 2>",
          4: "gemm_ring_kernel<{l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{l}>", 7: "gemm_8ph_kernel<{l}>"}
 
 

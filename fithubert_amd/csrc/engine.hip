@@ -13,6 +13,7 @@
 
 #include "gemm.h"
 #include "kernels.h"
+#include "common.cuh"
 
 namespace {
 
@@ -71,6 +72,36 @@ __global__ void head_bias_bwd_kernel(const float* __restrict__ params, float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) t += part[r][cl];
     hg[o_up_b + co] += t;
+  }
+}
+
+// bf16 TRANSPOSED copies of the four Linear weights of every transformer layer, one launch for all of them (grid z = layer x
+// matrix): the data gradients  dX = dY . W  then read W^T with the reduction index contiguous -- both GEMM operands R_CONTIG, which is
+// what the fastest main loops (8-phase, small-M) take; the R_STRIDED form read W through transposing LDS loads in the ring loops only.
+struct LayerTArgs {
+  long src_off[4], dst_off[4];  // element offsets inside a layer's parameter block / transposed block
+  int rows[4], cols[4];         // of the source matrix [rows][cols]
+  long src_stride, dst_stride, src0;
+};
+__global__ void __launch_bounds__(256) layer_transpose_kernel(const float* __restrict__ params, bf16* __restrict__ dst, LayerTArgs a) {
+  __shared__ float tile[32][33];
+  const int l = blockIdx.z >> 2, m = blockIdx.z & 3;
+  const int R = a.rows[m], C = a.cols[m];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  if (c0 >= C || r0 >= R) return;
+  const float* src = params + a.src0 + (long)l * a.src_stride + a.src_off[m];
+  bf16* out = dst + (long)l * a.dst_stride + a.dst_off[m];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < R) out[(long)c * R + r] = (bf16)tile[tx][ty + 8 * i];
   }
 }
 
@@ -238,6 +269,7 @@ struct WcLayout {
   long tr_wf = -1, head_wup = -1, head_wup_stride = 0, pos_wf, pos_wb, pos_norm;
   long head_wm = -1, head_bm = -1, head_wupf = -1;  // merged head weights [L][f*P][D] (compute dtype), merged bias [L][P] fp32,
                                                     // fp32 copy of the permuted upsampler weights [L][f][D][D]
+  long layT = -1, layT_stride = 0, t_qkv = 0, t_o = 0, t_fc1 = 0, t_fc2 = 0;  // bf16 transposed layer weights (bytes / elements)
   long total = 0;
   WcLayout(const fh_student_config& c, const ParamLayout& pl) {
     const int es = c.dtype == 0 ? 4 : 2;
@@ -266,6 +298,12 @@ struct WcLayout {
     pos_wf = o; o += rup(pw * es, 256);
     pos_wb = o; o += rup(pw * es, 256);
     pos_norm = o; o += rup(3L * c.conv_pos * 4, 256);
+    if (c.dtype != 0) {  // [L] x { Wqkv^T [D][3D] | Wo^T [D][D] | W1^T [D][Fd] | W2^T [Fd][D] }
+      const long Fd = c.ffn_dim;
+      t_qkv = 0; t_o = 3 * D * D; t_fc1 = t_o + D * D; t_fc2 = t_fc1 + D * Fd;
+      layT_stride = t_fc2 + Fd * D;
+      layT = o; o += rup(layT_stride * c.layers * 2, 256);
+    }
     total = o;
   }
 };
@@ -428,6 +466,10 @@ struct Ctx {
     return p.c.dtype == 0 ? (const void*)(params + poff) : (const void*)(wc + p.wl.cast_off + poff * 2);
   }
   const void* rel(long boff) const { return wc + boff; }
+  // transposed bf16 weight `toff` of layer l (bf16 mode), or null
+  const void* layT(int l, long toff) const {
+    return p.wl.layT >= 0 ? (const void*)(wc + p.wl.layT + ((long)l * p.wl.layT_stride + toff) * 2) : nullptr;
+  }
   fh_drop drop(float prob, uint32_t site) const {
     fh_drop d;
     d.p = p.k.training ? prob : 0.f;
@@ -594,6 +636,19 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
   }
   RC(fh_posconv_prep_launch(dt, params + p.pl.pos_g, params + p.pl.pos_v, wc + p.wl.pos_wf, wc + p.wl.pos_wb,
                             (float*)(wc + p.wl.pos_norm), D, c.conv_pos_groups, c.conv_pos, st));
+  if (p.wl.layT >= 0) {
+    const int Fd = c.ffn_dim;
+    LayerTArgs a;
+    a.src0 = p.pl.layer0; a.src_stride = p.pl.layer_stride; a.dst_stride = p.wl.layT_stride;
+    a.src_off[0] = p.pl.l_qkv_w; a.dst_off[0] = p.wl.t_qkv; a.rows[0] = 3 * D; a.cols[0] = D;
+    a.src_off[1] = p.pl.l_o_w;   a.dst_off[1] = p.wl.t_o;   a.rows[1] = D;     a.cols[1] = D;
+    a.src_off[2] = p.pl.l_fc1_w; a.dst_off[2] = p.wl.t_fc1; a.rows[2] = Fd;    a.cols[2] = D;
+    a.src_off[3] = p.pl.l_fc2_w; a.dst_off[3] = p.wl.t_fc2; a.rows[3] = D;     a.cols[3] = Fd;
+    const int maxc = D > Fd ? D : Fd, maxr = 3 * D > Fd ? 3 * D : Fd;
+    hipLaunchKernelGGL(layer_transpose_kernel, dim3((maxc + 31) / 32, (maxr + 31) / 32, c.layers * 4), dim3(256), 0, st, params,
+                       (bf16*)(wc + p.wl.layT), a);
+    FH_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -1031,7 +1086,8 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     {  // dz1 = (df2 . W2) * mask2 * gelu'(z1)
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(df2_l, FH_R_CONTIG, D);
-      g.Y = fh_operand(x.nat(lpo + p.pl.l_fc2_w), FH_R_STRIDED, Fd);
+      if (const void* wt = x.layT(l, p.wl.t_fc2)) g.Y = fh_operand(wt, FH_R_CONTIG, D);   // W2^T [Fd][D]
+      else g.Y = fh_operand(x.nat(lpo + p.pl.l_fc2_w), FH_R_STRIDED, Fd);
       g.C = x.at(p.dz1, (long)l * M2 * Fd);
       g.M = (int)M2; g.N = Fd; g.Kseg = D; g.ldc = Fd;
       g.ep.drop = x.drop(c.activation_dropout, site + 2);
@@ -1041,7 +1097,8 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     {  // dx1 = dz1 . W1 + ds2
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.at(p.dz1, (long)l * M2 * Fd), FH_R_CONTIG, Fd);
-      g.Y = fh_operand(x.nat(lpo + p.pl.l_fc1_w), FH_R_STRIDED, D);
+      if (const void* wt = x.layT(l, p.wl.t_fc1)) g.Y = fh_operand(wt, FH_R_CONTIG, Fd);  // W1^T [D][Fd]
+      else g.Y = fh_operand(x.nat(lpo + p.pl.l_fc1_w), FH_R_STRIDED, D);
       g.C = x.W(p.dx1b);
       g.M = (int)M2; g.N = D; g.Kseg = Fd; g.ldc = D;
       g.ep.residual = x.W(p.ds2);
@@ -1054,7 +1111,8 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     {  // da = dao . Wo
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(dao_l, FH_R_CONTIG, D);
-      g.Y = fh_operand(x.nat(lpo + p.pl.l_o_w), FH_R_STRIDED, D);
+      if (const void* wt = x.layT(l, p.wl.t_o)) g.Y = fh_operand(wt, FH_R_CONTIG, D);     // Wo^T [D][D]
+      else g.Y = fh_operand(x.nat(lpo + p.pl.l_o_w), FH_R_STRIDED, D);
       g.C = x.W(p.da);
       g.M = (int)M2; g.N = D; g.Kseg = D; g.ldc = D;
       RC(fh_gemm_launch(g, dt, x.st));
@@ -1068,7 +1126,8 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     {  // dxin = dqkv . Wqkv + ds1
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.at(p.dqkv, (long)l * M2 * 3 * D), FH_R_CONTIG, 3 * D);
-      g.Y = fh_operand(x.nat(lpo + p.pl.l_qkv_w), FH_R_STRIDED, D);
+      if (const void* wt = x.layT(l, p.wl.t_qkv)) g.Y = fh_operand(wt, FH_R_CONTIG, 3 * D);  // Wqkv^T [D][3D]
+      else g.Y = fh_operand(x.nat(lpo + p.pl.l_qkv_w), FH_R_STRIDED, D);
       g.C = x.at(p.dxin, (long)(l & 1) * M2 * D);
       g.M = (int)M2; g.N = D; g.Kseg = 3 * D; g.ldc = D;
       g.ep.residual = x.W(p.ds1);

@@ -230,13 +230,13 @@ template <int XL, int YL> struct TileMath<float, XL, YL> {
 };
 
 // ------------------------------------------------------------------ epilogue (shared by both main loops)
-template <typename T>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int i0, int j0, int xi0, int yj0,
+template <typename T, int NN = 4, int NM = 4>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[NN][NM], int i0, int j0, int xi0, int yj0,
                                               int lane, int g) {
   const GemmEpilogue& ep = p.ep;
   const int jq = (lane >> 4) * 4;
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < NM; ++m) {
     const int i = i0 + xi0 + 16 * m + (lane & 15);
     if (i >= p.M) continue;
     RowMap rm = map_row(i, p.c_rpb);
@@ -244,7 +244,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
     bool zero_row = false;
     if (ep.row_len) zero_row = rm.t >= ep.row_len[rm.b];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < NN; ++n) {
       const int j = j0 + yj0 + 16 * n + jq;
       if (j >= p.N) continue;
       if (ep.tail_cols > 0 && rm.t == p.c_rpb - 1 && j >= ep.tail_cols) continue;
@@ -1164,6 +1164,68 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams
   }
 }
 
+// ------------------------------------------------------------------ small-M loop (R_CONTIG x R_CONTIG): the whole reduction in one trip
+// At the reference's own batch (3 utterances per GPU: M = 747 rows per layer GEMM) a launch has a few dozen tiles and its time
+// is the LATENCY of its K loop: 7.5 dependent load -> LDS -> MFMA steps of ~2.5 us each = 22-27 us for 30 MFLOP, 110 such launches
+// per step.  Here a workgroup of 4 waves owns a 64 x 64 tile and brings the WHOLE reduction extent (512 elements per pass: 64 KiB per
+// operand) into LDS with one burst of LDS-DMA -- one memory round trip --, then runs all its MFMAs back to back; wave w owns the
+// 16-column strip w (4 accumulators), the operand image and fragment reads are the ring loaders'.  ~4x more tiles than the
+// 128-tile loops (so the few rows spread over the CUs) and ~3x shorter per launch.
+template <int DUMMY>
+__global__ void __launch_bounds__(256) gemm_small_kernel(const GemmParams p) {
+  typedef RingLoader<FH_R_CONTIG, 64, 512, 4> LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.z;
+  const int tiles_j = (p.N + 63) / 64;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
+  const int i0 = ti * 64, j0 = tj * 64;
+  LD lx, ly;
+  lx.init(p.X, g, i0, p.M, tid);
+  ly.init(p.Y, g, j0, p.N, tid);
+  f32x4 acc[1][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nseg = tile_nseg(p, j0);
+  for (int seg = 0; seg < nseg; ++seg)
+    for (int k0 = 0; k0 < p.Kseg; k0 += 512) {
+      lx.set_tile(p.X, seg, k0, p.Kseg);
+      ly.set_tile(p.Y, seg, k0, p.Kseg);
+      lx.issue(lds);
+      ly.issue(lds + LD::TILE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int nks = min(16, (p.Kseg - k0 + 31) >> 5);
+      for (int ks = 0; ks < nks; ++ks) {
+        const bf16x8 fy = LD::frag(lds + LD::TILE, 16 * wave, ks, lane);
+        bf16x8 fx[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fx[m] = LD::frag(lds, 16 * m, ks, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy, fx[m], acc[0][m], 0, 0, 0);
+      }
+      __syncthreads();  // the tiles are rewritten by the next pass
+    }
+  gemm_epilogue<bf16, 1, 4>(p, acc, i0, j0, 0, 16 * wave, lane, g);
+}
+bool small_ok(const GemmParams& p) {
+  return p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG && !p.ep.atomic && (p.splitk & 0xffff) <= 1;
+}
+int launch_small(const GemmParams& p, hipStream_t stream) {
+  const int tiles_i = (p.M + 63) / 64, tiles_j = (p.N + 63) / 64;
+  dim3 grid(tiles_i * tiles_j, 1, p.groups), block(256);
+  const size_t smem = 2 * (size_t)64 * 512 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_small_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_small_kernel<0>, grid, block, smem, stream, p);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM - 1) / BM, tiles_j = (p.N + BN - 1) / BN;
   dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(256);
@@ -1734,7 +1796,7 @@ std::unordered_map<unsigned long long, TuneChoice> g_tune;
 void resolve_path() {
   if (g_gemm_path < 0) {
     const char* e = getenv("FH_GEMM_PATH");
-    g_gemm_path = !e ? 9 : ((e[0] == 'r' ? 0 : ((e[0] >= '2' && e[0] <= '7') ? e[0] - '0' : 9)));
+    g_gemm_path = !e ? 9 : ((e[0] == 'r' ? 0 : ((e[0] >= '1' && e[0] <= '7') ? e[0] - '0' : 9)));
   }
 }
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
@@ -1743,6 +1805,7 @@ int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   if (path == 0 || (path == 3 && ring_ok(p, 64)) || (path >= 4 && path <= 6 && ring_ok(p, 32)) ||
       (path == 7 && ring_ok(p, 64)))
     g_last_loop = path;
+  if (path == 1 && small_ok(p)) { g_last_loop = 1; return launch_small(p, stream); }
   if (path == 0) return launch_t<bf16>(p, stream);
   if (path == 3 && ring_ok(p, 64)) return launch_ring<256, 256, 2, 4, 64, 2>(p, stream);
   if (path == 4 && ring_ok(p, 32)) return launch_ring<256, 128, 2, 2, 32, 3>(p, stream);
@@ -1806,6 +1869,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
       add(2, ring_splitk(p, 128, 128, 1024));
     } else {
       add(0, p.splitk);
+      if (small_ok(p) && (long)p.M * p.N * p.groups <= (long)8192 * 2048) add(1, p.splitk);  // few tiles: the one-trip small-M loop
       if (ring_ok(p, 64)) add(3, p.splitk);
       if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); add(6, p.splitk); }
       if (ring_ok(p, 64)) add(7, p.splitk);

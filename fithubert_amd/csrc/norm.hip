@@ -118,6 +118,9 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
+#ifndef LN_BWD_UNROLL
+#define LN_BWD_UNROLL 2
+#endif
 // dy_total = (dy [+ dy2]) [* dropmask(out_drop)]  is the gradient w.r.t. the LayerNorm output.
 // dx -> gradient w.r.t. the LayerNorm input; dx2 (optional) = dx * dropmask(in_drop).
 template <typename T, int NCH>
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(NCH == 1 ? 1024 : (NCH == 2 ? 512 : 256)) ln_b
   }
   const int r0 = wave_global * rows_per_wave;
   const int r1 = min(M, r0 + rows_per_wave);
-#pragma unroll 2
+#pragma unroll LN_BWD_UNROLL
   for (int row = r0; row < r1; ++row) {
     const float mean = mean_in[row], rstd = rstd_in[row];
     float g[NCH][VEC], xh[NCH][VEC];
@@ -300,7 +303,9 @@ int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const flo
   // 16 waves x 8 rows per workgroup: the per-column dgamma / dbeta sums leave a workgroup as ONE atomic per column, so rows per
   // workgroup set the atomic count (128 rows: 249 x 960 atomics for the student's 31872 x 480; 64 rows as 4 waves x 16 was 20 %
   // slower), while 8 rows per wave keep ~4000 waves in flight for the load -> shuffle-reduce -> store chain
-  const int rpw = 8;
+  // few rows (the reference's own batch: 747 per layer): one dependent 8-row walk per wave was the whole 25 us of the launch;
+  // fewer rows per wave shorten the chain (the extra per-column atomics are nothing at that size)
+  const int rpw = M >= 16384 ? 8 : (M >= 4096 ? 4 : (M >= 1024 ? 2 : 1));
   const int wpb = nch == 1 ? 16 : (nch == 2 ? 8 : 4);  // = the kernel's launch bound; [waves][2][C] floats of LDS stay <= 64 KiB
   const int waves = (M + rpw - 1) / rpw;
   dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);

@@ -88,10 +88,11 @@ int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 /* Optional per-launch HIP-event timing of the GEMM kernel on its own stream (used by bench.py's roofline object).
  * Slots are indexed loop*8 + dtype*4 + X.layout*2 + Y.layout (loop: the main loop that ran, fh_gemm_set_path numbering).
  * collect() waits for the recorded events, sums into 64-entry arrays, and clears. */
-/* bf16 main loop: 0 = 16x16x32 MFMA register staging (128x128 tile), 2 = 32x32x16 MFMA register
+/* bf16 main loop: 0 = 16x16x32 MFMA register staging (128x128 tile), 1 = small-M loop (64x64 tiles, the whole reduction extent in LDS
+ * in one LDS-DMA trip; R_CONTIG x R_CONTIG), 2 = 32x32x16 MFMA register
  * staging (128x128), 3 / 4 / 5 = large-tile LDS-DMA rings (256x256 BK 64, 256x128 BK 32, 256x256 BK 32), 6 = 256x256 ping-pong
  * ring, 7 = 256x256 8-phase loop (R_CONTIG x R_CONTIG), 9 = per-shape choice (default), -1 = re-read env FH_GEMM_PATH
- * (reg | 2..7). */
+ * (reg | 1..7). */
 int fh_gemm_set_path(int path);
 /* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
  * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the

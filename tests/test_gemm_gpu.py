@@ -208,7 +208,7 @@ def test_gemm_groups_dropout_rowmask(dt):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("loop", [2, 3, 5, 6, 7])
+@pytest.mark.parametrize("loop", [1, 2, 3, 5, 6, 7])
 @pytest.mark.parametrize("opts", ["plain", "bias_gelu", "bias_preact_gelu_drop", "aux_residual", "rowmask_drop",
                                   "gapped_aux_residual", "gapped_bias_preact_gelu_drop_rowmask"])
 def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
@@ -333,3 +333,43 @@ def test_conv1d_k3s2_dgrad_as_one_gemm(dt, path, cin, cout, T):
     rtol, atol = _tol(dt, 2 * cout)
     tol = (atol + rtol) * ref.abs().max().item() * (1.0 if dt == L.DT_F32 else 1.5)   # bf16: the fast gelu' adds <= 1.1e-4
     assert (dx[:, :covered].double() - ref[:, :covered]).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("M,N,K,nseg", [(747, 480, 480, 1), (996, 1440, 480, 1), (250, 480, 1440, 1), (130, 96, 520, 1), (747, 480, 960, 1),
+                                        (300, 256, 256, 2)])
+def test_small_m_loop_one_trip_reduction(M, N, K, nseg):
+    """Path 1 (gemm_small_kernel): 64 x 64 tiles whose whole reduction extent comes into LDS in one LDS-DMA burst per 512-deep
+    pass -- the loop the per-shape tuner picks for the reference's own batch (3 utterances: 747 rows).  Ragged M / N tiles, K
+    that is not a multiple of 32 x 16, several passes (K > 512), a grouped launch and a two-segment reduction with row shifts
+    (conv windows), against fp64 and against the register-staging loop 2."""
+    dev = "cuda"
+    torch.manual_seed(M + N + K)
+    G = 3
+    X = torch.randn(G, M + 1, K, device=dev).to(torch.bfloat16)   # one spare row: segment 1 reads row t + 1
+    W = (torch.randn(G, N, nseg * K, device=dev) / (nseg * K) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+
+    def run(path):
+        L.lib().fh_gemm_set_path(path)
+        out = torch.full((G, M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        d = L.GemmDesc()
+        d.X = L.operand(X.data_ptr(), 0, K, gstride=(M + 1) * K, nseg=nseg, tshift=(0, 1) if nseg == 2 else (0, 0))
+        d.Y = L.operand(W.data_ptr(), 0, nseg * K, gstride=N * nseg * K, nseg=nseg, segoff=(0, K) if nseg == 2 else (0, 0))
+        d.C = out.data_ptr()
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk, d.c_gstride = M, N, K, N, G, 1, M * N
+        d.ep = L.epilogue(bias=bias.data_ptr())
+        _run(d, L.DT_BF16)
+        return out
+
+    try:
+        got, base = run(1), run(2)
+    finally:
+        L.lib().fh_gemm_set_path(9)
+    Xd, Wd = X.double(), W.double()
+    ref = Xd[:, :M] @ Wd[:, :, :K].transpose(1, 2) + bias.double()
+    if nseg == 2:
+        ref = ref + Xd[:, 1:M + 1] @ Wd[:, :, K:].transpose(1, 2)
+    scale = ref.abs().max().item()
+    assert not torch.isnan(got.float()).any()
+    assert (got.double() - ref).abs().max().item() <= 2e-2 * scale
+    assert (got.double() - base.double()).abs().max().item() <= 1e-2 * scale
