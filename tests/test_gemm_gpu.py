@@ -288,10 +288,11 @@ def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
     assert err <= 2e-2 * scale, (err, scale)
 
 
-@pytest.mark.parametrize("dt,path", [(L.DT_F32, 9), (L.DT_BF16, 0), (L.DT_BF16, 2), (L.DT_BF16, 3), (L.DT_BF16, 4), (L.DT_BF16, 5),
-                                     (L.DT_BF16, 6), (L.DT_BF16, 7)])
+@pytest.mark.parametrize("dt,path", [(L.DT_F32, 9), (L.DT_BF16, 0), (L.DT_BF16, 1), (L.DT_BF16, 2), (L.DT_BF16, 3), (L.DT_BF16, 4),
+                                     (L.DT_BF16, 5), (L.DT_BF16, 6), (L.DT_BF16, 7)])
+@pytest.mark.parametrize("wt", [False, True])
 @pytest.mark.parametrize("cin,cout,T", [(256, 256, 399), (256, 256, 400), (512, 512, 263), (64, 128, 38)])
-def test_conv1d_k3s2_dgrad_as_one_gemm(dt, path, cin, cout, T):
+def test_conv1d_k3s2_dgrad_as_one_gemm(dt, path, cin, cout, T, wt):
     """The k = 3, s = 2 conv data gradient as ONE product (engine.hip): output row u = frame pair (2u, 2u+1), segment 0 =
     dy[u] against [W_0 | W_1], segment 1 = dy[u-1] against [W_2 | 0] (Y.seg1_limit: never multiplied), times gelu'(aux); with
     an odd number of input frames the last pair's odd frame does not exist (ep.tail_cols) -- the buffer is NaN-poisoned around
@@ -315,7 +316,11 @@ def test_conv1d_k3s2_dgrad_as_one_gemm(dt, path, cin, cout, T):
     dx = buf[: B * T * cin].view(B, T, cin)
     d = L.GemmDesc()
     d.X = L.operand(dy.data_ptr(), 0, cout, rpb=n_even, bstride=Tout * cout, nseg=2, tshift=(0, -1), tvalid=Tout)
-    d.Y = L.operand(wf.data_ptr(), 1, k * cin, nseg=2, segoff=(0, 2 * cin), seg1_limit=cin)
+    if wt:   # the engine's bf16 form: weights as [k * Cin][Cout] (reduction index contiguous), segment 1 = the rows of tap 2
+        wtt = w.permute(2, 1, 0).contiguous().view(k * cin, cout)
+        d.Y = L.operand(wtt.data_ptr(), 0, cout, nseg=2, segoff=(0, 2 * cin * cout), seg1_limit=cin)
+    else:
+        d.Y = L.operand(wf.data_ptr(), 1, k * cin, nseg=2, segoff=(0, 2 * cin), seg1_limit=cin)
     d.C = dx.data_ptr()
     d.M, d.N, d.Kseg, d.groups, d.splitk = B * n_even, 2 * cin, cout, 1, 1
     d.ldc, d.c_rpb, d.c_bstride = 2 * cin, n_even, T * cin
