@@ -146,6 +146,21 @@ def run_variants(task, cfg, args, dev, budget_s: float):
             "equiv_10s_per_s": round(smp / SAMPLES_10S / dt, 1), "ms_per_step": round(dt / 4 * 1e3, 2),
             "workload": "BASELINE.json configs[2] per GPU: buckets of 64 sorted-by-length utterances drawn from the LibriSpeech "
                         "train-clean-100 length table, zero-padded to the bucket maximum"}
+    # ---- the reference's own training configuration: 3 utterances per GPU, 4 accumulated micro-batches per optimizer step
+    # (data/conf/fithubert.yaml:9-10) -- the latency-bound end of the design
+    if left() > 30:
+        c3 = copy.deepcopy(cfg)
+        c3["train"]["accumulate_grad_batches"] = 4
+        t3 = W2V2Distil(c3, dtype=args.dtype, device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native",
+                        teacher=task.teacher_model)
+        t3.configure_optimizers(num_training_steps=100)
+        batches = [fixed_length_batch(3, SAMPLES_10S, seed=50 + i, device=dev) for i in range(4)]
+        dt, utt, smp = time_steps(t3, batches, 16, 8)
+        assert t3.opt_step == 6
+        out["reference_batch_3x4"] = {"per_gpu_batch": 3, "accumulate_grad_batches": 4, "utt_per_s": round(utt / dt, 1),
+                                      "ms_per_micro_batch": round(dt / 16 * 1e3, 2), "ms_per_optimizer_step": round(dt / 4 * 1e3, 2),
+                                      "workload": "fithubert.yaml as shipped: batch_size 3, accumulate_grad_batches 4, fixed 10 s clips"}
+        del t3
     # ---- 24-layer student + HuBERT-Large-shaped teacher
     if left() > 45:
         c2 = copy.deepcopy(cfg)

@@ -261,29 +261,35 @@ __global__ void __launch_bounds__(256) conv0_bwd_onepass_kernel(Conv0Args a, con
   }
 }
 
-// per utterance b: waveform sums from the statistics partials (fp64), then for every channel the formula above
+// per (utterance b, block of 64 channels): waveform sums from the statistics partials and the per-channel sums of the pass
+// partials (fp64, every thread walking a CONTIGUOUS run of the partial arrays -- the first form had one thread per channel walk
+// all blocks with a 48-byte stride: 95-180 us for a few KB of arithmetic), then for every channel the formula above
+constexpr int CBW = 64;
 __global__ void __launch_bounds__(256) conv0_bwd_combine_kernel(const float* spart, const float* wpart, const float* w,
                                                                 const float* gamma, const float* mean, const float* rstd, float* dw,
                                                                 float* dgamma, float* dbeta, int nchunk, int nblk, int C0, int K,
                                                                 int KT, int T0, float scale) {
   __shared__ double sx[MAXK], rx[MAXK * MAXK];
-  const int b = blockIdx.x;
+  __shared__ double acc[CBW * (MAXK + 2)];
+  const int b = blockIdx.x, cb = blockIdx.y * CBW;
   const int ns = K + K * K;
   for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-    double acc = 0.0;
-    for (int k = 0; k < nchunk; ++k) acc += (double)spart[((long)b * nchunk + k) * ns + s];
-    if (s < K) sx[s] = acc; else rx[s - K] = acc;
+    double a = 0.0;
+    for (int k = 0; k < nchunk; ++k) a += (double)spart[((long)b * nchunk + k) * ns + s];
+    if (s < K) sx[s] = a; else rx[s - K] = a;
+  }
+  const int per = KT + 2, items = CBW * per;   // (channel, slot) pairs of this block: contiguous in every partial block
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    double a = 0.0;
+    const float* pp = wpart + ((long)b * nblk * C0 + cb) * per + it;
+    for (int k = 0; k < nblk; ++k) a += (double)pp[(long)k * C0 * per];
+    acc[it] = a;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C0; c += blockDim.x) {
-    double A[MAXK], s1 = 0.0, s2 = 0.0;
-    for (int j = 0; j < K; ++j) A[j] = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-      const float* pp = wpart + (((long)b * nblk + k) * C0 + c) * (KT + 2);
-      for (int j = 0; j < K; ++j) A[j] += (double)pp[j];
-      s1 += (double)pp[KT];
-      s2 += (double)pp[KT + 1];
-    }
+  const int c = cb + threadIdx.x;
+  if (threadIdx.x < CBW && c < C0) {
+    const double* A = acc + threadIdx.x * per;
+    const double s1 = A[KT], s2 = A[KT + 1];
     const double g = gamma[c], rs = rstd[b * C0 + c], mu = mean[b * C0 + c];
     const double m1 = g * s1 / T0, m2 = g * s2 / T0;
     for (int j = 0; j < K; ++j) {
@@ -370,7 +376,7 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
   else { if (K == 10) FH_C0_WG(bf16, 10); else FH_C0_WG(bf16, MAXK); }
 #undef FH_C0_WG
   FH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv0_bwd_combine_kernel, dim3(B), dim3(256), 0, st, (const float*)part, (const float*)wpart, w, gamma, mean,
+  hipLaunchKernelGGL(conv0_bwd_combine_kernel, dim3(B, (C0 + CBW - 1) / CBW), dim3(256), 0, st, (const float*)part, (const float*)wpart, w, gamma, mean,
                      rstd, dw, dgamma, dbeta, a.nchunk, nblk, C0, K, K == 10 ? 10 : MAXK, a.T0, grad_scale);
   FH_CHECK_LAUNCH();
   return 0;

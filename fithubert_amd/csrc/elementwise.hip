@@ -22,11 +22,13 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
 // dst[a][b][c] (dims d[p0], d[p1], d[p2]) = src[i0][i1][i2] with (a, b, c) = (i[p0], i[p1], i[p2])
 template <typename T>
 __global__ void permute3_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int d2, int p0, int p1,
-                                int p2) {
+                                int p2, long src_gstride, long dst_gstride) {
   const int d[3] = {d0, d1, d2};
   const long n = (long)d0 * d1 * d2;
   const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
+  src += (long)blockIdx.y * src_gstride;   // blockIdx.y = group (one launch for the 12 projection heads)
+  dst += (long)blockIdx.y * dst_gstride;
   const int e1 = d[p1], e2 = d[p2];
   int idx[3];
   idx[p2] = (int)(o % e2);
@@ -206,14 +208,14 @@ int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t s
 }
 
 int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int d1, int d2, int p0, int p1, int p2,
-                            hipStream_t st) {
+                            hipStream_t st, int groups, long src_gstride, long dst_gstride) {
   const long n = (long)d0 * d1 * d2;
-  if (n <= 0) return 0;
-  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (n <= 0 || groups <= 0) return 0;
+  dim3 grid((unsigned)((n + 255) / 256), groups), block(256);
   if (dtype == 0)
-    hipLaunchKernelGGL(permute3_kernel<float>, grid, block, 0, st, src, (float*)dst, d0, d1, d2, p0, p1, p2);
+    hipLaunchKernelGGL(permute3_kernel<float>, grid, block, 0, st, src, (float*)dst, d0, d1, d2, p0, p1, p2, src_gstride, dst_gstride);
   else
-    hipLaunchKernelGGL(permute3_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, d0, d1, d2, p0, p1, p2);
+    hipLaunchKernelGGL(permute3_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, d0, d1, d2, p0, p1, p2, src_gstride, dst_gstride);
   FH_CHECK_LAUNCH();
   return 0;
 }

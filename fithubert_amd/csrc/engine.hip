@@ -289,8 +289,7 @@ struct WcLayout {
       if (c.n_tasks == 0) {
         head_wm = o; o += rup((long)c.layers * c.tr_factor * c.pred_dim * D * es, 256);
         head_bm = o; o += rup((long)c.layers * c.pred_dim * 4, 256);
-        if (c.dtype != 0) { head_wupf = o; o += rup(head_wup_stride * c.layers * 4, 256); }
-        else head_wupf = head_wup;
+        head_wupf = head_wup;   // (round 1 kept an fp32 copy for the chain rule of the merged heads; it runs in the compute dtype now)
       }
     }
     const long cp = fh_posconv_cp(c.embed_dim / c.conv_pos_groups);
@@ -341,7 +340,7 @@ struct Plan {
   long c0_mean, c0_rstd, c0_scratch;
   long ln0, ln0_mean, ln0_rstd, features, x0, zc, psum, ln1_mean, ln1_rstd, x1;
   long xo, qkv, attn, lse, s1, st1_mean, st1_rstd, xa, z1, hbuf, f2, s2, st2_mean, st2_rstd;
-  long u = -1, pred, hz = -1, hh = -1, dhz = -1, gfeat = -1, cnn_pred = -1, dgf = -1, dwm = -1, dbl = -1;
+  long u = -1, pred, hz = -1, hh = -1, dhz = -1, gfeat = -1, cnn_pred = -1, dgf = -1, dwm = -1, dwm16 = -1, dbl = -1;
   // backward
   long du, ghead, dxin, ds2, df2, dz1, dx1b, ds1, dao, da, dqkv, delta;
   long dx1tr, dpsum, dzc, dx0, dfeat, dln0, dylast, pos_dws;
@@ -407,6 +406,7 @@ struct Plan {
       du = -1;
       if (c.n_tasks == 0 && c.tr_factor > 0) {  // gradient of the merged head weights / this pass's d_pred column sums
         dwm = ws.add("dwm", {Lh, (long)sh.f * P, D}, 4);
+        if (c.dtype != 0) dwm16 = ws.add("dwm16", {Lh, (long)sh.f * P, D}, 2);
         dbl = ws.add("dbl", {Lh, P}, 4);
       }
       ghead = ws.add("ghead", {L, M2, D}, es);
@@ -606,14 +606,10 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
     RC(fh_permute3_cast_launch(dt, params + p.pl.tr_w, wc + p.wl.tr_wf, D, D, c.tr_factor, 0, 2, 1, st));
     const int es = dt == 0 ? 4 : 2;
     if (c.n_tasks == 0) {
-      for (int l = 0; l < c.layers; ++l) {
-        // ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin]
-        RC(fh_permute3_cast_launch(dt, params + p.pl.head0 + l * p.pl.head_stride + p.pl.h_up_w,
-                                   wc + p.wl.head_wup + (long)l * p.wl.head_wup_stride * es, D, D, c.tr_factor, 2, 1, 0, st));
-        if (dt != 0)
-          RC(fh_permute3_cast_launch(0, params + p.pl.head0 + l * p.pl.head_stride + p.pl.h_up_w,
-                                     wc + p.wl.head_wupf + (long)l * p.wl.head_wup_stride * 4, D, D, c.tr_factor, 2, 1, 0, st));
-      }
+      // ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin], all heads in one launch (the bf16 mode's chain rule runs on these
+      // bf16 copies too; the fp32 mode's copy IS the fp32 one)
+      RC(fh_permute3_cast_launch(dt, params + p.pl.head0 + p.pl.h_up_w, wc + p.wl.head_wup, D, D, c.tr_factor, 2, 1, 0, st, c.layers,
+                                 p.pl.head_stride, p.wl.head_wup_stride));
       // merged weights Wm[l][j][p][ci] = sum_co Wlin[l][p][co] * Wup[l][ci][co][j]
       const int P = c.pred_dim, f = c.tr_factor;
       const unsigned char* nat = dt == 0 ? (const unsigned char*)params : wc + p.wl.cast_off;
@@ -973,27 +969,34 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
         RC(wgrad(x, d_pred, fP, A, x.W<float>(p.dwm), (int)fP, D, M2, Lh, M2 * fP, fP * D, 0, 0, 0, 0, 0, 0, -1, hs));
         RC(fh_colsum_launch(dt, d_pred, x.W<float>(p.dbl), (int)(M2 * s.f), P, P, Lh, M2 * fP, P, 0, 1.f, hs));
       }
-      // chain rule onto the reference's parameters (fp32 GEMMs on the fp32 masters, accumulate into the gradient buffer)
-      const float* wupf = (const float*)x.rel(p.wl.head_wupf) + (long)l0 * p.wl.head_wup_stride;
+      // chain rule onto the reference's parameters, accumulated into the gradient buffer: in the compute dtype (fp32 mode: exact fp32
+      // GEMMs on the fp32 masters; bf16 mode: the fp32 merged-weight gradient is rounded to bf16 once and the four grouped products run
+      // on the bf16 MFMA with fp32 accumulation -- the fp32 form cost 0.5 ms per optimizer step, 7 % of a step at the reference's batch)
+      const unsigned char* dwm_c = x.W<unsigned char>(p.dwm);
+      if (dt != 0) {
+        RC(fh_cast_launch(dt, x.W<float>(p.dwm), x.W(p.dwm16), (long)Lh * fP * D, hs));
+        dwm_c = x.W<unsigned char>(p.dwm16);
+      }
+      const unsigned char* wupc = (const unsigned char*)x.rel(p.wl.head_wupf) + (long)l0 * p.wl.head_wup_stride * p.es;
       for (int j = 0; j < s.f; ++j) {
         {  // dWlin[p][co] += sum_ci dWm[j][p][ci] * Wup[ci][co][j]
           GemmParams g = fh_gemm_params();
-          g.X = fh_operand(x.W<float>(p.dwm) + (long)j * P * D, FH_R_CONTIG, D);
+          g.X = fh_operand(dwm_c + (long)j * P * D * p.es, FH_R_CONTIG, D);
           g.X.gstride = fP * D;
-          g.Y = fh_operand(wupf + (long)j * D * D, FH_R_CONTIG, D);
+          g.Y = fh_operand(wupc + (long)j * D * D * p.es, FH_R_CONTIG, D);
           g.Y.gstride = p.wl.head_wup_stride;
           g.C = grads + hp0 + p.pl.h_lin_w;
           g.M = P; g.N = D; g.Kseg = D; g.ldc = D;
           g.c_gstride = p.pl.head_stride;
           g.groups = Lh;
           g.ep.atomic = 1;
-          RC(fh_gemm_launch(g, 0, hs));
+          RC(fh_gemm_launch(g, dt, hs));
         }
         {  // dWup[ci][co][j] += sum_p dWm[j][p][ci] * Wlin[p][co]
           GemmParams g = fh_gemm_params();
-          g.X = fh_operand(x.W<float>(p.dwm) + (long)j * P * D, FH_R_STRIDED, D);
+          g.X = fh_operand(dwm_c + (long)j * P * D * p.es, FH_R_STRIDED, D);
           g.X.gstride = fP * D;
-          g.Y = fh_operand(x.params + hp0 + p.pl.h_lin_w, FH_R_STRIDED, D);
+          g.Y = fh_operand(x.nat(hp0 + p.pl.h_lin_w), FH_R_STRIDED, D);
           g.Y.gstride = p.pl.head_stride;
           g.C = grads + hp0 + p.pl.h_up_w + j;
           g.M = D; g.N = D; g.Kseg = P; g.ldc = (long)D * s.f;
@@ -1002,7 +1005,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
           g.ep.atomic = 1;
           g.ep.idiv = 1; g.ep.si1 = (long)D * s.f; g.ep.si0 = 0;
           g.ep.jdiv = 1; g.ep.sj1 = s.f; g.ep.sj0 = 0;
-          RC(fh_gemm_launch(g, 0, hs));
+          RC(fh_gemm_launch(g, dt, hs));
         }
       }
       hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(Lh, (D + 15) / 16), dim3(256), 0, hs, x.params, grads, hp0, p.pl.head_stride, p.pl.h_lin_w,

@@ -59,7 +59,7 @@ int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const
 // ---- elementwise.hip
 int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t st);
 int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int d1, int d2, int p0, int p1, int p2,
-                            hipStream_t st);
+                            hipStream_t st, int groups = 1, long src_gstride = 0, long dst_gstride = 0);  // strides in elements
 int fh_adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                     float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, hipStream_t st);
 int fh_unary_launch(int dtype, const void* src, void* dst, long n, int mode, hipStream_t st);  // 0: dst = gelu(src), 1: dst += src
