@@ -614,3 +614,57 @@ def test_fused_layer_kernels_equal_the_unfused_path(padded, training):
         assert e < 6e-3, (n, e)
     if training:
         assert _rel_l2(res[1][1], res[0][1]) < 2e-2
+
+
+@pytest.mark.parametrize("variant", ["fithubert", "heads_off", "ex_split_head", "frozen_extractor"])
+def test_backward_notify_segments_tile_the_gradient_buffer(variant):
+    """fh_student_backward_notify: the ranges it reports (projection heads first, transformer layers next, the encoder front last)
+    tile the flat gradient buffer exactly once in every configuration -- layer-wise heads, heads disabled (d_hidden entry), the
+    DistilHuBERT-style split head, a frozen extractor (early return) --, each range is final when it is reported (the callback
+    snapshots it on a stream the library has ordered behind the producing kernels), and the gradients equal the plain backward's."""
+    name = "ex.yaml" if variant == "ex_split_head" else "fithubert.yaml"
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", name)))["distiller"]
+    cfg = dict(cfg, encoder_layers=2, init_conv_layers=False, init_encoder_layers=0)
+    if variant == "frozen_extractor":
+        cfg["feature_grad_mult"] = 0.0
+    eng, _ = _engine(cfg, 3, "bf16")
+    heads_on = variant != "heads_off"
+    wav = (0.3 * torch.randn(3, 24000, generator=torch.Generator().manual_seed(1))).to(DEV)
+    comm = torch.cuda.Stream()
+
+    def run(notify):
+        eng.grads.zero_()
+        ws = eng.forward(wav, None, training=True, heads_on=heads_on, seed=4)
+        g = torch.Generator().manual_seed(2)
+        kw = {}
+        if heads_on:
+            kw["d_pred"] = (1e-2 * torch.randn(ws.view("pred").shape, generator=g)).to(DEV).to(eng.elem)
+        else:
+            kw["d_hidden"] = (1e-2 * torch.randn(ws.view("xo")[1:].shape, generator=g)).to(DEV).to(eng.elem).contiguous()
+        segs, snaps = [], []
+        if notify:
+            def on_segment(seg, first, count):
+                segs.append((seg, first, count))
+                with torch.cuda.stream(comm):          # ordered (device side) behind the kernels that write the range
+                    snaps.append(eng.grads[first:first + count].clone())
+            eng.backward(ws, on_segment=on_segment, comm_stream=comm.cuda_stream, **kw)
+        else:
+            eng.backward(ws, **kw)
+        torch.cuda.synchronize()
+        return segs, snaps, eng.grads.clone()
+
+    _, _, plain = run(False)
+    segs, snaps, got = run(True)
+    assert _rel_l2(got, plain) < 1e-4                   # fp32 atomics: order-dependent rounding only
+    pos = 0
+    for _, first, count in sorted(segs, key=lambda t: t[1]):
+        assert first == pos and count > 0, segs
+        pos = first + count
+    assert pos == eng.n_params, segs
+    assert [s for s, _, _ in segs] == sorted(s for s, _, _ in segs)      # segment ids in completion order
+    if heads_on:
+        views = eng.param_views(torch.arange(eng.n_params))
+        head_first = min(int(v.reshape(-1)[0]) for k, v in views.items() if k.startswith("proj_head."))
+        assert segs[0][1] == head_first, segs                            # the heads' range is reported first
+    for (_, first, count), snap in zip(segs, snaps):
+        assert torch.equal(snap, got[first:first + count]), (first, count)   # final at the time it was reported
