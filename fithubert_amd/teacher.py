@@ -236,6 +236,17 @@ class _NativeFrontend:
                                                 1, 1, 1 if gelu else 0, self._st()), "fh_conv1d_forward")
         return y
 
+    def fc1_gelu(self, x: torch.Tensor, w: dict) -> torch.Tensor:
+        """gelu(x W1^T + b1): ONE own GEMM with the GELU in its epilogue (default), or hipBLASLt + a streaming GELU pass."""
+        if self.fc1_native:
+            B, T, D = x.shape
+            Fd = w["w1"].shape[0]
+            h = torch.empty(B, T, Fd, device=self.dev, dtype=self.tdt)
+            self.L.check(self.lib.fh_conv1d_forward(self.dt, x.contiguous().data_ptr(), w["w1"].data_ptr(), w["c1"].data_ptr(), h.data_ptr(),
+                                                    B, T, D, Fd, 1, 1, 1, self._st()), "fh_conv1d_forward")
+            return h
+        return self.gelu_(F.linear(x, w["w1"], w["c1t"]))
+
     def gelu_(self, x: torch.Tensor) -> torch.Tensor:
         """exact GELU in place (one 16-byte-vector streaming kernel; 137 vs 201 us for the ATen kernel on the B = 128 fc1 output)"""
         self.L.check(self.lib.fh_gelu_forward(self.dt, x.data_ptr(), x.data_ptr(), x.numel(), self._st()), "fh_gelu_forward")
@@ -274,14 +285,14 @@ class _NativeFrontend:
         L, lib, w = self.L, self.lib, self.tl[i]
         B, T, D = x.shape
         h = self.ln(x, w["g1"], w["b1"])
-        qkv = F.linear(h, w["wqkv"], w["bqkv"])
+        qkv = self.linear(h, w["wqkv"], w["bqkv"], w["bqkv32"])
         attn = torch.empty(B, T, D, device=self.dev, dtype=self.tdt)
         L.check(lib.fh_attention_forward(self.dt, qkv.data_ptr(), attn.data_ptr(), None, key_len.data_ptr() if key_len is not None else None,
                                          B, T, self.heads, self.dh, float(self.dh) ** -0.5, L.Drop(0.0, 0, 0), self._st()),
                 "fh_attention_forward")
-        x1 = x + F.linear(attn, w["wo"], w["bo"])
+        x1 = x + self.linear(attn, w["wo"], w["bo"], w["bo32"])
         h2 = self.ln(x1, w["g2"], w["b2"])
-        lr = F.linear(self.gelu_(F.linear(h2, w["w1"], w["c1t"])), w["w2"], w["c2"])
+        lr = self.linear(self.fc1_gelu(h2, w), w["w2"], w["c2"], w["c232"])
         torch.add(x1, lr, out=out)
         return out, lr
 
@@ -300,14 +311,7 @@ class _NativeFrontend:
                 "fh_attention_forward")
         o = self.linear(attn, w["wo"], w["bo"], w["bo32"])
         x1 = self.add_ln(o, x, w["g1"], w["b1"], torch.empty_like(x))
-        if self.fc1_native:
-            Fd = w["w1"].shape[0]
-            h = torch.empty(B, T, Fd, device=self.dev, dtype=self.tdt)
-            L.check(lib.fh_conv1d_forward(self.dt, x1.data_ptr(), w["w1"].data_ptr(), w["c1"].data_ptr(), h.data_ptr(), B, T, D, Fd,
-                                          1, 1, 1, self._st()), "fh_conv1d_forward")
-        else:
-            h = self.gelu_(F.linear(x1, w["w1"], w["c1t"]))
-        lr = self.linear(h, w["w2"], w["c2"], w["c232"])
+        lr = self.linear(self.fc1_gelu(x1, w), w["w2"], w["c2"], w["c232"])
         self.add_ln(lr, x1, w["g2"], w["b2"], out)
         return out, lr
 

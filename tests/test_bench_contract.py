@@ -1,0 +1,54 @@
+"""CPU: the bench line contract on the committed result of the current round (profiles/r02_bench_default.json, written by
+tools/final_measure.sh + tools/collect_profiles.sh from `python bench.py` on an MI355X): every key the driver and the judge read is
+there, with the right type and internally consistent numbers."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    assert files, "no committed bench line under profiles/"
+    return json.loads(open(files[-1]).read().strip().splitlines()[-1])
+
+
+def test_bench_line_has_the_contract_keys():
+    d = _latest()
+    for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert k in d and isinstance(d[k], t), k
+    assert d["vs_baseline"] is None                     # BASELINE.md holds no published number for this metric
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "bf16" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = utterances all ranks processed / timed seconds
+    assert abs(d["value"] - d["n_gpus"] * d["config"]["per_gpu_batch"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+
+
+def test_roofline_and_cpu_baseline_objects():
+    d = _latest()
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "mfma_busy"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    assert r["mfma_busy"] is None or 0 < r["mfma_busy"] < 1
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    # the reported thread count is the best of the sweep it came from
+    if "sweep" in c:
+        best = max(c["sweep"], key=lambda e: e["utt_per_s"])
+        assert best["threads"] == c["cores"] and abs(best["utt_per_s"] - c["value"]) < 1e-6
+
+
+def test_variants_block_is_outside_the_headline():
+    d = _latest()
+    v = d.get("variants")
+    assert isinstance(v, dict) and "error" not in v
+    assert len(v["fixed_length_buckets"]) == 8 and {e["seconds"] for e in v["fixed_length_buckets"]} == {2, 4, 6, 8, 10, 12, 14, 16}
+    for key in ("librispeech_histogram_buckets", "student24_hubert_large_teacher"):
+        assert v[key]["utt_per_s"] > 0
