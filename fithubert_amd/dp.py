@@ -29,8 +29,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # FH_DIST_BACKEND=gloo: CPU-staged collectives on device tensors (two ranks on ONE GPU, tests)
+            backend = os.environ.get("FH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

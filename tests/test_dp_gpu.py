@@ -79,3 +79,66 @@ def test_training_step_over_a_one_rank_rccl_group():
     if r.returncode != 0 or "DP_OK" not in r.stdout:
         tb = r.stderr[r.stderr.rfind("Traceback"):] if "Traceback" in r.stderr else r.stderr[-3000:]
         raise AssertionError("1-rank RCCL training step failed:\n" + r.stdout[-1500:] + "\n" + tb[-4000:])
+
+
+SCRIPT2 = r'''
+import os, sys, yaml, torch
+sys.path.insert(0, %r)
+rank = int(os.environ["RANK"])
+from fithubert_amd.dp import init_distributed, assert_replicas_equal
+r, w, _ = init_distributed()            # FH_DIST_BACKEND=gloo, LOCAL_RANK=0: both ranks share cuda:0
+assert (r, w) == (rank, 2)
+import torch.distributed as dist
+from fithubert_amd.distill import W2V2Distil
+from fithubert_amd.dataset import fixed_length_batch
+from fithubert_amd.teacher import TeacherConfig
+y = yaml.safe_load(open(os.path.join(%r, "conf", "fithubert.yaml")))
+y["distiller"].update(encoder_layers=2)
+y["train"].update(distil_random_layer=1, accumulate_grad_batches=2)
+tc = TeacherConfig.base("hubert"); tc.encoder_layers = 2
+task = W2V2Distil(y, dtype="bf16", device="cuda:0", teacher_cfg=tc, seed=7 * rank, teacher_native_frontend=True)   # different inits:
+assert task.rank == rank and task.sync.world == 2                                                                   # rank 0's weights win
+assert_replicas_equal(task.engine.params)
+task.configure_optimizers(num_training_steps=10)
+pool = [fixed_length_batch(2, 24000, seed=100 * rank + i, device="cuda:0") for i in range(5)]      # every rank its own shard
+seeds = []
+orig = task.engine.forward
+def fwd(x, lengths, **kw):
+    seeds.append(kw["seed"]); return orig(x, lengths, **kw)
+task.engine.forward = fwd
+vals = []
+for i in range(4):
+    out = task.training_step(pool[i], batch_idx=i, next_batch=pool[i + 1])
+    vals.append(out[-1].item())
+    if i %% 2 == 1:
+        assert task.sync.covered() and len(task.sync.launched) >= 3, task.sync.launched
+torch.cuda.synchronize()
+assert task.opt_step == 2 and all(v == v for v in vals), vals
+assert_replicas_equal(task.engine.params)          # identical updates from the averaged gradients
+gathered = [None, None]
+dist.all_gather_object(gathered, seeds)
+tune = {12345}                                               # the GEMM tuner's throw-away pass (StudentEngine.autotune)
+assert not (set(gathered[0]) - tune) & (set(gathered[1]) - tune), gathered     # per-rank dropout masks
+dist.barrier()
+dist.destroy_process_group()
+print("DP2_OK", rank, vals)
+''' % (ROOT, ROOT)
+
+
+def test_two_ranks_train_on_one_gpu_over_gloo():
+    """Two real ranks (two processes, two native engines) sharing the one GPU of the test box, collectives staged through
+    gloo: construction broadcast, gradient accumulation, the exchange launched segment by segment from inside the native
+    backward on the communication stream, AdamW on the averaged gradients -- replicas stay bit-identical, every rank draws its
+    own dropout masks.  (RCCL itself cannot put two ranks on one device; the RCCL leg is the 1-rank test above.)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=400) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        if p.returncode != 0 or "DP2_OK" not in so:
+            tb = se[se.rfind("Traceback"):] if "Traceback" in se else se[-3000:]
+            raise AssertionError(f"rank {rank} failed:\n" + so[-1500:] + "\n" + tb[-4000:])
