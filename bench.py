@@ -389,8 +389,8 @@ def main():
                                    ("VARIANT: fithubert.yaml student with %d layers + HuBERT-%s-shaped teacher (random init), fixed 10 s clips"
                                     % (cfg["distiller"]["encoder_layers"], "Large" if args.teacher == "large" else "Base")),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": SAMPLES_10S, "parallelism": f"dp{world}",
-                       "teacher": "bf16; " + ("conv frontend, pos-conv, attention, add+LayerNorm: HIP kernels shared with the student; "
-                                              "q|k|v / out-proj / fc1 / fc2 GEMMs: hipBLASLt via PyTorch-ROCm" if args.teacher_frontend == "native"
+                       "teacher": "bf16; " + ("conv frontend, pos-conv, attention, add+LayerNorm, fc1 + GELU: HIP kernels shared with the student; "
+                                              "q|k|v / out-proj / fc2 GEMMs: hipBLASLt via PyTorch-ROCm" if args.teacher_frontend == "native"
                                               else "stock PyTorch-ROCm (MIOpen convs, hipBLASLt, SDPA)"), "optimizer": "fused AdamW every step"},
             "step_tflops": None if variant else round(value * GF_STEP / 1e3, 1),
             "step_frac_of_mfma_peak": None if variant else round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
