@@ -40,6 +40,8 @@ LOOPS = {0: "gemm_kernel<bf16, {l}>", 1: "gemm_small_kernel<0>", 2: "gemm32_kern
 def kernel_name(slot: int) -> str:
     """fh_prof_collect slot -> the kernel's name as rocprofv3 prints it (anonymous namespace prefix dropped)."""
     loop, var = slot // 8, slot % 8
+    if loop == 1 and var < 4:
+        return "gemm_8ph_persistent_kernel<%s>" % LAYOUTS[var]
     if var < 4:
         return "gemm_kernel<float, %s>" % LAYOUTS[var]
     return LOOPS[loop].format(l=LAYOUTS[var - 4])

@@ -1585,20 +1585,18 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
   }
 };
 
+// one 256 x 256 output tile (logical tile lb, reduction split lblk.split of nsplit) of the 8-phase loop
 template <int XL, int YL>
-__global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char* lds, const LogicalBlock lblk, int nsplit, int g) {
   constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.z;
   const int tiles_j = (p.N + 255) / 256;
-  const LogicalBlock lblk = logical_block(p.splitk);
   const int lb = lblk.lb;
   const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
   const int i0 = ti * 256, j0 = tj * 256;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
   const int ntiles = tiles_per_seg * tile_nseg(p, j0);
-  const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int per_split = (ntiles + nsplit - 1) / nsplit;
   const int t0 = lblk.split * per_split;
   const int t1 = min(ntiles, t0 + per_split);
   if (t0 >= t1) return;
@@ -1725,6 +1723,24 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   }
 }
 
+template <int XL, int YL>
+__global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  gemm_8ph_tile<XL, YL>(p, lds, logical_block(p.splitk), (int)gridDim.y, (int)blockIdx.z);
+}
+// Persistent form (loop 8): one workgroup per CU walks the tiles w, w + G, w + 2 G, ... (G = grid size, a multiple of 8, so a
+// workgroup's tiles keep their XCD class and the column tiles of a row tile stay on one XCD's L2 as in the one-tile form).  What it
+// saves is the per-tile workgroup turnover -- drain of the stores, release of 128 KiB of LDS, dispatch, argument loads -- on launches
+// whose tiles are short (K = 480: a tile is ~40 K cycles).  No reduction splits.
+template <int XL, int YL>
+__global__ void __launch_bounds__(512) gemm_8ph_persistent_kernel(const GemmParams p, int total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    gemm_8ph_tile<XL, YL>(p, lds, LogicalBlock{xcd_remap(t, total), 0}, 1, (int)blockIdx.z);
+    __syncthreads();   // the staging reads of this tile's epilogue are done before the next tile's LDS-DMA lands
+  }
+}
+
 int launch_8ph(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256;
   dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(512);
@@ -1746,6 +1762,38 @@ int launch_8ph(const GemmParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_8ph_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p);
   else
     hipLaunchKernelGGL((gemm_8ph_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_8ph_persistent(const GemmParams& p, hipStream_t stream) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -121;
+    ncu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount & ~7 : 8;
+  }
+  const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256, total = tiles_i * tiles_j;
+  dim3 grid(total < ncu ? total : ncu, 1, p.groups), block(512);
+  const size_t smem = 131072;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int xl = p.X.layout, yl = p.Y.layout;
+  if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p, total);
+  else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
+    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_STRIDED>), grid, block, smem, stream, p, total);
+  else if (xl == FH_R_STRIDED && yl == FH_R_CONTIG)
+    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p, total);
+  else
+    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p, total);
   FH_CHECK_LAUNCH();
   return 0;
 }
@@ -1796,7 +1844,7 @@ std::unordered_map<unsigned long long, TuneChoice> g_tune;
 void resolve_path() {
   if (g_gemm_path < 0) {
     const char* e = getenv("FH_GEMM_PATH");
-    g_gemm_path = !e ? 9 : ((e[0] == 'r' ? 0 : ((e[0] >= '1' && e[0] <= '7') ? e[0] - '0' : 9)));
+    g_gemm_path = !e ? 9 : ((e[0] == 'r' ? 0 : ((e[0] >= '1' && e[0] <= '8') ? e[0] - '0' : 9)));
   }
 }
 int launch_path(const GemmParams& p, int path, hipStream_t stream) {
@@ -1812,6 +1860,7 @@ int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   if (path == 5 && ring_ok(p, 32)) return launch_ring<256, 256, 2, 4, 32, 4>(p, stream);
   if (path == 6 && ring_ok(p, 32)) return launch_pp(p, stream);
   if (path == 7 && ring_ok(p, 64)) return launch_8ph(p, stream);
+  if (path == 8 && ring_ok(p, 64) && (p.splitk & 0xffff) <= 1) { g_last_loop = 8; return launch_8ph_persistent(p, stream); }
   return launch_32(p, stream);
 }
 
@@ -1872,7 +1921,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
       if (small_ok(p) && (long)p.M * p.N * p.groups <= (long)8192 * 2048) add(1, p.splitk);  // few tiles: the one-trip small-M loop
       if (ring_ok(p, 64)) add(3, p.splitk);
       if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); add(6, p.splitk); }
-      if (ring_ok(p, 64)) add(7, p.splitk);
+      if (ring_ok(p, 64)) { add(7, p.splitk); add(8, p.splitk); }
     }
   }
   hipEvent_t a, b;
@@ -1970,7 +2019,7 @@ extern "C" int fh_prof_collect(double* ms /*[64]*/, double* flops /*[64]*/, long
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     if (tf)
       fprintf(tf, "%d %d %d %d %d %d %d %d %.4f\n", r.M, r.N, r.K, r.groups, (r.variant >> 1) & 1, r.variant & 1,
-              r.variant >> 3, r.splitk, t);
+              (r.variant >= 8 && r.variant < 12) ? 8 : r.variant >> 3, r.splitk, t);
     ms[r.variant] += t;
     flops[r.variant] += r.flops;
     launches[r.variant] += 1;
@@ -2010,7 +2059,11 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   r.M = p.M; r.N = p.N; r.K = p.Kseg * p.X.nseg; r.groups = p.groups; r.splitk = p.splitk;
   hipEventRecord(r.a, stream);
   const int rc = dtype == 0 ? launch_t<float>(p, stream) : launch_bf16(p, stream);
-  if (dtype != 0) { r.variant += 8 * (g_last_loop & 7); r.splitk = g_last_splitk; }
+  if (dtype != 0) {
+    // slot = loop * 8 + 4 + layouts; the persistent 8-phase loop (8) takes the otherwise unused slots 8 + layouts
+    r.variant = g_last_loop == 8 ? 8 + p.X.layout * 2 + p.Y.layout : r.variant + 8 * (g_last_loop & 7);
+    r.splitk = g_last_splitk;
+  }
   hipEventRecord(r.b, stream);
   g_prof.push_back(r);
   return rc;

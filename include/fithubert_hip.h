@@ -91,8 +91,9 @@ int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 /* bf16 main loop: 0 = 16x16x32 MFMA register staging (128x128 tile), 1 = small-M loop (64x64 tiles, the whole reduction extent in LDS
  * in one LDS-DMA trip; R_CONTIG x R_CONTIG), 2 = 32x32x16 MFMA register
  * staging (128x128), 3 / 4 / 5 = large-tile LDS-DMA rings (256x256 BK 64, 256x128 BK 32, 256x256 BK 32), 6 = 256x256 ping-pong
- * ring, 7 = 256x256 8-phase loop (R_CONTIG x R_CONTIG), 9 = per-shape choice (default), -1 = re-read env FH_GEMM_PATH
- * (reg | 1..7). */
+ * ring, 7 = 256x256 8-phase loop, 8 = the same as a persistent launch (one workgroup per CU walks the tiles), 9 = per-shape choice
+ * (default), -1 = re-read env FH_GEMM_PATH
+ * (reg | 1..8). */
 int fh_gemm_set_path(int path);
 /* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
  * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the

@@ -208,7 +208,7 @@ def test_gemm_groups_dropout_rowmask(dt):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("loop", [1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("loop", [1, 2, 3, 5, 6, 7, 8])
 @pytest.mark.parametrize("opts", ["plain", "bias_gelu", "bias_preact_gelu_drop", "aux_residual", "rowmask_drop",
                                   "gapped_aux_residual", "gapped_bias_preact_gelu_drop_rowmask"])
 def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
@@ -289,7 +289,7 @@ def test_gemm_epilogue_forms_agree_on_large_tiles(loop, opts):
 
 
 @pytest.mark.parametrize("dt,path", [(L.DT_F32, 9), (L.DT_BF16, 0), (L.DT_BF16, 1), (L.DT_BF16, 2), (L.DT_BF16, 3), (L.DT_BF16, 4),
-                                     (L.DT_BF16, 5), (L.DT_BF16, 6), (L.DT_BF16, 7)])
+                                     (L.DT_BF16, 5), (L.DT_BF16, 6), (L.DT_BF16, 7), (L.DT_BF16, 8)])
 @pytest.mark.parametrize("wt", [False, True])
 @pytest.mark.parametrize("cin,cout,T", [(256, 256, 399), (256, 256, 400), (512, 512, 263), (64, 128, 38)])
 def test_conv1d_k3s2_dgrad_as_one_gemm(dt, path, cin, cout, T, wt):
@@ -378,3 +378,49 @@ def test_small_m_loop_one_trip_reduction(M, N, K, nseg):
     assert not torch.isnan(got.float()).any()
     assert (got.double() - ref).abs().max().item() <= 2e-2 * scale
     assert (got.double() - base.double()).abs().max().item() <= 1e-2 * scale
+
+
+@pytest.mark.parametrize("opts", ["bias_preact_gelu", "residual"])
+def test_persistent_8_phase_loop_walks_more_tiles_than_cus(opts):
+    """Loop 8: one workgroup per CU walks tiles w, w + G, ...: 324 tiles of 256 x 256 (ragged last row tile) so that every workgroup
+    takes at least one second tile -- LDS reuse across tiles (staging of tile i vs LDS-DMA of tile i + 1), accumulator reset, the
+    wave-group stagger re-armed per tile -- against fp64 and the one-tile launch (loop 7), both epilogue forms."""
+    dev = "cuda"
+    torch.manual_seed(3)
+    M, N, K = 20480 + 37, 1024, 192
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+
+    def run(path):
+        L.lib().fh_gemm_set_path(path)
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        pre = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        d = L.GemmDesc()
+        d.X = L.operand(X.data_ptr(), 0, K)
+        d.Y = L.operand(W.data_ptr(), 0, K)
+        d.C = out.data_ptr()
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+        if opts == "residual":
+            d.ep = L.epilogue(bias=bias.data_ptr(), residual=res.data_ptr())
+        else:
+            d.ep = L.epilogue(bias=bias.data_ptr(), act=L.ACT_GELU, preact=pre.data_ptr())
+        _run(d, L.DT_BF16)
+        return out, pre
+
+    try:
+        got, pre = run(8)
+        base, pre7 = run(7)
+    finally:
+        L.lib().fh_gemm_set_path(9)
+    assert torch.equal(got, base)                                  # same arithmetic, tile by tile
+    z = X.double() @ W.double().t() + bias.double()
+    if opts == "residual":
+        ref = z + res.double()
+    else:
+        assert torch.equal(pre, pre7)
+        assert (pre.double() - z).abs().max().item() <= 2e-2 * z.abs().max().item()
+        ref = torch.nn.functional.gelu(z)
+    assert not torch.isnan(got.float()).any()
+    assert (got.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
