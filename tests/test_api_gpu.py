@@ -438,3 +438,46 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
     d = (b.engine.params - full[0][0]).abs().max().item()
     assert d <= max(4 * noise, 1e-6), (d, noise)
     assert abs(l5 - full[0][1]) <= max(4 * abs(full[0][1] - full[1][1]), 2e-3 * abs(full[0][1]))
+
+
+def test_three_training_steps_follow_the_oracle_trajectory():
+    """End to end against the CPU restatement of the reference's training step (oracle/train_step_ref.py: teacher forward,
+    student forward in train mode, calculate_loss, autograd backward, torch.optim.AdamW -- the stand-in for the unpinned s3prl
+    optimizer): the fp32 engine on the same weights / teacher / batches, dropout 0, constant learning rate.  The loss of every
+    step within 1e-4 (step k's loss sees k - 1 native optimizer steps) and the accumulated parameter update within 2 %."""
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig, build_teacher
+    from oracle import teacher_ref as T
+    from oracle.train_step_ref import CpuDistilStep
+
+    y = _cfg(encoder_layers=3, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    y["train"].update(distil_random_layer=2, accumulate_grad_batches=1)
+    tcfg = dict(T.BASE, encoder_layers=3)
+    cpu = CpuDistilStep(y, teacher_cfg=tcfg, seed=3)
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 3
+    teacher = build_teacher(tc, dtype=torch.float32, device=DEV, state_dict={k: v.clone() for k, v in cpu.teacher.items()})
+    task = W2V2Distil(y, dtype="float32", device=DEV, teacher=teacher, seed=0)
+    task.student_model.load_state_dict({k: v.detach().clone() for k, v in cpu.student.items()})
+    task.rand_l = list(cpu.rand_l)
+    task._set_loss_tables()
+    p0 = task.engine.params.clone()
+    c0 = {k: v.detach().clone() for k, v in cpu.student.items()}
+    g = torch.Generator().manual_seed(11)
+    batches = [0.3 * torch.randn(2, 16000, generator=g) for _ in range(3)]
+    pm = torch.zeros(2, 16000, dtype=torch.bool)
+    for i, x in enumerate(batches):
+        ref = cpu.step(x, pm)["loss"]
+        out = task.training_step({"x": x.to(DEV), "padding_mask": pm.to(DEV), "_lengths": [16000, 16000], "_any_pad": False}, batch_idx=i)
+        assert abs(out[-1].item() - ref) < 1e-4, (i, out[-1].item(), ref)
+    views = task.engine.param_views()
+    p0v = task.engine.param_views(p0)
+    num = den = 0.0
+    for k, v in cpu.student.items():
+        if k.startswith("upsampler."):
+            continue                                    # present in the state dict, never used (model.py:342-348)
+        d_ref = (v.detach() - c0[k]).double()
+        d_got = (views[k] - p0v[k]).double().cpu()
+        num += float((d_got - d_ref).pow(2).sum())
+        den += float(d_ref.pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
