@@ -493,7 +493,7 @@ class W2V2Distil:
     def load_checkpoint(self, path: str, strict: bool = True) -> int:
         """Restore a checkpoint written by ``save_checkpoint`` (or any Lightning-convention ``.ckpt`` of this student: then only the
         weights).  Returns the epoch stored in it."""
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        ck = torch.load(path, map_location="cpu", weights_only=True)   # tensors + plain containers only: nothing in it needs unpickling code
         sd = {k[len("student_model."):]: v for k, v in ck["state_dict"].items() if k.startswith("student_model.")}
         self.student_model.load_state_dict(sd, strict=strict)
         self.student_model.mark_params_updated()
