@@ -41,7 +41,7 @@ def kernel_name(slot: int) -> str:
     """fh_prof_collect slot -> the kernel's name as rocprofv3 prints it (anonymous namespace prefix dropped)."""
     loop, var = slot // 8, slot % 8
     if loop == 1 and var < 4:
-        return "gemm_8ph_persistent_kernel<%s>" % LAYOUTS[var]
+        return "gemm_8ph_stream_kernel<%s>" % LAYOUTS[var]
     if var < 4:
         return "gemm_kernel<float, %s>" % LAYOUTS[var]
     return LOOPS[loop].format(l=LAYOUTS[var - 4])

@@ -883,6 +883,16 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char*
                : "memory");
 }
 
+// the same with the destination as a wave-uniform LDS byte address (kept in an SGPR: no 64-bit generic pointer per destination)
+__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lptr_t)p)); }
+
 template <int LAYOUT, int ROWS, int BK_, int NW> struct RingLoader;
 
 template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_CONTIG, ROWS, BK_, NW> {
@@ -1444,7 +1454,7 @@ template <> struct QuarterLoader<FH_R_CONTIG> {  // 256 rows x 64 k, image = 16-
   // is_x: X operand (halves = upper / lower 64 rows of each of the 2 wave rows); else Y (halves = 32-column halves of 4 wave columns)
   __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid, bool is_x) {
     base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
-    wave = tid >> 6;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform values stay in SGPRs: the LDS destinations are scalar)
     const int lane = tid & 63, r = lane >> 2;
     kch = (lane & 3) ^ ((r >> 3) << 1);
     vmask = 0;
@@ -1484,12 +1494,16 @@ template <> struct QuarterLoader<FH_R_CONTIG> {  // 256 rows x 64 k, image = 16-
         step[h][ks] = 0;
       }
   }
-  __device__ __forceinline__ void issue_half(unsigned char* tile, int h) {
+  __device__ __forceinline__ void issue_half(unsigned tile, int h) {  // tile: LDS byte address of the operand's 32 KiB image
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      glds16(ptr[h][ks], tile + (rt[h] * 2 + ks) * 1024);
+      glds16(ptr[h][ks], tile + (unsigned)((rt[h] * 2 + ks) * 1024));
       ptr[h][ks] += step[h][ks];
     }
+  }
+  __device__ __forceinline__ void skip_half(int h) {  // the pointer advance of issue_half without the DMA
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) ptr[h][ks] += step[h][ks];
   }
   static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row0, int ks, int lane) {
     return RingLoader<FH_R_CONTIG, 256, 64, 8>::frag(tile, row0, ks, lane);
@@ -1513,7 +1527,7 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
   int rpb;
   __device__ __forceinline__ void init(const GemmOperand& o, int g, int idx0, int idx_limit, int tid, bool is_x) {
     base = reinterpret_cast<const bf16*>(o.p) + (long)g * o.gstride;
-    wave = tid >> 6;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     cvalid = 0;
     rpb = o.rpb > 0 ? o.rpb : 0x7fffffff;
@@ -1558,10 +1572,12 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
         tcur[h][u] = -1;
       }
   }
-  __device__ __forceinline__ void issue_half(unsigned char* tile, int h) {
+  __device__ __forceinline__ void issue_half(unsigned tile, int h) { step_half<true>(tile, h); }
+  __device__ __forceinline__ void skip_half(int h) { step_half<false>(0u, h); }
+  template <bool DMA> __device__ __forceinline__ void step_half(unsigned tile, int h) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      glds16(ptr[h][u], tile + dst[h][u]);
+      if (DMA) glds16(ptr[h][u], tile + (unsigned)dst[h][u]);
       const bool live = tcur[h][u] >= 0;
       const int tn = tcur[h][u] + 64;
       const bool w = live && tn >= rpb;  // requires rpb >= 64 (checked on the host)
@@ -1584,6 +1600,32 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
     return u.f;
   }
 };
+
+// phase building blocks of the 8-phase loops (they name acc, fa, fb, bx, by, xi0, yj0, lane of the enclosing function):
+// the DMA wait (this wave's own loads, RAW) goes BEFORE the barrier; the fragment reads are only waited for behind it, so
+// their latency overlaps the wait for the other wave group (the buffers they read are rewritten a whole K-tile later)
+#define FH_PHASE_TAIL(WAITSTR)                                   \
+  asm volatile(WAITSTR ::: "memory");                            \
+  __builtin_amdgcn_sched_barrier(0);                             \
+  __builtin_amdgcn_s_barrier();                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+  __builtin_amdgcn_sched_barrier(0);                             \
+  __builtin_amdgcn_s_setprio(1);
+#define FH_PHASE_MMA(MH, NH)                                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m)                       \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[(NH) * 2 + n][(MH) * 4 + m] =                                  \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][n], fa[ks][m], acc[(NH) * 2 + n][(MH) * 4 + m], 0, 0, 0);     \
+  __builtin_amdgcn_s_setprio(0);                                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);
+#define FH_READ_A(MH)                                                                                                  \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m) fa[ks][m] =           \
+      QuarterLoader<XL>::frag(bx, xi0 + (MH) * 64 + 16 * m, ks, lane);
+#define FH_READ_B(NH)                                                                                                  \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int n = 0; n < 2; ++n) fb[ks][n] =           \
+      QuarterLoader<YL>::frag(by, yj0 + (NH) * 32 + 16 * n, ks, lane);
+
 
 // one 256 x 256 output tile (logical tile lb, reduction split lblk.split of nsplit) of the 8-phase loop
 template <int XL, int YL>
@@ -1639,45 +1681,21 @@ __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char
     ++issued;
   };
   // prologue: tile 0 in need order; its last quarter may still be in flight when the loop starts
+  const unsigned lds0 = lds_addr_of(lds);
   advance();
-  lx.issue_half(lds, 0);
-  ly.issue_half(lds + XT, 0);
-  ly.issue_half(lds + XT, 1);
-  lx.issue_half(lds, 1);
+  lx.issue_half(lds0, 0);
+  ly.issue_half(lds0 + XT, 0);
+  ly.issue_half(lds0 + XT, 1);
+  lx.issue_half(lds0, 1);
   asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
   if (late) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   bf16x8 fa[2][4], fb[2][2];  // [ks][m-tile of the half], [ks][n-tile of the half]
-  // the DMA wait (this wave's own loads, RAW) goes BEFORE the barrier; the fragment reads are only waited for behind it, so
-  // their latency overlaps the wait for the other wave group (the buffers they read are rewritten a whole K-tile later)
-#define FH_PHASE_TAIL(WAITSTR)                                   \
-  asm volatile(WAITSTR ::: "memory");                            \
-  __builtin_amdgcn_sched_barrier(0);                             \
-  __builtin_amdgcn_s_barrier();                                  \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
-  __builtin_amdgcn_sched_barrier(0);                             \
-  __builtin_amdgcn_s_setprio(1);
-#define FH_PHASE_MMA(MH, NH)                                                                                          \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m)                       \
-      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[(NH) * 2 + n][(MH) * 4 + m] =                                  \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][n], fa[ks][m], acc[(NH) * 2 + n][(MH) * 4 + m], 0, 0, 0);     \
-  __builtin_amdgcn_s_setprio(0);                                                                                       \
-  __builtin_amdgcn_sched_barrier(0);                                                                                   \
-  __builtin_amdgcn_s_barrier();                                                                                        \
-  __builtin_amdgcn_sched_barrier(0);
-#define FH_READ_A(MH)                                                                                                  \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m) fa[ks][m] =           \
-      QuarterLoader<XL>::frag(bx, xi0 + (MH) * 64 + 16 * m, ks, lane);
-#define FH_READ_B(NH)                                                                                                  \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int n = 0; n < 2; ++n) fb[ks][n] =           \
-      QuarterLoader<YL>::frag(by, yj0 + (NH) * 32 + 16 * n, ks, lane);
-
   for (int it = 0; it < nt; ++it) {
     const unsigned char* bx = lds + (it & 1) * STAGE;
     const unsigned char* by = bx + XT;
-    unsigned char* wx = lds + ((it + 1) & 1) * STAGE;
-    unsigned char* wy = wx + XT;
+    const unsigned wx = lds0 + ((it + 1) & 1) * STAGE, wy = wx + XT;
     // phase 1: quadrant (mh0, nh0); next tile's A(mh0)
     FH_READ_B(0)
     FH_READ_A(0)
@@ -1701,10 +1719,6 @@ __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char
     FH_PHASE_TAIL("s_waitcnt vmcnt(2)")
     FH_PHASE_MMA(1, 0)
   }
-#undef FH_PHASE_TAIL
-#undef FH_PHASE_MMA
-#undef FH_READ_A
-#undef FH_READ_B
   if (!late) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned char* my = lds + wave * EPI_WAVE;
@@ -1728,16 +1742,281 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   gemm_8ph_tile<XL, YL>(p, lds, logical_block(p.splitk), (int)gridDim.y, (int)blockIdx.z);
 }
-// Persistent form (loop 8): one workgroup per CU walks the tiles w, w + G, w + 2 G, ... (G = grid size, a multiple of 8, so a
-// workgroup's tiles keep their XCD class and the column tiles of a row tile stay on one XCD's L2 as in the one-tile form).  What it
-// saves is the per-tile workgroup turnover -- drain of the stores, release of 128 KiB of LDS, dispatch, argument loads -- on launches
-// whose tiles are short (K = 480: a tile is ~40 K cycles).  No reduction splits.
+// ------------------------------------------------------------------ loop 8: the 8-phase loop as a STREAMING persistent launch
+// One workgroup per CU walks the tiles f, f + G, f + 2 G, ... (G = grid size, a multiple of 8, so a workgroup's tiles keep their XCD
+// class and the column tiles of a row tile stay on one XCD's L2 as in the one-tile form).  In-kernel stamps (s_memtime, K = 768
+// tiles) put the one-tile form's time outside the main loop at: first-load latency ~2.8 K cycles, and an epilogue that is
+// STORE-ISSUE bound -- a CU retires its 128 KiB of bf16 output at ~14 B / cycle (~9.4 K cycles, every wave blocked in its store
+// instructions, the other waves waiting for it at the next barrier), whatever else the epilogue does.  This form puts the next
+// tile's start-up UNDER that store phase:
+//   epilogue rows 0 - 63 (8 stores per wave)  |  next tile: loaders set up (VALU that runs while the store path drains), its bias
+//   row and its first TWO K-tiles issued by LDS-DMA into the tile buffers (dead since the main loop ended)  |  epilogue rows 64 - 127
+// so that the data lands while the second half of the stores is issued, and the next main loop starts on resident tiles:
+//   * vmcnt counts loads, stores and LDS-DMA in ONE in-order queue: `s_waitcnt vmcnt(n)` with n = the operations issued AFTER the
+//     piece waited for (K-tile 1's pieces, the second half's stores) retires it without waiting for those stores'
+//     acknowledgement (~2.5 us under load); the first half's stores are older, but ~4 us old by then;
+//   * the loop's own counted waits are younger than all stores: with two K-tiles resident its first iteration issues nothing and
+//     waits once (K-tile 1), and by the second iteration's first counted wait the stores have been acknowledged;
+//   * nothing the compiler can see may be a vector-memory LOAD between the LDS-DMA and the stores (it would be waited for with
+//     a count that ignores the asm-issued DMA, i.e. drain them): the bias row comes in by LDS-DMA as well (256 B per wave into a
+//     stash next to the staging rows), every other epilogue operand is a kernel argument (scalar loads); the kernels must not
+//     spill (scratch accesses are vector memory) -- hence ONE set of loaders, set up when half the accumulators are dead.
+// The epilogue is the bf16-staged form (epilogue_bf16) in 16-row passes, staged in the 32 KiB of LDS above the two tile buffers
+// (8 waves x (16 rows x 144 B + 256 B bias stash)); launches whose epilogue needs per-row operands, fp32 / atomic output or a
+// reduction split are not offered this loop (stream_ok); a row tile cut by M masks its stores and drains them before the next tile
+// (an instruction without an active lane may be branched over, so their number is not known).
+constexpr int EPS_WAVE = 16 * EPB_ROW + 256;
+__device__ __forceinline__ void glds4(const float* gsrc, unsigned dst) {  // 64 lanes x 4 B -> 256 contiguous bytes at LDS address dst
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+// waits until at most n (wave-uniform: 8 or 16 stores, 8 prefetch pieces, their sums; anything else drains) of this wave's
+// vector-memory operations are pending
+__device__ __forceinline__ void wait_vm_upto(int n) {
+  switch (__builtin_amdgcn_readfirstlane(n)) {
+#define FH_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    FH_W(8) FH_W(16) FH_W(24)
+#undef FH_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+// m-tiles M0 .. M1 - 1 (16 rows each) of this wave's 128 x 64 block: bias / GELU / dropout in the accumulator layout, staged as
+// bf16 sixteen rows at a time.  Returns the number of store INSTRUCTIONS issued when that is known exactly (wave-uniform: 0 when
+// the wave's 64 columns lie beyond N, 2 -- 4 with a pre-activation copy -- per m-tile for a block whose rows are all inside M:
+// every instruction then has an active lane), -1 for a block cut by M (rows past M are masked out, and an instruction without
+// active lanes may be branched over).
+template <int M0, int M1, bool PRE, bool GELU, bool DROP, typename AccT>
+__device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const AccT& acc, const float (&b4)[4][4], unsigned char* my, int i0,
+                                                   int j0, int xi0, int yj0, int lane, int g) {
+  const GemmEpilogue& ep = p.ep;
+  const int r = lane & 15, q = lane >> 4;
+  const int jr = j0 + yj0 + 8 * (lane & 7);
+  const bool jrv = jr < p.N;
+  if (!__builtin_amdgcn_readfirstlane(j0 + yj0 < p.N && i0 + xi0 < p.M)) return 0;
+  const bool full = __builtin_amdgcn_readfirstlane(i0 + xi0 + 128 <= p.M);
+  const long rstep = 8L * p.ldc;
+  const unsigned char* lp = my + (lane >> 3) * EPB_ROW + (lane & 7) * 16;
+  unsigned char* wp = my + r * EPB_ROW + 8 * q;
+#pragma unroll
+  for (int m = M0; m < M1; ++m) {
+    const int row = i0 + xi0 + 16 * m + (lane >> 3);
+    const long base = (long)g * p.c_gstride + (long)row * p.ldc + jr;
+    const bool sv0 = jrv && (full || row < p.M), sv1 = jrv && (full || row + 8 < p.M);
+    float v[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[n][e] = fmaf(acc[n][m][e], ep.alpha, b4[n][e]);
+    if (PRE) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        uint2 pk;
+        pk.x = bf16_bits(v[n][0]) | (bf16_bits(v[n][1]) << 16);
+        pk.y = bf16_bits(v[n][2]) | (bf16_bits(v[n][3]) << 16);
+        *reinterpret_cast<uint2*>(wp + n * 32) = pk;
+      }
+      const V16 t0 = ld16(lp), t1 = ld16(lp + 8 * EPB_ROW);
+      if (sv0) st16(reinterpret_cast<bf16*>(ep.preact) + base, t0);
+      if (sv1) st16(reinterpret_cast<bf16*>(ep.preact) + base + rstep, t1);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      if (GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[n][e] = gelu_fast_f(v[n][e]);
+      }
+      if (DROP) {
+        const unsigned long long didx = ((unsigned long long)g * p.M + (i0 + xi0 + 16 * m + r)) * (unsigned long long)p.N +
+                                        (j0 + yj0 + 16 * n + 4 * q);
+        drop_scale_vec<4>(ep.drop, didx, v[n]);
+      }
+      uint2 pk;
+      pk.x = bf16_bits(v[n][0]) | (bf16_bits(v[n][1]) << 16);
+      pk.y = bf16_bits(v[n][2]) | (bf16_bits(v[n][3]) << 16);
+      *reinterpret_cast<uint2*>(wp + n * 32) = pk;
+    }
+    const V16 t0 = ld16(lp), t1 = ld16(lp + 8 * EPB_ROW);
+    if (sv0) st16(reinterpret_cast<bf16*>(p.C) + base, t0);
+    if (sv1) st16(reinterpret_cast<bf16*>(p.C) + base + rstep, t1);
+  }
+  return full ? (M1 - M0) * (PRE ? 4 : 2) : -1;
+}
+// the option tests hoisted out of the unrolled passes: each instance is straight-line code the scheduler can overlap across passes
+template <int M0, int M1, typename AccT>
+__device__ __forceinline__ int epilogue_stream16(const GemmParams& p, const AccT& acc, const float (&b4)[4][4], unsigned char* my, int i0,
+                                                 int j0, int xi0, int yj0, int lane, int g) {
+  const int opt = (p.ep.preact ? 4 : 0) | (p.ep.act == FH_ACT_GELU ? 2 : 0) | (p.ep.drop.p > 0.f ? 1 : 0);
+  switch (__builtin_amdgcn_readfirstlane(opt)) {
+#define FH_E(O) case O: return epilogue_stream16_t<M0, M1, ((O) & 4) != 0, ((O) & 2) != 0, ((O) & 1) != 0>(p, acc, b4, my, i0, j0, xi0, yj0, lane, g);
+    FH_E(1) FH_E(2) FH_E(3) FH_E(4) FH_E(5) FH_E(6) FH_E(7)
+#undef FH_E
+    default: return epilogue_stream16_t<M0, M1, false, false, false>(p, acc, b4, my, i0, j0, xi0, yj0, lane, g);
+  }
+}
+
 template <int XL, int YL>
-__global__ void __launch_bounds__(512) gemm_8ph_persistent_kernel(const GemmParams p, int total) {
+__global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p, int tiles, int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  for (int t = blockIdx.x; t < total; t += gridDim.x) {
-    gemm_8ph_tile<XL, YL>(p, lds, LogicalBlock{xcd_remap(t, total), 0}, 1, (int)blockIdx.z);
-    __syncthreads();   // the staging reads of this tile's epilogue are done before the next tile's LDS-DMA lands
+  constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool late = wave >= 4;
+  const int tiles_j = (p.N + 255) / 256;
+  const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
+  const int xi0 = (wave >> 2) * 128, yj0 = (wave & 3) * 64;
+  const unsigned lds0 = lds_addr_of(lds);
+  unsigned char* my = lds + 2 * STAGE + wave * EPS_WAVE;
+  const float* stash = reinterpret_cast<const float*>(my + 16 * EPB_ROW);
+  const unsigned stash_lds = lds0 + 2 * STAGE + wave * EPS_WAVE + 16 * EPB_ROW;
+  const bool has_bias = p.ep.bias != nullptr;
+
+  QuarterLoader<XL> lx;
+  QuarterLoader<YL> ly;
+  int i0 = 0, j0 = 0, g = 0, nt = 0;
+  int is_seg = 0, is_k0 = 0, issued = 0;
+  bool need_slow = true;
+  auto advance = [&]() {
+    if (issued == nt) {
+      lx.set_zero();
+      ly.set_zero();
+    } else if (issued < nt) {
+      const bool partial = is_k0 + BK_ > p.Kseg;
+      if (need_slow || partial) {
+        lx.set_tile(p.X, is_seg, is_k0, p.Kseg);
+        ly.set_tile(p.Y, is_seg, is_k0, p.Kseg);
+      }
+      is_k0 += BK_;
+      need_slow = false;
+      if (is_k0 >= p.Kseg) {
+        is_k0 = 0;
+        is_seg = min(is_seg + 1, 1);
+        need_slow = true;
+      }
+    }
+    ++issued;
+  };
+  // tile f becomes the current tile: loaders set up, its bias row and its first two K-tiles issued (1 + 8 + 8 pieces at most,
+  // oldest first; the quarters of a K-tile in the order the phases need them)
+  auto start_tile = [&](int f) {
+    g = f / tiles;
+    const int lb = xcd_remap(f - g * tiles, tiles);
+    const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
+    i0 = ti * 256;
+    j0 = tj * 256;
+    nt = tiles_per_seg * tile_nseg(p, j0);
+    if (has_bias) {
+      const int j = j0 + yj0 + lane;
+      const float* bp = j < p.N ? p.ep.bias + (long)g * p.ep.bias_gstride + (p.ep.bias_mod > 0 ? (j % p.ep.bias_mod) : j)
+                                : reinterpret_cast<const float*>(g_zero_chunk);
+      glds4(bp, stash_lds);
+    }
+    lx.init(p.X, g, i0, p.M, tid, true);
+    ly.init(p.Y, g, j0, p.N, tid, false);
+    is_seg = 0;
+    is_k0 = 0;
+    issued = 0;
+    need_slow = true;
+    for (int k = 0; k < (nt > 1 ? 2 : 1); ++k) {
+      const unsigned b = lds0 + k * STAGE;
+      advance();
+      lx.issue_half(b, 0);
+      ly.issue_half(b + XT, 0);
+      ly.issue_half(b + XT, 1);
+      lx.issue_half(b, 1);
+    }
+  };
+
+  int f = blockIdx.x;
+  if (f >= total) return;
+  start_tile(f);
+  int younger = 0;  // vector-memory operations this wave issued AFTER the last prefetch piece (stores of the previous tile's second half); < 0: drain
+  f32x4 acc[4][8];  // [n][m]
+  bf16x8 fa[2][4], fb[2][2];
+  for (;;) {
+    // K-tile 0 (and the bias row) landed in every wave; K-tile 1 may still be in flight
+    wait_vm_upto(younger < 0 ? 0 : younger + (nt > 1 ? 8 : 0));
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {  // iteration 0: both K-tiles are resident or on their way, nothing to issue, one wait (K-tile 1) at the end
+      const unsigned char* bx = lds;
+      const unsigned char* by = bx + XT;
+      FH_READ_B(0)
+      FH_READ_A(0)
+      FH_PHASE_TAIL("")
+      FH_PHASE_MMA(0, 0)
+      FH_READ_B(1)
+      FH_PHASE_TAIL("")
+      FH_PHASE_MMA(0, 1)
+      FH_READ_A(1)
+      FH_PHASE_TAIL("")
+      FH_PHASE_MMA(1, 1)
+      FH_READ_B(0)
+      wait_vm_upto(younger < 0 ? 0 : younger);
+      FH_PHASE_TAIL("")
+      FH_PHASE_MMA(1, 0)
+    }
+    for (int it = 1; it < nt; ++it) {
+      const unsigned char* bx = lds + (it & 1) * STAGE;
+      const unsigned char* by = bx + XT;
+      const unsigned wx = lds0 + ((it + 1) & 1) * STAGE, wy = wx + XT;
+      FH_READ_B(0)
+      FH_READ_A(0)
+      advance();
+      lx.issue_half(wx, 0);
+      FH_PHASE_TAIL("")
+      FH_PHASE_MMA(0, 0)
+      FH_READ_B(1)
+      ly.issue_half(wy, 0);
+      FH_PHASE_TAIL("s_waitcnt vmcnt(4)")
+      FH_PHASE_MMA(0, 1)
+      FH_READ_A(1)
+      ly.issue_half(wy, 1);
+      FH_PHASE_TAIL("")
+      FH_PHASE_MMA(1, 1)
+      FH_READ_B(0)
+      lx.issue_half(wx, 1);
+      FH_PHASE_TAIL("s_waitcnt vmcnt(2)")
+      FH_PHASE_MMA(1, 0)
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // both tile buffers are dead in every wave from here on
+    const int fn = f + (int)gridDim.x;
+    const bool has_next = fn < total;
+    const int ci0 = i0, cj0 = j0, cg = g;
+    float b4[4][4];
+    {
+      const int q = lane >> 4;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (has_bias) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(stash + 16 * n + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b4[n][e] = t[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b4[n][e] = 0.f;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stash is rewritten by the next tile's bias piece
+    __builtin_amdgcn_sched_barrier(0);
+    const int n1 = epilogue_stream16<0, 4>(p, acc, b4, my, ci0, cj0, xi0, yj0, lane, cg);
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) start_tile(fn);
+    __builtin_amdgcn_sched_barrier(0);
+    const int n2 = epilogue_stream16<4, 8>(p, acc, b4, my, ci0, cj0, xi0, yj0, lane, cg);
+    __builtin_amdgcn_sched_barrier(0);
+    younger = (n1 < 0 || n2 < 0) ? -1 : n2;
+    if (!has_next) break;
+    f = fn;
   }
 }
 
@@ -1766,7 +2045,13 @@ int launch_8ph(const GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
-int launch_8ph_persistent(const GemmParams& p, hipStream_t stream) {
+// launches loop 8 can take: the bf16-staged epilogue without per-row operands, one reduction split
+bool stream_ok(const GemmParams& p) {
+  const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
+  return !p.ep.atomic && !p.ep.gelu_aux && !p.ep.residual && !p.ep.row_len && !p.ep.out_f32 && !p.ep.tail_cols &&
+         (p.c_rpb <= 0 || wrap0 == 0) && (p.splitk & 0xffff) <= 1;
+}
+int launch_8ph_stream(const GemmParams& p, hipStream_t stream) {
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -1774,26 +2059,28 @@ int launch_8ph_persistent(const GemmParams& p, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -121;
     ncu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount & ~7 : 8;
   }
-  const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256, total = tiles_i * tiles_j;
-  dim3 grid(total < ncu ? total : ncu, 1, p.groups), block(512);
-  const size_t smem = 131072;
+  const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256, tiles = tiles_i * tiles_j;
+  const long total = (long)tiles * p.groups;
+  if (total > 0x7fffffffL) return -122;
+  dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1), block(512);
+  const size_t smem = 131072 + 8 * EPS_WAVE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int xl = p.X.layout, yl = p.Y.layout;
   if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
-    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p, total);
+    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p, tiles, (int)total);
   else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
-    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_CONTIG, FH_R_STRIDED>), grid, block, smem, stream, p, total);
+    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_STRIDED>), grid, block, smem, stream, p, tiles, (int)total);
   else if (xl == FH_R_STRIDED && yl == FH_R_CONTIG)
-    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p, total);
+    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p, tiles, (int)total);
   else
-    hipLaunchKernelGGL((gemm_8ph_persistent_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p, total);
+    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p, tiles, (int)total);
   FH_CHECK_LAUNCH();
   return 0;
 }
@@ -1860,7 +2147,7 @@ int launch_path(const GemmParams& p, int path, hipStream_t stream) {
   if (path == 5 && ring_ok(p, 32)) return launch_ring<256, 256, 2, 4, 32, 4>(p, stream);
   if (path == 6 && ring_ok(p, 32)) return launch_pp(p, stream);
   if (path == 7 && ring_ok(p, 64)) return launch_8ph(p, stream);
-  if (path == 8 && ring_ok(p, 64) && (p.splitk & 0xffff) <= 1) { g_last_loop = 8; return launch_8ph_persistent(p, stream); }
+  if (path == 8 && ring_ok(p, 64) && stream_ok(p)) { g_last_loop = 8; return launch_8ph_stream(p, stream); }
   return launch_32(p, stream);
 }
 
@@ -1907,12 +2194,18 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
       const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
       // the atomic epilogue costs ~9 us per extra split of a 12 x 480 x 480 gradient (tools/gemm_wgrad_sweep.py): fewer workgroups
       // than CUs can win, so the candidates start below one wave of workgroups
+      // both roundings of target / tiles: rounding up alone puts e.g. 3 tiles x 86 splits = 258 workgroups on 256 CUs (two
+      // rounds for the last two workgroups); 3 x 85 fills one round
       for (int target : {64, 128, 192, 256, 512}) {
-        const int sk = ring_splitk(p, 256, 256, target);
-        for (int remap : {0, FH_SPLIT_REMAP}) {
-          if (remap && (sk < 2 || tiles256 < 2)) continue;  // nothing to co-locate
-          if (ring_ok(p, 64)) { add(3, sk | remap); add(7, sk | remap); }
-          if (ring_ok(p, 32)) add(5, sk | remap);
+        const int sk_up = ring_splitk(p, 256, 256, target);
+        long sk_dn = target / (tiles256 * p.groups);
+        if (sk_dn > sk_up) sk_dn = sk_up;   // ring_splitk's caps (reduction length, 256)
+        for (int sk : {sk_up, (int)(sk_dn < 1 ? 1 : sk_dn)}) {
+          for (int remap : {0, FH_SPLIT_REMAP}) {
+            if (remap && (sk < 2 || tiles256 < 2)) continue;  // nothing to co-locate
+            if (ring_ok(p, 64)) { add(3, sk | remap); add(7, sk | remap); }
+            if (ring_ok(p, 32)) add(5, sk | remap);
+          }
         }
       }
       add(2, ring_splitk(p, 128, 128, 1024));
@@ -1921,7 +2214,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
       if (small_ok(p) && (long)p.M * p.N * p.groups <= (long)8192 * 2048) add(1, p.splitk);  // few tiles: the one-trip small-M loop
       if (ring_ok(p, 64)) add(3, p.splitk);
       if (ring_ok(p, 32)) { add(4, p.splitk); add(5, p.splitk); add(6, p.splitk); }
-      if (ring_ok(p, 64)) { add(7, p.splitk); add(8, p.splitk); }
+      if (ring_ok(p, 64)) { add(7, p.splitk); if (stream_ok(p)) add(8, p.splitk); }
     }
   }
   hipEvent_t a, b;
@@ -1974,6 +2267,7 @@ std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 bool g_prof_on = false;
 }  // namespace
 
+extern "C" int fh_gemm_last_loop(void) { return g_last_loop; }
 extern "C" int fh_gemm_set_path(int path) {
   g_gemm_path = path;
   return 0;

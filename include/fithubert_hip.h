@@ -91,10 +91,12 @@ int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 /* bf16 main loop: 0 = 16x16x32 MFMA register staging (128x128 tile), 1 = small-M loop (64x64 tiles, the whole reduction extent in LDS
  * in one LDS-DMA trip; R_CONTIG x R_CONTIG), 2 = 32x32x16 MFMA register
  * staging (128x128), 3 / 4 / 5 = large-tile LDS-DMA rings (256x256 BK 64, 256x128 BK 32, 256x256 BK 32), 6 = 256x256 ping-pong
- * ring, 7 = 256x256 8-phase loop, 8 = the same as a persistent launch (one workgroup per CU walks the tiles), 9 = per-shape choice
- * (default), -1 = re-read env FH_GEMM_PATH
- * (reg | 1..8). */
+ * ring, 7 = 256x256 8-phase loop, 8 = the same as a STREAMING persistent launch (one workgroup per CU walks the tiles and issues the
+ * next tile's first two K-tiles before the epilogue of the current one; launches with the bf16-staged epilogue only, others fall
+ * back to loop 2), 9 = per-shape choice (default), -1 = re-read env FH_GEMM_PATH (reg | 1..8). */
 int fh_gemm_set_path(int path);
+/* The main loop the last bf16 launch ran (fh_gemm_set_path numbering): what a forced or tuned path resolved to. */
+int fh_gemm_last_loop(void);
 /* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
  * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the
  * output several times -- only for throw-away passes (StudentEngine.autotune).  mode 0: stop measuring; unmeasured shapes

@@ -380,47 +380,65 @@ def test_small_m_loop_one_trip_reduction(M, N, K, nseg):
     assert (got.double() - base.double()).abs().max().item() <= 1e-2 * scale
 
 
-@pytest.mark.parametrize("opts", ["bias_preact_gelu", "residual"])
-def test_persistent_8_phase_loop_walks_more_tiles_than_cus(opts):
-    """Loop 8: one workgroup per CU walks tiles w, w + G, ...: 324 tiles of 256 x 256 (ragged last row tile) so that every workgroup
-    takes at least one second tile -- LDS reuse across tiles (staging of tile i vs LDS-DMA of tile i + 1), accumulator reset, the
-    wave-group stagger re-armed per tile -- against fp64 and the one-tile launch (loop 7), both epilogue forms."""
+@pytest.mark.parametrize("M,N,K,groups,opts", [
+    (20480 + 37, 1024, 192, 1, "bias_preact_gelu"),   # 324 tiles, ragged last row tile (its stores are masked and drained), 3 K-tiles
+    (70000, 480, 480, 1, "bias"),                      # ragged column tile (a wave whose 64 columns lie past N issues no store), K tail
+    (66000, 1440, 64, 1, "bias_gelu"),                 # ONE K-tile per output tile
+    (140000, 256, 128, 1, "bias_preact_gelu"),         # two K-tiles: the whole reduction is prefetched under the previous epilogue
+    (30000, 512, 256, 3, "bias_gelu_drop"),            # groups flattened into the tile walk; dropout indices
+    (66048, 768, 768, 1, "plain"),                     # no bias piece in the prefetch; M a multiple of 256
+    (300, 200, 96, 1, "bias_gelu"),                    # fewer tiles than CUs
+])
+def test_streaming_8_phase_loop(M, N, K, groups, opts):
+    """Loop 8: one workgroup per CU walks tiles f, f + G, ... and issues the next tile's first two K-tiles (and bias row) by LDS-DMA
+    before the epilogue of the current one; the waits are COUNTED against the epilogue's own stores (gemm.hip, loop 8).  A wrong
+    count reads a tile buffer before its data landed, so every case is compared bit for bit with the one-tile launch (loop 7, same
+    arithmetic per tile) and against fp64: many tiles per workgroup, ragged rows / columns, 1 / 2 / many K-tiles, with and without
+    the pre-activation copy (16 / 32 stores per wave), grouped launches."""
     dev = "cuda"
     torch.manual_seed(3)
-    M, N, K = 20480 + 37, 1024, 192
-    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
-    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
-    bias = torch.randn(N, device=dev)
-    res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    X = torch.randn(groups, M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(groups, N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(groups, N, device=dev)
 
     def run(path):
         L.lib().fh_gemm_set_path(path)
-        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
-        pre = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        out = torch.full((groups, M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        pre = torch.full((groups, M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         d = L.GemmDesc()
-        d.X = L.operand(X.data_ptr(), 0, K)
-        d.Y = L.operand(W.data_ptr(), 0, K)
+        d.X = L.operand(X.data_ptr(), 0, K, gstride=M * K)
+        d.Y = L.operand(W.data_ptr(), 0, K, gstride=N * K)
         d.C = out.data_ptr()
-        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
-        if opts == "residual":
-            d.ep = L.epilogue(bias=bias.data_ptr(), residual=res.data_ptr())
-        else:
-            d.ep = L.epilogue(bias=bias.data_ptr(), act=L.ACT_GELU, preact=pre.data_ptr())
-        _run(d, L.DT_BF16)
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, groups, 1
+        d.c_gstride = M * N
+        kw = {}
+        if "bias" in opts: kw.update(bias=bias.data_ptr(), bias_gstride=N)
+        if "gelu" in opts: kw["act"] = L.ACT_GELU
+        if "preact" in opts: kw["preact"] = pre.data_ptr()
+        if "drop" in opts: kw["drop"] = (0.25, 17, 3)
+        d.ep = L.epilogue(**kw)
+        for _ in range(3):   # back-to-back launches: a stale tile buffer of the previous launch must not matter either
+            _run(d, L.DT_BF16)
         return out, pre
 
     try:
         got, pre = run(8)
+        assert L.lib().fh_gemm_last_loop() == 8
         base, pre7 = run(7)
     finally:
         L.lib().fh_gemm_set_path(9)
+    assert not torch.isnan(got.float()).any()
     assert torch.equal(got, base)                                  # same arithmetic, tile by tile
-    z = X.double() @ W.double().t() + bias.double()
-    if opts == "residual":
-        ref = z + res.double()
-    else:
+    z = torch.bmm(X.double(), W.double().transpose(1, 2))
+    if "bias" in opts: z = z + bias.double()[:, None, :]
+    if "preact" in opts:
         assert torch.equal(pre, pre7)
         assert (pre.double() - z).abs().max().item() <= 2e-2 * z.abs().max().item()
-        ref = torch.nn.functional.gelu(z)
-    assert not torch.isnan(got.float()).any()
-    assert (got.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    ref = torch.nn.functional.gelu(z) if "gelu" in opts else z
+    keep = torch.ones_like(got, dtype=torch.bool)
+    if "drop" in opts:
+        keep = got != 0
+        assert abs(keep.double().mean().item() - 0.75) < 0.01
+        ref = ref / 0.75
+    assert ((got.double() - ref) * keep).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
