@@ -443,8 +443,8 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
 def test_three_training_steps_follow_the_oracle_trajectory():
     """End to end against the CPU restatement of the reference's training step (oracle/train_step_ref.py: teacher forward,
     student forward in train mode, calculate_loss, autograd backward, torch.optim.AdamW -- the stand-in for the unpinned s3prl
-    optimizer): the fp32 engine on the same weights / teacher / batches, dropout 0, constant learning rate.  The loss of every
-    step within 1e-4 (step k's loss sees k - 1 native optimizer steps) and the accumulated parameter update within 2 %."""
+    optimizer): the fp32 engine on the same weights / teacher / batches, dropout 0, constant learning rate.  The first loss within
+    1e-4, the later ones (step k's loss sees k native optimizer steps) within 1e-3 relative, the accumulated parameter update within 2 %."""
     from fithubert_amd.distill import W2V2Distil
     from fithubert_amd.teacher import TeacherConfig, build_teacher
     from oracle import teacher_ref as T
@@ -469,7 +469,11 @@ def test_three_training_steps_follow_the_oracle_trajectory():
     for i, x in enumerate(batches):
         ref = cpu.step(x, pm)["loss"]
         out = task.training_step({"x": x.to(DEV), "padding_mask": pm.to(DEV), "_lengths": [16000, 16000], "_any_pad": False}, batch_idx=i)
-        assert abs(out[-1].item() - ref) < 1e-4, (i, out[-1].item(), ref)
+        # step 0 is forward parity (1e-4).  From step 1 on the loss sees Adam updates, and Adam's first steps move EVERY parameter by
+        # ~lr in the direction of the gradient's sign -- parameters whose true gradient is zero (the key-projection bias: softmax is
+        # shift invariant) or below the fp32 atomics' summation-order noise move by +-lr at random, in the reference as much as here;
+        # run to run that is worth up to 4e-4 of the later losses on this model (same binary, same inputs), so they get 1e-3
+        assert abs(out[-1].item() - ref) < (1e-4 if i == 0 else 1e-3 * abs(ref)), (i, out[-1].item(), ref)
     views = task.engine.param_views()
     p0v = task.engine.param_views(p0)
     num = den = 0.0

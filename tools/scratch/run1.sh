@@ -1,3 +1,2 @@
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gemm_gpu.py -x -q -m gpu -k "streaming or epilogue_forms" 2>&1 | tail -3
-python tools/scratch/stream_bench.py 2>&1 | grep -v amdgpu.ids
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
