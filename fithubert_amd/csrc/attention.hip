@@ -4,15 +4,16 @@
 //   dropout on the probabilities) -- q scaled by head_dim^-0.5, scores = q k^T per head, masked_fill(-inf), fp32
 //   softmax, dropout, @ v.  (Third-party arithmetic; semantics pinned in oracle/student_ref.py::_mha.)
 //
-// Layout: qkv [B][T][3*D] (q | k | v, head h at columns h*dh..), out [B][T][D].  One workgroup = 128 queries of one
-// (batch, head); each wave owns 32 queries.  K/V tiles of 64 keys are staged in LDS.  Scores are computed TRANSPOSED
-// (S^T = K Q^T) so that a lane holds one query column: the softmax reductions are two wavefront shuffles, the
+// Layout: qkv [B][T][3*D] (q | k | v, head h at columns h*dh..), out [B][T][D].  One workgroup = 128 .. 512 queries of one
+// (batch, head); each wave owns 32 queries.  K/V tiles of 64 keys go through LDS (forward: streamed, double-buffered).  Scores are computed TRANSPOSED
+// (S^T = K Q^T) so that a lane holds one query column: the softmax reductions are two row exchanges (v_permlane16/32_swap), the
 // accumulator tiles of S^T are directly the B operand of the P.V product (no LDS round trip), and V^T / K^T come
 // from transposing LDS reads (ds_read_b64_tr_b16).  Head dim 40 is zero-padded to the MFMA K granularity in LDS only.
 // Backward recomputes P from the saved log-sum-exp.  bf16, T <= 256 (the 10 s student): ONE fused pass per (batch, head) -- the
 // dK/dV decomposition (wave owns keys) plus a dQ contraction through an LDS scratch, attn_bwd_fused_kernel.  Otherwise: a dQ pass
 // (the forward's decomposition) and a dK/dV pass.  These kernels are VALU-bound (exp2 + dropout hash per score), not MFMA-bound.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.cuh"
 #include "kernels.h"
@@ -122,6 +123,41 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const T* base, lo
     st16(lds + r * AT<T>::RS + c * 16, v);
   }
 }
+// Several 64-row tiles at once: every thread first issues ALL its 16-byte global loads (up to 4 per pass), then stores them.
+// One tile per stage_tile call meant one exposed global-load round trip per tile -- staged that way, the teacher's forward (T = 499:
+// 8 key + 8 value tiles) spent 34 K of its 87 K cycles per workgroup in 16 serialised round trips (s_memtime stamps).  The
+// backward kernels stage their resident tiles through this.
+// place(t, src, ld, dst, row0): tile t's source rows start at src + row0 * ld (head slice, d contiguous) and land at dst.
+template <typename T, typename F>
+__device__ __forceinline__ void stage_tiles(int ntiles, int nrows_valid, int dh, F&& place) {
+  constexpr int VEC = ElemTraits<T>::VEC, BATCH = 4;
+  const int cpr = dh / VEC, per_tile = 64 * cpr, total = ntiles * per_tile;
+  const float inv_pt = 1.0f / (float)per_tile, inv_cpr = 1.0f / (float)cpr;  // exact for these ranges: (i + 0.5) / n is >= 0.5 / n off an integer
+  for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * BATCH) {
+    V16 v[BATCH];
+    unsigned char* d[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int idx = i0 + j * (int)blockDim.x;
+      d[j] = nullptr;
+      v[j] = v16_zero();
+      if (idx < total) {
+        const int t = (int)(((float)idx + 0.5f) * inv_pt), rem = idx - t * per_tile;
+        const int r = (int)(((float)rem + 0.5f) * inv_cpr), c = rem - r * cpr;
+        const T* src;
+        long sld;
+        unsigned char* dst;
+        int row0;
+        place(t, src, sld, dst, row0);
+        d[j] = dst + r * AT<T>::RS + c * 16;
+        if (row0 + r < nrows_valid) v[j] = ld16(src + (long)(row0 + r) * sld + c * VEC);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j)
+      if (d[j]) st16(d[j], v[j]);
+  }
+}
 template <typename T> __device__ __forceinline__ void zero_lds(unsigned char* lds, int bytes) {
   for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16) st16(lds + i, v16_zero());
 }
@@ -133,22 +169,51 @@ __device__ __forceinline__ unsigned long long drop_row_pitch(int Tn) { return (u
 // v_exp_f32 without libm's denormal-range rescue (a compare, two selects and an ldexp per call): every exponent here is <= 0 up
 // to rounding and a probability below 2^-126 may flush to zero
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// butterfly over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48 hold one query's partials).  gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows between two registers in ONE VALU issue: with both operands = v the pair
+// comes back as (v of the even row | v of the odd row) in every lane of a row pair -- no ds_bpermute round trip through the LDS
+// pipe (8 per 64-key tile and wave in the forward's softmax).
+__device__ __forceinline__ void row_pairs16(float v, float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void row_pairs32(float v, float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float xor_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  float a, b;
+  row_pairs16(v, a, b);
+  v = fmaxf(a, b);
+  row_pairs32(v, a, b);
+  return fmaxf(a, b);
 }
 __device__ __forceinline__ float xor_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  float a, b;
+  row_pairs16(v, a, b);
+  v = a + b;
+  row_pairs32(v, a, b);
+  return a + b;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int NDT, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+// DROP is a template parameter and the key mask lives in a separate instance of the tile step: left as run-time tests both were
+// if-converted into the one loop body -- the teacher (no dropout, full tiles) executed the dropout hash (16 quarter-rate
+// v_mul_lo_u32 per tile and wave) and 32 compare / select pairs per tile for nothing: 249 VALU instructions per 64-key tile and
+// wave where the softmax itself needs ~100 (s_memtime: 1630 cycles per wave and tile against 512 of MFMA).
+template <typename T, int NDT, int NW, bool DROP>
+__global__ void __launch_bounds__(NW * 64, 4) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const int* __restrict__ key_len, int B,
-                                                       int Tn, int H, int dh, float scale_log2e, DropCfg drop, int resident) {
-  // resident != 0: ALL key/value tiles of this (batch, head) are staged once (T <= 512 bf16 / 320 fp32 fits the 160 KiB
-  // LDS) -- one global-load latency and one barrier per workgroup instead of one per 64-key tile.
+                                                       int Tn, int H, int dh, float scale_log2e, DropCfg drop) {
+  // K / V are STREAMED through two (K tile | V tile) buffers (36 KiB): every thread fetches its 16-byte pieces of tile k + 1 into
+  // registers right after the barrier of tile k, computes tile k, and stores them when it comes round -- the loads' latency and the
+  // HBM traffic sit under the softmax / MFMA work; one barrier per tile, any T.  (Round 1 staged ALL tiles of a (batch, head) up
+  // front for T <= 512: no barrier in the key loop, but s_memtime stamps showed 25 K of a workgroup's 70 K cycles at T = 499 in
+  // front of the loop -- 16 serialised load round trips, then, batched, an HBM-bound burst at ~11 B / cycle / CU with every CU
+  // staging at once -- and above T = 512 the old tiled path loaded synchronously.  Streamed: 255 -> 202 us per teacher layer
+  // together with the DROP / tail-mask instances below, and the long-utterance path no longer waits for every tile.)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PAIR = 2 * 64 * AT<T>::RS;
   constexpr int NK = AT<T>::NK;
@@ -162,8 +227,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
   // dropout keys of this (batch, head)'s Tn x Tn index range (Tn <= 65536: at most two high words)
   const DropKeySpan dspan = drop_key_span(drop, ((unsigned long long)b * H + h) * Tn * drop_row_pitch(Tn));
 
-  const int ntile = (klen + 63) / 64;
-  zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
+  zero_lds<T>(lds, 2 * PAIR);  // (columns dh .. 63 of the padded rows are never written again)
   frag qf[2][NK];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -171,14 +235,35 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) qf[qt][ks] = gfrag<T>(base + (long)query * ld, query < Tn, ks, lane, dh);
   }
-  if (resident) {
-    __syncthreads();
-    for (int kt = 0; kt < ntile; ++kt) {
-      stage_tile<T>(lds + kt * PAIR, base + D, ld, kt * 64, Tn, dh);
-      stage_tile<T>(lds + kt * PAIR + 64 * AT<T>::RS, base + 2 * D, ld, kt * 64, Tn, dh);
-    }
-    __syncthreads();
+  __syncthreads();
+  // this thread's pieces of one (K tile | V tile) pair -- piece i = row (i / cpr) % 64 of K (i < 64 cpr) or V
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int NPC = (2 * 64 * (64 / VEC) + NW * 64 - 1) / (NW * 64);  // pieces per thread at the widest head
+  const int cpr = dh / VEC, npiece = 2 * 64 * cpr;
+  V16 pre[NPC];
+  int prow[NPC], pdst[NPC];  // row inside the tile (-1: no piece), LDS byte offset inside the buffer
+  long psrc[NPC];            // element offset from `base` at tile 0
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int i = (int)threadIdx.x + j * NW * 64;
+    const int isv = i >= 64 * cpr, rem = i - isv * 64 * cpr, row = rem / cpr, c = rem - row * cpr;
+    prow[j] = i < npiece ? row : -1;
+    pdst[j] = isv * 64 * AT<T>::RS + row * AT<T>::RS + c * 16;
+    psrc[j] = (long)D + (long)isv * D + (long)row * ld + c * VEC;
   }
+  auto fetch = [&](int kt0) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      pre[j] = v16_zero();
+      if (prow[j] >= 0 && kt0 + prow[j] < Tn) pre[j] = ld16(base + psrc[j] + (long)kt0 * ld);
+    }
+  };
+  auto deposit = [&](unsigned char* buf) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)
+      if (prow[j] >= 0) st16(buf + pdst[j], pre[j]);
+  };
+  fetch(0);
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   f32x4 o[2][NDT];
 #pragma unroll
@@ -186,15 +271,14 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kt0 = 0; kt0 < klen; kt0 += 64) {
-    const unsigned char* Ks = lds + (resident ? (kt0 >> 6) * PAIR : 0);
+  auto tile_step = [&](int kt0, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;  // the last tile of a length that is no multiple of 64: keys past klen are masked
+    unsigned char* Ks = lds + ((kt0 >> 6) & 1) * PAIR;
     const unsigned char* Vs = Ks + 64 * AT<T>::RS;
-    if (!resident) {
-      __syncthreads();
-      stage_tile<T>(lds, base + D, ld, kt0, Tn, dh);
-      stage_tile<T>(lds + 64 * AT<T>::RS, base + 2 * D, ld, kt0, Tn, dh);
-      __syncthreads();
-    }
+    // the buffer's previous readers (tile k - 2) finished before they arrived at the barrier of tile k - 1, which this wave has passed
+    deposit(Ks);
+    __syncthreads();
+    if (kt0 + 64 < klen) fetch(kt0 + 64);
     f32x4 s[4][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -207,7 +291,6 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
         s[kb][1] = mma(a, qf[1][ks], s[kb][1]);
       }
     }
-    const bool tail = kt0 + 64 > klen;  // wave-uniform: only the last tile needs the key mask
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int query = q0 + 16 * qt + r;
@@ -217,7 +300,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = s[kb][qt][e];
-          if (tail && kt0 + 16 * kb + 4 * q + e >= klen) v = -INFINITY;
+          if (TAIL && kt0 + 16 * kb + 4 * q + e >= klen) v = -INFINITY;
           s[kb][qt][e] = v;
           mx = fmaxf(mx, v);
         }
@@ -236,11 +319,13 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
         }
       rs = xor_sum(rs);
       l[qt] = l[qt] * alpha + rs;
+      if (__any(alpha != 1.0f)) {  // (a running maximum that did not move leaves alpha = 2^0 in every lane: skipping is exact)
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[qt][dt][e] *= alpha;
-      if (drop.p > 0.f) {
+          for (int e = 0; e < 4; ++e) o[qt][dt][e] *= alpha;
+      }
+      if (DROP && drop.p > 0.f) {  // (the run-time test stays: without it the compiler keeps all 16 hashes in flight and spills under the 128-register cap)
         const unsigned long long rowbase = (((unsigned long long)b * H + h) * Tn + query) * drop_row_pitch(Tn) + kt0;
         const DropKey dk = drop_key_at(dspan, rowbase);
         const uint32_t lo = (uint32_t)rowbase;
@@ -259,7 +344,10 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const T* __restrict__
     for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) mma_transposed<T, NDT>(Vs, m2, s[2 * m2][qt], s[2 * m2 + 1][qt], o[qt], lane);
-  }
+  };
+  const int nfull = klen >> 6;
+  for (int kt = 0; kt < nfull; ++kt) tile_step(kt * 64, std::false_type{});
+  if (klen & 63) tile_step(nfull * 64, std::true_type{});
 
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -402,10 +490,13 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
   zero_lds<T>(lds, (resident ? ntile : 1) * PAIR);
   if (resident) {
     __syncthreads();
-    for (int kt = 0; kt < ntile; ++kt) {
-      stage_tile<T>(lds + kt * PAIR, base + D, ld, kt * 64, Tn, dh);
-      stage_tile<T>(lds + kt * PAIR + 64 * AT<T>::RS, base + 2 * D, ld, kt * 64, Tn, dh);
-    }
+    stage_tiles<T>(2 * ntile, Tn, dh, [&](int t, const T*& src, long& sld, unsigned char*& dst, int& row0) {
+      const int kt = t >> 1, isv = t & 1;  // key tile, value tile of 64 keys
+      src = base + D + isv * D;
+      sld = ld;
+      dst = lds + kt * PAIR + isv * 64 * AT<T>::RS;
+      row0 = kt * 64;
+    });
   }
   frag qf[2][NK], dof[2][NK];
   float L2[2], dl[2];
@@ -545,7 +636,18 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
   };
   if (resident) {
     __syncthreads();
-    for (int kt = 0; kt < ntile; ++kt) stage_q(kt, kt * 64);
+    stage_tiles<T>(2 * ntile, Tn, dh, [&](int t, const T*& src, long& sld, unsigned char*& dst, int& row0) {
+      const int kt = t >> 1, isdo = t & 1;  // query tile, dO tile of 64 queries
+      src = isdo ? dobase : base;
+      sld = isdo ? (long)D : ld;
+      dst = lds + kt * PAIR + isdo * 64 * AT<T>::RS;
+      row0 = kt * 64;
+    });
+    for (int i = threadIdx.x; i < ntile * 64; i += blockDim.x) {  // log-sum-exp and delta of every query
+      float* L2w = reinterpret_cast<float*>(lds + (i >> 6) * PAIR + 2 * 64 * AT<T>::RS);
+      L2w[i & 63] = i < Tn ? lse[((long)b * H + h) * Tn + i] : INFINITY;
+      L2w[64 + (i & 63)] = i < Tn ? delta[((long)b * H + h) * Tn + i] : 0.f;
+    }
   }
   frag kf[2][NK], vf[2][NK];
 #pragma unroll
@@ -711,12 +813,13 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
 
   zero_lds<T>(lds, 4 * PAIR + 256 * RS);  // the scratch is fully rewritten every step
   __syncthreads();
-  for (int kt = 0; kt < ntile; ++kt) {
-    unsigned char* sb = lds + kt * PAIR;
-    stage_tile<T>(sb, base, ld, kt * 64, Tn, dh);
-    stage_tile<T>(sb + 64 * RS, dobase, D, kt * 64, Tn, dh);
-    stage_tile<T>(Kt + kt * 64 * RS, base + D, ld, kt * 64, Tn, dh);
-  }
+  stage_tiles<T>(3 * ntile, Tn, dh, [&](int t, const T*& src, long& sld, unsigned char*& dst, int& row0) {
+    const int kt = t / 3, which = t - 3 * kt;  // query, dO, key tile of 64 rows
+    src = which == 0 ? base : (which == 1 ? dobase : base + D);
+    sld = which == 1 ? (long)D : ld;
+    dst = which == 2 ? Kt + kt * 64 * RS : lds + kt * PAIR + which * 64 * RS;
+    row0 = kt * 64;
+  });
   {  // lse, and delta[query] = sum_d out * dout: two threads per query row
     const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
     float part = 0.f;
@@ -869,11 +972,16 @@ template <typename K> void set_lds(K kernel, size_t bytes) {
 // (512 queries) per workgroup share the same resident tiles -- 4 waves per SIMD at <= 128 VGPRs.
 template <typename T, int NDT, int NW>
 int fwd_launch_t(const T* qkv, T* out, float* lse, const int* key_len, int B, int Tn, int H, int dh, float sl2, fh_drop drop,
-                 int res, hipStream_t st) {
+                 hipStream_t st) {
   dim3 grid((Tn + 32 * NW - 1) / (32 * NW), H, B), block(NW * 64);
-  const size_t smem = (size_t)(res ? res : 1) * 2 * 64 * AT<T>::RS;
-  set_lds(attn_fwd_kernel<T, NDT, NW>, smem);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NDT, NW>), grid, block, smem, st, qkv, out, lse, key_len, B, Tn, H, dh, sl2, drop, res);
+  const size_t smem = (size_t)2 * 2 * 64 * AT<T>::RS;  // two (K | V) tile buffers
+  if (drop.p > 0.f) {
+    set_lds(attn_fwd_kernel<T, NDT, NW, true>, smem);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NDT, NW, true>), grid, block, smem, st, qkv, out, lse, key_len, B, Tn, H, dh, sl2, drop);
+  } else {
+    set_lds(attn_fwd_kernel<T, NDT, NW, false>, smem);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NDT, NW, false>), grid, block, smem, st, qkv, out, lse, key_len, B, Tn, H, dh, sl2, drop);
+  }
   FH_CHECK_LAUNCH();
   return 0;
 }
@@ -934,25 +1042,23 @@ int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, c
   if (int rc = check_dims(dtype, H, dh, 64)) return rc;
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype == 0) {  // fp32 parity mode: 4-wave workgroups (the wider builds are tuned for the bf16 register budget)
-    const int res = resident_tiles<float>(Tn);
     const float* q = (const float*)qkv;
-    if (dh > 48) return fwd_launch_t<float, 4, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-    return fwd_launch_t<float, 3, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+    if (dh > 48) return fwd_launch_t<float, 4, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+    return fwd_launch_t<float, 3, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
   }
-  const int res = resident_tiles<bf16>(Tn);
   const bf16* q = (const bf16*)qkv;
-  const int nw = wide_waves(res, Tn);
+  const int nw = wide_waves(1, Tn);
   if (dh > 48) {  // 64-wide heads: the teacher (HuBERT Base 768 / 12, Large 1024 / 16), the ex.yaml student
     switch (nw) {
-      case 16: return fwd_launch_t<bf16, 4, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-      case 8: return fwd_launch_t<bf16, 4, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-      default: return fwd_launch_t<bf16, 4, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+      case 16: return fwd_launch_t<bf16, 4, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+      case 8: return fwd_launch_t<bf16, 4, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+      default: return fwd_launch_t<bf16, 4, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
     }
   }
   switch (nw) {
-    case 16: return fwd_launch_t<bf16, 3, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-    case 8: return fwd_launch_t<bf16, 3, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
-    default: return fwd_launch_t<bf16, 3, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, res, st);
+    case 16: return fwd_launch_t<bf16, 3, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+    case 8: return fwd_launch_t<bf16, 3, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+    default: return fwd_launch_t<bf16, 3, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
   }
 }
 
