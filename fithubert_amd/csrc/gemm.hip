@@ -891,6 +891,17 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_a
                : "v"(gsrc), "s"(lds_addr)
                : "memory");
 }
+// two pieces 1 KiB apart in LDS with ONE M0 set-up: the instruction offset is added to the LDS address AND to the global address, so
+// the second source pointer is passed 1 KiB low
+__device__ __forceinline__ void glds16x2(const unsigned char* g0, const unsigned char* g1, unsigned lds_addr) {
+  unsigned keep;
+  const unsigned char* g1m = g1 - 1024;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+               "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g0), "v"(g1m), "s"(lds_addr)
+               : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lptr_t)p)); }
 
 template <int LAYOUT, int ROWS, int BK_, int NW> struct RingLoader;
@@ -1495,11 +1506,9 @@ template <> struct QuarterLoader<FH_R_CONTIG> {  // 256 rows x 64 k, image = 16-
       }
   }
   __device__ __forceinline__ void issue_half(unsigned tile, int h) {  // tile: LDS byte address of the operand's 32 KiB image
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      glds16(ptr[h][ks], tile + (unsigned)((rt[h] * 2 + ks) * 1024));
-      ptr[h][ks] += step[h][ks];
-    }
+    glds16x2(ptr[h][0], ptr[h][1], tile + (unsigned)(rt[h] * 2 * 1024));
+    ptr[h][0] += step[h][0];
+    ptr[h][1] += step[h][1];
   }
   __device__ __forceinline__ void skip_half(int h) {  // the pointer advance of issue_half without the DMA
 #pragma unroll
@@ -1575,9 +1584,9 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
   __device__ __forceinline__ void issue_half(unsigned tile, int h) { step_half<true>(tile, h); }
   __device__ __forceinline__ void skip_half(int h) { step_half<false>(0u, h); }
   template <bool DMA> __device__ __forceinline__ void step_half(unsigned tile, int h) {
+    if (DMA) glds16x2(ptr[h][0], ptr[h][1], tile + (unsigned)dst[h][0]);  // dst[h][1] = dst[h][0] + 1024 (k-chunks 2 w', 2 w' + 1 of one panel)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      if (DMA) glds16(ptr[h][u], tile + (unsigned)dst[h][u]);
       const bool live = tcur[h][u] >= 0;
       const int tn = tcur[h][u] + 64;
       const bool w = live && tn >= rpb;  // requires rpb >= 64 (checked on the host)
