@@ -21,7 +21,7 @@ NAME = re.compile(r"(gemm\w*_kernel<[^>]*>)")
 LAYOUTS = {(0, 0): "0, 0", (0, 1): "0, 1", (1, 0): "1, 0", (1, 1): "1, 1"}
 LOOPS = {0: "gemm_kernel<bf16, {l}>", 1: "gemm_small_kernel<0>", 2: "gemm32_kernel<{l}>", 3: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 64, 2>",
          4: "gemm_ring_kernel<{l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{l}>",
-         7: "gemm_8ph_kernel<{l}>", 8: "gemm_8ph_persistent_kernel<{l}>"}
+         7: "gemm_8ph_kernel<{l}>", 8: "gemm_8ph_stream_kernel<{l}>"}
 
 
 def load(d, counters):
