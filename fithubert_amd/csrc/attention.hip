@@ -1047,7 +1047,10 @@ int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, c
     return fwd_launch_t<float, 3, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
   }
   const bf16* q = (const bf16*)qkv;
-  const int nw = wide_waves(1, Tn);
+  // Workgroup width: 16 waves share one stream of K / V tiles, but at small batches the grid must still cover the chip -- halve
+  // the width while the launch has fewer workgroups than CUs (B = 4, T = 499: 48 workgroups of 16 waves -> 192 of 4)
+  int nw = wide_waves(1, Tn);
+  while (nw > 4 && (long)B * H * ((Tn + 32 * nw - 1) / (32 * nw)) < 256) nw >>= 1;
   if (dh > 48) {  // 64-wide heads: the teacher (HuBERT Base 768 / 12, Large 1024 / 16), the ex.yaml student
     switch (nw) {
       case 16: return fwd_launch_t<bf16, 4, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
