@@ -34,7 +34,7 @@ class GemmEpilogue(C.Structure):
         ("preact", C.c_void_p), ("act", C.c_int), ("drop", Drop), ("gelu_aux", C.c_void_p),
         ("residual", C.c_void_p), ("row_len", C.c_void_p), ("out_f32", C.c_int), ("atomic", C.c_int),
         ("idiv", C.c_int), ("si1", C.c_long), ("si0", C.c_long), ("jdiv", C.c_int), ("sj1", C.c_long),
-        ("sj0", C.c_long), ("tail_cols", C.c_int),
+        ("sj0", C.c_long), ("tail_cols", C.c_int), ("aux_factor", C.c_int),
     ]
 
 

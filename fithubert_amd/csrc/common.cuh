@@ -167,6 +167,22 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
   if constexpr (ElemTraits<T>::DT == 0) return gelu_grad_f(x); else return gelu_fast_grad_f(x);
 }
 
+// activation and derivative together (the forward of a layer that saves GELU' instead of its pre-activation: ep.aux_factor)
+template <typename T> __device__ __forceinline__ void gelu_both_t(float x, float& y, float& g) {
+  if constexpr (ElemTraits<T>::DT == 0) {
+    float cdf, pdf;
+    gelu_parts(x, cdf, pdf);
+    y = x * cdf;
+    g = fmaf(x, pdf, cdf);
+  } else {
+    float x2;
+    const float s = gelu_fast_sig(x, x2);
+    const float wp = fmaf(fmaf(5.0f * FH_GELU_C, x2, 3.0f * FH_GELU_B), x2, FH_GELU_A);
+    y = x * s;
+    g = fmaf(y * (1.0f - s), wp, s);
+  }
+}
+
 // ---------------------------------------------------------------- counter-based dropout
 // mask(seed, site, idx) is a pure function, so backward regenerates the forward's mask.
 __device__ __forceinline__ uint32_t fh_mix32(uint32_t x) {

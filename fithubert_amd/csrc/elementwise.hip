@@ -70,17 +70,17 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
-// dst = src * gelu'(aux) * scale
+// dst = src * gelu'(aux) * scale   (factor != 0: aux already holds gelu' -- the forward saved it, fh_gemm_epilogue.aux_factor)
 template <typename T>
 __global__ void mul_gelu_grad_kernel(const T* __restrict__ src, const T* __restrict__ aux, T* __restrict__ dst, long nvec,
-                                     float scale) {
+                                     float scale, int factor) {
   constexpr int VEC = ElemTraits<T>::VEC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
     float a[VEC], z[VEC];
     unpack16<T>(ld16(src + i * VEC), a);
     unpack16<T>(ld16(aux + i * VEC), z);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) a[e] *= gelu_grad_t<T>(z[e]) * scale;
+    for (int e = 0; e < VEC; ++e) a[e] *= (factor ? z[e] : gelu_grad_t<T>(z[e])) * scale;
     st16(dst + i * VEC, pack16<T>(a));
   }
 }
@@ -164,7 +164,8 @@ int fh_unary_launch(int dtype, const void* src, void* dst, long n, int mode, hip
   return 0;
 }
 
-int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* dst, long n, float scale, hipStream_t st) {
+int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* dst, long n, float scale, hipStream_t st,
+                            int factor) {
   const int vec = dtype == 0 ? 4 : 8;
   if (n <= 0) return 0;
   if (n % vec) return -701;
@@ -172,10 +173,10 @@ int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* d
   dim3 grid((unsigned)min((long)4096, (nvec + 255) / 256)), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(mul_gelu_grad_kernel<float>, grid, block, 0, st, (const float*)src, (const float*)aux, (float*)dst,
-                       nvec, scale);
+                       nvec, scale, factor);
   else
     hipLaunchKernelGGL(mul_gelu_grad_kernel<bf16>, grid, block, 0, st, (const bf16*)src, (const bf16*)aux, (bf16*)dst, nvec,
-                       scale);
+                       scale, factor);
   FH_CHECK_LAUNCH();
   return 0;
 }

@@ -16,6 +16,11 @@
 #include "common.cuh"
 
 namespace {
+// FH_SAVE_GELU_GRAD=0: the conv stack saves pre-activations and the backward evaluates GELU' (the round-1 form; A/B comparisons)
+int save_gelu_grad() {
+  static const int on = [] { const char* e = getenv("FH_SAVE_GELU_GRAD"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on;
+}
 
 #define RC(x)                 \
   do {                        \
@@ -671,7 +676,10 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
     g.C = x.W(p.y[i]);
     g.M = B * s.T[i]; g.N = c.conv_dim[i]; g.Kseg = kk * cin; g.ldc = c.conv_dim[i];
     g.ep.act = FH_ACT_GELU;
-    if (tr) g.ep.preact = x.W(p.z[i]);
+    if (tr) {  // z[i] receives GELU'(pre-activation): what the backward multiplies with (fh_gemm_epilogue.aux_factor)
+      g.ep.preact = x.W(p.z[i]);
+      g.ep.aux_factor = save_gelu_grad();
+    }
     RC(fh_gemm_launch(g, dt, x.st));
   }
   // ---- LayerNorm + post_extract_proj (+ dropout_input, zero padded frames)   model.py:446-489, module.py:273-274
@@ -1227,7 +1235,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     if (c.feature_grad_mult != 1.f) return -822;
     dy0 = x.W(p.dylast);
   } else {
-    RC(fh_mul_gelu_grad_launch(dt, x.W(p.dylast), x.W(p.z[nl]), x.W(p.dz[nl]), s.Mp * E, c.feature_grad_mult, x.st));
+    RC(fh_mul_gelu_grad_launch(dt, x.W(p.dylast), x.W(p.z[nl]), x.W(p.dz[nl]), s.Mp * E, c.feature_grad_mult, x.st, save_gelu_grad()));
   }
   for (int i = nl; i >= 1; --i) {
     const int cin = c.conv_dim[i - 1], cout = c.conv_dim[i], kk = c.conv_k[i], sd = c.conv_stride[i];
@@ -1250,6 +1258,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.M = (int)Mi; g.N = kk * cin; g.Kseg = cout;
       g.ldc = (long)sd * cin; g.c_rpb = Ti; g.c_bstride = (long)Tin * cin;
       g.ep.gelu_aux = aux;
+      g.ep.aux_factor = save_gelu_grad();
       RC(fh_gemm_launch(g, dt, x.st));
       RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, sd * (Ti - 1) + kk, x.st));
     } else if (getenv("FH_DGRAD_SPLIT")) {  // A/B aid: the two-product form (odd frames, then even frames with two segments)
@@ -1262,6 +1271,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.M = (int)Mi; g.N = cin; g.Kseg = cout;
       g.ldc = 2L * cin; g.c_rpb = Ti; g.c_bstride = (long)Tin * cin;
       g.ep.gelu_aux = aux ? aux + (long)cin * p.es : nullptr;
+      g.ep.aux_factor = save_gelu_grad();
       RC(fh_gemm_launch(g, dt, x.st));
       GemmParams e = fh_gemm_params();
       e.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
@@ -1272,6 +1282,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       e.M = B * n_even; e.N = cin; e.Kseg = cout;
       e.ldc = 2L * cin; e.c_rpb = n_even; e.c_bstride = (long)Tin * cin;
       e.ep.gelu_aux = aux;
+      e.ep.aux_factor = save_gelu_grad();
       RC(fh_gemm_launch(e, dt, x.st));
       RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, n_even == Ti + 1 ? 2 * Ti + 1 : 2 * Ti, x.st));
     } else {  // k = 3, s = 2: dx[2u] = dz[u] . W_0 + dz[u-1] . W_2,  dx[2u+1] = dz[u] . W_1
@@ -1289,6 +1300,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       e.M = B * n_even; e.N = 2 * cin; e.Kseg = cout;
       e.ldc = 2L * cin; e.c_rpb = n_even; e.c_bstride = (long)Tin * cin;
       e.ep.gelu_aux = aux;
+      e.ep.aux_factor = save_gelu_grad();
       e.ep.tail_cols = 2 * n_even > Tin ? cin : 0;
       RC(fh_gemm_launch(e, dt, x.st));
       if (2 * n_even < Tin) RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, 2 * n_even, x.st));

@@ -268,10 +268,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
       }
       const long coff = crow + j;
-      if (ep.preact) st4(reinterpret_cast<T*>(ep.preact) + coff, v);
-      if (ep.act == FH_ACT_GELU) {
+      if (ep.preact && ep.aux_factor && ep.act == FH_ACT_GELU) {  // the saved tensor is GELU'(pre-activation)
+        float gq[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+        for (int e = 0; e < 4; ++e) gelu_both_t<T>(v[e], v[e], gq[e]);
+        st4(reinterpret_cast<T*>(ep.preact) + coff, gq);
+      } else {
+        if (ep.preact) st4(reinterpret_cast<T*>(ep.preact) + coff, v);
+        if (ep.act == FH_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_t<T>(v[e]);
+        }
       }
       if (ep.drop.p > 0.f) {
         const unsigned long long didx = ((unsigned long long)g * p.M + i) * (unsigned long long)p.N + j;
@@ -281,7 +288,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
         float a[4];
         ld4(reinterpret_cast<const T*>(ep.gelu_aux) + coff, a);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_t<T>(a[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= ep.aux_factor ? a[e] : gelu_grad_t<T>(a[e]);
       }
       if (ep.residual) {
         float r[4];
@@ -420,17 +427,24 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
         v[e] = fmaf(a[e], ep.alpha, bv[e]);
         v[4 + e] = fmaf(b[e], ep.alpha, bv[4 + e]);
       }
-      if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
-      if (gelu) {
+      if (ep.preact && ep.aux_factor && gelu) {  // the saved tensor is GELU'(pre-activation)
+        float gq[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+        for (int e = 0; e < 8; ++e) gelu_both_t<T>(v[e], v[e], gq[e]);
+        st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], gq);
+      } else {
+        if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
+        if (gelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+        }
       }
       if (drop) drop_scale_vec<8>(ep.drop, d0 + (unsigned long long)(it * 8) * (unsigned long long)p.N, v);
       if (ep.gelu_aux) {
         float x[8];
         aux[it].get(x);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_t<T>(x[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= ep.aux_factor ? x[e] : gelu_grad_t<T>(x[e]);
       }
       if (ep.residual) {
         float x[8];
@@ -493,17 +507,24 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
         v[4 + e] = fmaf(b[e], ep.alpha, bv[4 + e]);
       }
     }
-    if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
-    if (ep.act == FH_ACT_GELU) {
+    if (ep.preact && ep.aux_factor && ep.act == FH_ACT_GELU) {
+      float gq[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+      for (int e = 0; e < 8; ++e) gelu_both_t<T>(v[e], v[e], gq[e]);
+      st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], gq);
+    } else {
+      if (ep.preact) st8<T>(reinterpret_cast<T*>(ep.preact) + co[it], v);
+      if (ep.act == FH_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+      }
     }
     if (ep.drop.p > 0.f) drop_scale_vec<8>(ep.drop, di[it], v);
     if (ep.gelu_aux) {
       float a[8];
       aux[it].get(a);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_t<T>(a[e]);
+      for (int e = 0; e < 8; ++e) v[e] *= ep.aux_factor ? a[e] : gelu_grad_t<T>(a[e]);
     }
     if (ep.residual) {
       float rr[8];
@@ -581,6 +602,7 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
     if (ep.bias && cv[n]) ld4(ep.bias + (long)g * ep.bias_gstride + (ep.bias_mod > 0 ? (j % ep.bias_mod) : j), b4[n]);
   }
   const bool gelu = ep.act == FH_ACT_GELU, drop = ep.drop.p > 0.f;
+  const bool both = gelu && ep.preact && ep.aux_factor;  // the saved tensor is GELU'(pre-activation)
   // read-back side: row it * 8 + (lane >> 3) of the pass, 8 columns at (lane & 7) * 8
   const int jr = j0 + yj0 + 8 * (lane & 7);
   const bool jrv = jr < p.N;
@@ -602,9 +624,15 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
       for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
+          float sv[4];  // what the saved tensor receives: the pre-activation, or GELU' of it (then v becomes the activation here)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sv[e] = v[mm][n][e];
+            if (both) gelu_both_t<bf16>(v[mm][n][e], v[mm][n][e], sv[e]);
+          }
           uint2 pk;
-          pk.x = bf16_bits(v[mm][n][0]) | (bf16_bits(v[mm][n][1]) << 16);
-          pk.y = bf16_bits(v[mm][n][2]) | (bf16_bits(v[mm][n][3]) << 16);
+          pk.x = bf16_bits(sv[0]) | (bf16_bits(sv[1]) << 16);
+          pk.y = bf16_bits(sv[2]) | (bf16_bits(sv[3]) << 16);
           *reinterpret_cast<uint2*>(wp + mm * 16 * EPB_ROW + n * 32) = pk;
         }
       if (jrv) {
@@ -617,7 +645,7 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
     for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        if (gelu) {
+        if (gelu && !both) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[mm][n][e] = gelu_fast_f(v[mm][n][e]);
         }
@@ -1797,7 +1825,7 @@ __device__ __forceinline__ void wait_vm_upto(int n) {
 // the wave's 64 columns lie beyond N, 2 -- 4 with a pre-activation copy -- per m-tile for a block whose rows are all inside M:
 // every instruction then has an active lane), -1 for a block cut by M (rows past M are masked out, and an instruction without
 // active lanes may be branched over).
-template <int M0, int M1, bool PRE, bool GELU, bool DROP, typename AccT>
+template <int M0, int M1, bool PRE, bool GELU, bool DROP, bool BOTH, typename AccT>
 __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const AccT& acc, const float (&b4)[4][4], unsigned char* my, int i0,
                                                    int j0, int xi0, int yj0, int lane, int g) {
   const GemmEpilogue& ep = p.ep;
@@ -1822,9 +1850,15 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
     if (PRE) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
+        float sv[4];  // the pre-activation, or (BOTH) GELU' of it while v becomes the activation
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sv[e] = v[n][e];
+          if (BOTH) gelu_both_t<bf16>(v[n][e], v[n][e], sv[e]);
+        }
         uint2 pk;
-        pk.x = bf16_bits(v[n][0]) | (bf16_bits(v[n][1]) << 16);
-        pk.y = bf16_bits(v[n][2]) | (bf16_bits(v[n][3]) << 16);
+        pk.x = bf16_bits(sv[0]) | (bf16_bits(sv[1]) << 16);
+        pk.y = bf16_bits(sv[2]) | (bf16_bits(sv[3]) << 16);
         *reinterpret_cast<uint2*>(wp + n * 32) = pk;
       }
       const V16 t0 = ld16(lp), t1 = ld16(lp + 8 * EPB_ROW);
@@ -1833,7 +1867,7 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      if (GELU) {
+      if (GELU && !BOTH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[n][e] = gelu_fast_f(v[n][e]);
       }
@@ -1857,12 +1891,13 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
 template <int M0, int M1, typename AccT>
 __device__ __forceinline__ int epilogue_stream16(const GemmParams& p, const AccT& acc, const float (&b4)[4][4], unsigned char* my, int i0,
                                                  int j0, int xi0, int yj0, int lane, int g) {
-  const int opt = (p.ep.preact ? 4 : 0) | (p.ep.act == FH_ACT_GELU ? 2 : 0) | (p.ep.drop.p > 0.f ? 1 : 0);
+  int opt = (p.ep.preact ? 4 : 0) | (p.ep.act == FH_ACT_GELU ? 2 : 0) | (p.ep.drop.p > 0.f ? 1 : 0);
+  if ((opt & 6) == 6 && p.ep.aux_factor) opt |= 8;  // the saved tensor is GELU'(pre-activation)
   switch (__builtin_amdgcn_readfirstlane(opt)) {
-#define FH_E(O) case O: return epilogue_stream16_t<M0, M1, ((O) & 4) != 0, ((O) & 2) != 0, ((O) & 1) != 0>(p, acc, b4, my, i0, j0, xi0, yj0, lane, g);
-    FH_E(1) FH_E(2) FH_E(3) FH_E(4) FH_E(5) FH_E(6) FH_E(7)
+#define FH_E(O) case O: return epilogue_stream16_t<M0, M1, ((O) & 4) != 0, ((O) & 2) != 0, ((O) & 1) != 0, ((O) & 8) != 0>(p, acc, b4, my, i0, j0, xi0, yj0, lane, g);
+    FH_E(1) FH_E(2) FH_E(3) FH_E(4) FH_E(5) FH_E(6) FH_E(7) FH_E(14) FH_E(15)
 #undef FH_E
-    default: return epilogue_stream16_t<M0, M1, false, false, false>(p, acc, b4, my, i0, j0, xi0, yj0, lane, g);
+    default: return epilogue_stream16_t<M0, M1, false, false, false, false>(p, acc, b4, my, i0, j0, xi0, yj0, lane, g);
   }
 }
 
@@ -2174,6 +2209,7 @@ unsigned long long tune_key(const GemmParams& p) {
   mix(qoct(p.M)); mix(qoct(p.N)); mix(qoct(p.Kseg)); mix(p.X.nseg); mix(p.X.layout); mix(p.Y.layout); mix(p.groups);
   mix(p.ep.atomic); mix(p.ep.atomic ? 0 : p.splitk);
   mix(p.ep.preact != nullptr); mix(p.ep.act); mix(p.ep.gelu_aux != nullptr); mix(p.ep.residual != nullptr);
+  if (p.ep.aux_factor) mix(104729);
   if (p.Y.seg1_limit > 0) mix(7919 + p.Y.seg1_limit);
   return h;
 }

@@ -63,7 +63,8 @@ int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int 
 int fh_adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                     float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, hipStream_t st);
 int fh_unary_launch(int dtype, const void* src, void* dst, long n, int mode, hipStream_t st);  // 0: dst = gelu(src), 1: dst += src
-int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* dst, long n, float scale, hipStream_t st);
+int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* dst, long n, float scale, hipStream_t st,
+                            int factor = 0);
 int fh_mask_drop_launch(int dtype, const void* src, void* dst, long rows, int C, int rpb, const int* row_len, fh_drop drop,
                         hipStream_t st);
 

@@ -67,6 +67,10 @@ typedef struct {
   int jdiv; long sj1, sj0; /* (idiv == 0: i*ldc ; jdiv == 0: j) */
   int tail_cols;           /* > 0: the LAST mapped row of every batch item (t == c_rpb - 1) is written in columns < tail_cols only
                               (an output row that packs two frames when the item has an odd number of them); multiple of 8 */
+  int aux_factor;          /* 1: the saved tensor holds GELU'(pre-activation) instead of the pre-activation.  Forward (act = GELU,
+                              preact set): `preact` receives GELU'(alpha X.Y + bias) -- the sigmoid of the activation is at hand there,
+                              the derivative costs 5 more VALU issues; backward (gelu_aux set): C = (X.Y) * gelu_aux, no GELU'
+                              evaluation (it cost ~17 issues per element in the conv data-gradient epilogues) */
 } fh_gemm_epilogue;
 
 typedef struct {

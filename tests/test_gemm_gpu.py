@@ -442,3 +442,44 @@ def test_streaming_8_phase_loop(M, N, K, groups, opts):
         ref = ref / 0.75
     assert ((got.double() - ref) * keep).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
+
+
+@pytest.mark.parametrize("loop", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_saved_gelu_derivative_forward_and_backward(loop):
+    """fh_gemm_epilogue.aux_factor: the forward stores GELU'(pre-activation) through `preact` (not the pre-activation) and the
+    backward multiplies by the stored factor instead of evaluating GELU' -- every epilogue form (M = 600: full and ragged row blocks,
+    N = 480: a partial column tile), against fp64."""
+    dev = "cuda"
+    torch.manual_seed(5)
+    M, N, K = 600, 480, 256
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    sav = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    d = L.GemmDesc()
+    d.X = L.operand(X.data_ptr(), 0, K)
+    d.Y = L.operand(W.data_ptr(), 0, K)
+    d.C = out.data_ptr()
+    d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+    d.ep = L.epilogue(bias=bias.data_ptr(), act=L.ACT_GELU, preact=sav.data_ptr(), aux_factor=1)
+    dY = torch.randn(M, K, device=dev).to(torch.bfloat16)   # backward product: (dY . W'^T) * saved, W' [N][K] read as R_CONTIG
+    dz = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    b = L.GemmDesc()
+    b.X = L.operand(dY.data_ptr(), 0, K)
+    b.Y = L.operand(W.data_ptr(), 0, K)
+    b.C = dz.data_ptr()
+    b.M, b.N, b.Kseg, b.ldc, b.groups, b.splitk = M, N, K, N, 1, 1
+    b.ep = L.epilogue(gelu_aux=sav.data_ptr(), aux_factor=1)
+    try:
+        L.lib().fh_gemm_set_path(loop)
+        _run(d, L.DT_BF16)
+        _run(b, L.DT_BF16)
+    finally:
+        L.lib().fh_gemm_set_path(9)
+    z = X.double() @ W.double().t() + bias.double()
+    gp = 0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-z * z / 2) / (2 * 3.141592653589793) ** 0.5
+    assert (out.double() - torch.nn.functional.gelu(z)).abs().max().item() <= 2e-2 * z.abs().max().item()
+    assert (sav.double() - gp).abs().max().item() <= 1e-2            # |GELU'| <= 1.13, bf16 storage
+    ref = (dY.double() @ W.double().t()) * sav.double()              # exactly the stored factor
+    assert (dz.double() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
