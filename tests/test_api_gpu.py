@@ -467,12 +467,19 @@ def test_three_training_steps_follow_the_oracle_trajectory():
     batches = [0.3 * torch.randn(2, 16000, generator=g) for _ in range(3)]
     pm = torch.zeros(2, 16000, dtype=torch.bool)
     for i, x in enumerate(batches):
-        ref = cpu.step(x, pm)["loss"]
+        # ONE CPU thread for the oracle step: with the host's full thread pool its fp32 reductions change order from run to run, and
+        # Adam's first steps (below) turn that into different update signs -- the ORACLE's step-1 loss was seen at 2.11841 and
+        # 2.11803 in two runs of the same binary while the GPU side repeated to 1e-9
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            ref = cpu.step(x, pm)["loss"]
+        finally:
+            torch.set_num_threads(nthr)
         out = task.training_step({"x": x.to(DEV), "padding_mask": pm.to(DEV), "_lengths": [16000, 16000], "_any_pad": False}, batch_idx=i)
         # step 0 is forward parity (1e-4).  From step 1 on the loss sees Adam updates, and Adam's first steps move EVERY parameter by
         # ~lr in the direction of the gradient's sign -- parameters whose true gradient is zero (the key-projection bias: softmax is
-        # shift invariant) or below the fp32 atomics' summation-order noise move by +-lr at random, in the reference as much as here;
-        # run to run that is worth up to 4e-4 of the later losses on this model (same binary, same inputs), so they get 1e-3
+        # shift invariant) or below summation-order noise move by +-lr at random, on either side: the later losses get 1e-3
         assert abs(out[-1].item() - ref) < (1e-4 if i == 0 else 1e-3 * abs(ref)), (i, out[-1].item(), ref)
     views = task.engine.param_views()
     p0v = task.engine.param_views(p0)
