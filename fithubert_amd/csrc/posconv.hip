@@ -29,21 +29,33 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // ---------------------------------------------------------------- weight norm forward + re-layout
 // ||v||^2 per tap, deterministic: one block per tap, fixed-order tree reduction (no float atomics, so two prepares of
 // the same weights give bit-identical kernel weights)
-__global__ void __launch_bounds__(256) wn_norm2_kernel(const float* __restrict__ v, float* __restrict__ norm2, int rows, int K) {
+// ||v[:, :, j]||^2 over the (co, ci) rows, in two deterministic stages.  v is [rows][K] with the tap index j contiguous, so the
+// threads of a wave walk j (coalesced) and a block owns a contiguous run of rows; one block per tap, as before, read every cache
+// line of v K times over (57 us for 7 MB -- 1 % of a B = 4 step).  part: [gridDim.x][K] block partials (scratch).
+constexpr int WN_NB = 120;
+__global__ void __launch_bounds__(256) wn_norm2_part_kernel(const float* __restrict__ v, float* __restrict__ part, int rows, int K) {
   __shared__ float red[256];
-  const int j = blockIdx.x;
-  float s = 0.f;
-  for (int r = threadIdx.x; r < rows; r += 256) {
-    const float x = v[(long)r * K + j];
-    s = fmaf(x, x, s);
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+  const int per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  for (int j0 = 0; j0 < K; j0 += 128) {                     // (K <= 128 in every shipped model: one trip)
+    const int j = j0 + (threadIdx.x & 127);
+    float s = 0.f;
+    if (j < K)
+      for (int r = r0 + (threadIdx.x >> 7); r < r1; r += 2) {
+        const float x = v[(long)r * K + j];
+        s = fmaf(x, x, s);
+      }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 128 && j < K) part[(long)blockIdx.x * K + j] = red[threadIdx.x] + red[threadIdx.x + 128];
     __syncthreads();
   }
-  if (threadIdx.x == 0) norm2[j] = red[0];
+}
+__global__ void wn_norm2_final_kernel(const float* __restrict__ part, float* __restrict__ norm2, int nb, int K) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(long)b * K + j];
+  norm2[j] = s;
 }
 
 // w_fwd[g][j][co][ci] = w[g*cg+co][ci][j] ; w_bwd[g][j'][ci][co] = w[g*cg+co][ci][K-1-j']  (zero padded to CP; fp32 as written,
@@ -442,7 +454,11 @@ int fh_posconv_prep_launch(int dtype, const float* g, const float* v, void* w_fw
   if (!cp || cg % 2 || K > 1024 || K % 32) return -501;
   // norm doubles as the ||v||^2 accumulator: [0, K) = norm, [K, 2K) = norm2 scratch
   float* norm2 = norm + K;
-  hipLaunchKernelGGL(wn_norm2_kernel, dim3(K), dim3(256), 0, st, v, norm2, D * cg, K);
+  // the block partials park in w_bwd, which the layout kernel (stream-ordered behind) overwrites: groups x K x CP x CP elements >= WN_NB x K floats
+  if ((size_t)groups * K * cp * cp * (dtype == 0 ? 4 : 2) < (size_t)WN_NB * K * sizeof(float)) return -502;
+  hipLaunchKernelGGL(wn_norm2_part_kernel, dim3(WN_NB), dim3(256), 0, st, v, (float*)w_bwd, D * cg, K);
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(wn_norm2_final_kernel, dim3((K + 127) / 128), dim3(128), 0, st, (const float*)w_bwd, norm2, WN_NB, K);
   FH_CHECK_LAUNCH();
   if (cp == 32) return dtype == 0 ? prep_t<float, 32>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st)
                                   : prep_t<bf16, 32>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st);
