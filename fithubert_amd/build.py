@@ -18,7 +18,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libfithubert_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+# -pragma-unroll-threshold: the 256-tile GEMM kernels index their 128-register accumulator block from fully unrolled epilogue loops;
+# past LLVM's default budget (16 K instructions after unrolling) the loops stay rolled, the accumulators move to scratch memory
+# and those epilogues run at half speed -- silently (tests/test_abi.py::test_gemm_kernels_keep_their_accumulators_in_registers)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
+         "-mllvm", "-pragma-unroll-threshold=262144"]
 
 
 def _deps_hash(src: str) -> str:

@@ -415,6 +415,24 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
       for (int it = 0; it < 4; ++it)
         if (!skip[it]) res[it].load(reinterpret_cast<const T*>(ep.residual) + co[it]);
     }
+    if (__builtin_amdgcn_readfirstlane(ep.gelu_aux && ep.aux_factor && !ep.preact && !gelu && !drop && !ep.residual && !ep.row_len)) {
+      // the conv data gradients (product x saved GELU'): their own straight-line instance of the row loop, without the option tests
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (skip[it]) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lp + it * 8 * EPI_ROW);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lp + it * 8 * EPI_ROW + 16);
+        float v[8], x[8];
+        aux[it].get(x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = fmaf(a[e], ep.alpha, bv[e]) * x[e];
+          v[4 + e] = fmaf(b[e], ep.alpha, bv[4 + e]) * x[4 + e];
+        }
+        st8<T>(reinterpret_cast<T*>(p.C) + co[it], v);
+      }
+      return;
+    }
     const unsigned long long d0 = ((unsigned long long)g * p.M + i_first) * (unsigned long long)p.N + j;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {

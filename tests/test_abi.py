@@ -23,3 +23,47 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_signature_table_matches_header():
     assert sorted(L.SIGNATURES) == _header_functions()
+
+
+def _kernel_scratch_bytes(obj):
+    """{kernel name: private (scratch) segment bytes} of the gfx950 code object embedded in a host object file."""
+    import shutil
+    import subprocess
+    import tempfile
+    bindir = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(bindir, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools) or not os.path.exists(obj):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
+        subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(d, "x.o")], check=True, capture_output=True)
+        subprocess.run([tools[1], "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}",
+                        "--unbundle"], check=True, capture_output=True)
+        notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+    out, name = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", line)
+        if m and name:
+            out[name] = int(m.group(1))
+    return out
+
+
+def test_gemm_kernels_keep_their_accumulators_in_registers():
+    """The 256-tile GEMM kernels index a 128-register accumulator block from fully unrolled epilogue loops.  When the unrolled body
+    outgrows LLVM's pragma-unroll budget the loops stay rolled, the block moves to scratch memory (528 bytes per lane) and the
+    epilogues run at half speed -- without any warning and with correct results (it happened in round 2 when the epilogue gained two
+    option blocks; build.py raises the budget).  The compiled code object says so: no such kernel may own more than a few spill
+    slots."""
+    scratch = _kernel_scratch_bytes(os.path.join(ROOT, "fithubert_amd", "csrc", "_obj", "gemm.hip.o"))
+    if scratch is None:
+        import pytest
+        pytest.skip("no built object file / LLVM tools")
+    big = {k: v for k, v in scratch.items() if re.search(r"gemm_(ring|pp|8ph|8ph_stream|small)_kernel|gemm32_kernel|gemm_kernel", k)}
+    assert len(big) >= 20, sorted(scratch)
+    bad = {k: v for k, v in big.items() if v > 128}
+    assert not bad, bad
+    hot = [v for k, v in big.items() if "gemm_8ph_stream_kernelILi0ELi0E" in k or "gemm_8ph_kernelILi0ELi0E" in k]
+    assert hot and max(hot) == 0, hot     # the forward loops: no scratch at all (a scratch access drains loop 8's counted vmcnt queue)
