@@ -204,7 +204,7 @@ __device__ __forceinline__ float xor_sum(float v) {
 // v_mul_lo_u32 per tile and wave) and 32 compare / select pairs per tile for nothing: 249 VALU instructions per 64-key tile and
 // wave where the softmax itself needs ~100 (s_memtime: 1630 cycles per wave and tile against 512 of MFMA).
 template <typename T, int NDT, int NW, bool DROP>
-__global__ void __launch_bounds__(NW * 64, 4) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const int* __restrict__ key_len, int B,
                                                        int Tn, int H, int dh, float scale_log2e, DropCfg drop) {
   // K / V are STREAMED through two (K tile | V tile) buffers (36 KiB): every thread fetches its 16-byte pieces of tile k + 1 into
