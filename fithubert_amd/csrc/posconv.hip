@@ -27,8 +27,6 @@ template <typename T, int CP> struct PC {
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // ---------------------------------------------------------------- weight norm forward + re-layout
-// ||v||^2 per tap, deterministic: one block per tap, fixed-order tree reduction (no float atomics, so two prepares of
-// the same weights give bit-identical kernel weights)
 // ||v[:, :, j]||^2 over the (co, ci) rows, in two deterministic stages.  v is [rows][K] with the tap index j contiguous, so the
 // threads of a wave walk j (coalesced) and a block owns a contiguous run of rows; one block per tap, as before, read every cache
 // line of v K times over (57 us for 7 MB -- 1 % of a B = 4 step).  part: [gridDim.x][K] block partials (scratch).
@@ -305,12 +303,52 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
 #pragma unroll
       for (int ib = 0; ib < CB; ++ib) acc[jj][cb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // bf16, channel groups that are no whole number of 16-byte vectors (fithubert.yaml: 30 channels): the (dzc | x window) rows of
+  // tile i + 1 are fetched into REGISTERS (40 four-byte pairs per thread at K = 128) before tile i is multiplied and stored to LDS
+  // behind it.  Staged synchronously, a tile cost 40 dependent load -> LDS-store round trips per thread against 2 us of MFMA work
+  // with one workgroup per CU: 608 us per launch, four fifths of it waiting.
+  constexpr int NPRE = 48, UN = CP / 2;
+  const int unitsA = TS * UN, total_units = unitsA + (TS + K - 1) * UN;
+  const bool prefetch = sizeof(T) == 2 && cg % 8 != 0 && total_units <= NPRE * 256;
+  uint32_t pre[NPRE];
+  auto fetch = [&](int tile) {
+    const int b = tile / ntt, t0 = (tile - b * ntt) * TS;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int idx = (int)threadIdx.x + j * 256;
+      pre[j] = 0u;
+      if (idx < total_units) {
+        const bool isb = idx >= unitsA;
+        const int loc = isb ? idx - unitsA : idx, row = loc / UN, u = loc - row * UN;
+        const int t = (isb ? t0 - pad_left : t0) + row;
+        if (t >= 0 && t < Tn && 2 * u + 1 < cg)
+          pre[j] = *reinterpret_cast<const uint32_t*>((isb ? x : dzc) + ((long)b * Tn + t) * D + g * cg + 2 * u);
+      }
+    }
+  };
+  auto deposit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int idx = (int)threadIdx.x + j * 256;
+      if (idx < total_units) {
+        const bool isb = idx >= unitsA;
+        const int loc = isb ? idx - unitsA : idx, row = loc / UN, u = loc - row * UN;
+        *reinterpret_cast<uint32_t*>((isb ? ldsB : ldsA) + row * RS + u * 4) = pre[j];
+      }
+    }
+  };
+  if (prefetch && (int)blockIdx.z < B * ntt) fetch(blockIdx.z);
   for (int tile = blockIdx.z; tile < B * ntt; tile += nsplit) {
     const int b = tile / ntt, t0 = (tile - b * ntt) * TS;
     __syncthreads();
-    stage_rows<T, CP, false>(ldsA, dzc, nullptr, nullptr, b, Tn, D, cg, g, t0, TS, 0, 0);
-    stage_rows<T, CP, false>(ldsB, x, nullptr, nullptr, b, Tn, D, cg, g, t0 - pad_left, TS + K - 1, 0, 0);
+    if (prefetch) {
+      deposit();
+    } else {
+      stage_rows<T, CP, false>(ldsA, dzc, nullptr, nullptr, b, Tn, D, cg, g, t0, TS, 0, 0);
+      stage_rows<T, CP, false>(ldsB, x, nullptr, nullptr, b, Tn, D, cg, g, t0 - pad_left, TS + K - 1, 0, 0);
+    }
     __syncthreads();
+    if (prefetch && tile + nsplit < B * ntt) fetch(tile + nsplit);
     if constexpr (sizeof(T) == 2) {
 #pragma unroll 1
       for (int ks = 0; ks < TS / 32; ++ks) {
