@@ -1107,7 +1107,9 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 }
 
 template <int XL, int YL, int BM_, int BN_, int WM, int WN, int BK_, int NST>
-__global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const GemmParams p) {
+// (the 4-wave build is meant to run TWO workgroups per CU: without the second launch-bound argument the compiler took 364 registers
+// per wave -- 236 + 128 accumulators -- and one workgroup was all a CU could hold)
+__global__ void __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) gemm_ring_kernel(const GemmParams p) {
   constexpr int NW = WM * WN, TM = BM_ / WM, TN = BN_ / WN, MT = TM / 16, NT = TN / 16, KS = BK_ / 32;
   typedef RingLoader<XL, BM_, BK_, NW> LX;
   typedef RingLoader<YL, BN_, BK_, NW> LY;
