@@ -355,7 +355,7 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
 int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta,
                         const void* dy, const float* mean, const float* rstd, float2* part, float2* ab, float* dw,
                         float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
-                        hipStream_t st) {
+                        hipStream_t st, int stats_ready) {
   if (K > MAXK || C0 % 64 != 0 || C0 / CV > 256 || 256 % (C0 / CV) != 0) return -201;
   Conv0Args a;
   a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta;
@@ -365,8 +365,10 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
   dim3 grid(a.nchunk, B), block(256);
   // statistics partials of the waveform (the same pass as the forward's) -> `part`, read as floats [B][nchunk][K + K*K]
   if (K + K * K > 2 * C0) return -202;
-  hipLaunchKernelGGL(conv0_stats_kernel, grid, dim3(128), smem_bytes(stride, K, false), st, a, (float*)part);
-  FH_CHECK_LAUNCH();
+  if (!stats_ready) {  // (the engine's backward finds the forward's partials of the same waveform still in `part`)
+    hipLaunchKernelGGL(conv0_stats_kernel, grid, dim3(128), smem_bytes(stride, K, false), st, a, (float*)part);
+    FH_CHECK_LAUNCH();
+  }
   const int nblk = fh_conv0_bwd_blocks(B, a.nchunk);  // ~1024 blocks in total; each writes its partial sums once
   dim3 wgrid(nblk, B);
   float* wpart = (float*)(ab + (long)B * C0);

@@ -1313,7 +1313,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
   RC(fh_conv0_bwd_launch(dt, wave, x.params + p.pl.conv_w[0], x.params + p.pl.gn_w, x.params + p.pl.gn_b, dy0,
                          x.W<float>(p.c0_mean), x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch),
                          x.W<float2>(p.c0_scratch) + (long)B * fh_conv0_nchunk(s.T[0]) * c.conv_dim[0], grads + p.pl.conv_w[0],
-                         grads + p.pl.gn_w, grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st));
+                         grads + p.pl.gn_w, grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st, /*stats_ready: the forward's waveform sums are still in c0_scratch*/ 1));
   return 0;
 }
 

@@ -13,7 +13,7 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
 int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta,
                         const void* dy, const float* mean, const float* rstd, float2* part, float2* ab, float* dw,
                         float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
-                        hipStream_t st);
+                        hipStream_t st, int stats_ready = 0);
 
 // ---- norm.hip
 int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
