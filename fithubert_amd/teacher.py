@@ -442,7 +442,10 @@ class TeacherModel(nn.Module):
             x = native.features(self, source)
         else:
             x = self.feature_extractor(source.to(dt)).transpose(1, 2)
-        x = self.layer_norm(x)
+        if native is not None:   # LayerNorm(512) over the conv features on the library's kernel (modules/model.py:446 on the teacher side)
+            x = native.ln(x, native._f32(self.layer_norm.weight), native._f32(self.layer_norm.bias))
+        else:
+            x = self.layer_norm(x)
         B, T, _ = x.shape
         fm = self._frame_mask(padding_mask, T, lengths)
         post = self.post_extract_proj(x)
@@ -457,7 +460,10 @@ class TeacherModel(nn.Module):
                 xc = xc[:, :, :-1]
             x = x + F.gelu(xc).transpose(1, 2)
         if not self.cfg.layer_norm_first:
-            x = self.encoder.layer_norm(x)
+            if native is not None:
+                x = native.ln(x, native._f32(self.encoder.layer_norm.weight), native._f32(self.encoder.layer_norm.bias))
+            else:
+                x = self.encoder.layer_norm(x)
         key_mask = None if fm is None else (~fm)[:, None, None, :]
         L = len(self.encoder.layers)
         hidden = torch.empty(L, B, T, x.shape[-1], device=x.device, dtype=dt)
