@@ -124,6 +124,7 @@ SIGNATURES = {
     "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
     "fh_gemm_set_path": (_I, [_I]),
     "fh_gemm_last_loop": (_I, []),
+    "fh_gemm_reserve_cus": (_I, [_I]),
     "fh_gemm_tune": (_I, [_I]),
     "fh_gemm_tune_export": (_I, [_P, _P, _P, _I]),
     "fh_gemm_tune_import": (_I, [_P, _P, _P, _I]),

@@ -2109,6 +2109,7 @@ int launch_8ph(const GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
+int g_reserve_cus = 0;
 // launches loop 8 can take: the bf16-staged epilogue without per-row operands, one reduction split
 bool stream_ok(const GemmParams& p) {
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
@@ -2126,7 +2127,11 @@ int launch_8ph_stream(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256, tiles = tiles_i * tiles_j;
   const long total = (long)tiles * p.groups;
   if (total > 0x7fffffffL) return -122;
-  dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1), block(512);
+  // a persistent workgroup owns its CU's registers and LDS for the whole launch (up to milliseconds): with fh_gemm_reserve_cus the
+  // grid leaves CUs free for kernels that must make progress meanwhile (the collective kernels of a data-parallel run)
+  int pgrid = (ncu - g_reserve_cus) & ~7;
+  if (pgrid < 8) pgrid = 8;
+  dim3 grid((unsigned)(total < pgrid ? total : pgrid), 1, 1), block(512);
   const size_t smem = 131072 + 8 * EPS_WAVE;
   static bool attr_set = false;
   if (!attr_set) {
@@ -2333,6 +2338,11 @@ bool g_prof_on = false;
 }  // namespace
 
 extern "C" int fh_gemm_last_loop(void) { return g_last_loop; }
+extern "C" int fh_gemm_reserve_cus(int n) {
+  const int old = g_reserve_cus;
+  if (n >= 0) g_reserve_cus = n;
+  return old;
+}
 extern "C" int fh_gemm_set_path(int path) {
   g_gemm_path = path;
   return 0;

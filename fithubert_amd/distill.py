@@ -141,6 +141,11 @@ class W2V2Distil:
         self.opt_step = 0
         self.num_training_steps = None
         self.sync = GradSync(self.engine.grads)
+        if self.sync.active and self.device.type == "cuda":
+            # data parallel: RCCL's collective kernels run beside the step; the persistent GEMM loop (which otherwise owns every CU
+            # for the length of a launch) leaves one CU per XCD to them
+            from . import _lib as _L
+            _L.lib().fh_gemm_reserve_cus(8)
         broadcast_parameters(self.engine.params)
         self.student_model.mark_params_updated()
         self._micro = 0

@@ -101,6 +101,10 @@ int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
 int fh_gemm_set_path(int path);
 /* The main loop the last bf16 launch ran (fh_gemm_set_path numbering): what a forced or tuned path resolved to. */
 int fh_gemm_last_loop(void);
+/* CUs the persistent loop 8 leaves free (rounded up to a multiple of 8, one per XCD; returns the previous value, n < 0 only reads).
+ * A persistent workgroup holds its CU's registers and LDS for the whole launch, so kernels of other streams that must make
+ * progress meanwhile -- RCCL's collectives in a data-parallel run (train.py:494) -- need CUs it does not occupy. */
+int fh_gemm_reserve_cus(int n);
 /* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
  * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the
  * output several times -- only for throw-away passes (StudentEngine.autotune).  mode 0: stop measuring; unmeasured shapes

@@ -425,6 +425,13 @@ def test_streaming_8_phase_loop(M, N, K, groups, opts):
         got, pre = run(8)
         assert L.lib().fh_gemm_last_loop() == 8
         base, pre7 = run(7)
+        if M == 70000:   # the same walk with CUs held back for other streams' kernels (fh_gemm_reserve_cus: data-parallel runs)
+            prev = L.lib().fh_gemm_reserve_cus(40)
+            try:
+                got40, _ = run(8)
+            finally:
+                L.lib().fh_gemm_reserve_cus(prev)
+            assert torch.equal(got40, base)
     finally:
         L.lib().fh_gemm_set_path(9)
     assert not torch.isnan(got.float()).any()
