@@ -388,6 +388,8 @@ def test_small_m_loop_one_trip_reduction(M, N, K, nseg):
     (30000, 512, 256, 3, "bias_gelu_drop"),            # groups flattened into the tile walk; dropout indices
     (66048, 768, 768, 1, "plain"),                     # no bias piece in the prefetch; M a multiple of 256
     (300, 200, 96, 1, "bias_gelu"),                    # fewer tiles than CUs
+    (40000, 512, 480, 1, "bias_ystrided"),             # Y read with the output index contiguous (a data gradient's layout)
+    (40000, 480, 512, 2, "plain_xstrided_ystrided"),   # both operands with the reduction index as the memory row
 ])
 def test_streaming_8_phase_loop(M, N, K, groups, opts):
     """Loop 8: one workgroup per CU walks tiles f, f + G, ... and issues the next tile's first two K-tiles (and bias row) by LDS-DMA
@@ -400,14 +402,17 @@ def test_streaming_8_phase_loop(M, N, K, groups, opts):
     X = torch.randn(groups, M, K, device=dev).to(torch.bfloat16)
     W = (torch.randn(groups, N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(groups, N, device=dev)
+    xs, ys = "xstrided" in opts, "ystrided" in opts
+    Xm = X.transpose(1, 2).contiguous() if xs else X      # [groups][K][M]: R_STRIDED, leading dimension M
+    Wm = W.transpose(1, 2).contiguous() if ys else W      # [groups][K][N]: R_STRIDED, leading dimension N
 
     def run(path):
         L.lib().fh_gemm_set_path(path)
         out = torch.full((groups, M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         pre = torch.full((groups, M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         d = L.GemmDesc()
-        d.X = L.operand(X.data_ptr(), 0, K, gstride=M * K)
-        d.Y = L.operand(W.data_ptr(), 0, K, gstride=N * K)
+        d.X = L.operand(Xm.data_ptr(), 1 if xs else 0, M if xs else K, gstride=M * K)
+        d.Y = L.operand(Wm.data_ptr(), 1 if ys else 0, N if ys else K, gstride=N * K)
         d.C = out.data_ptr()
         d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, groups, 1
         d.c_gstride = M * N
