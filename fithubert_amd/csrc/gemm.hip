@@ -1495,12 +1495,13 @@ int launch_pp(const GemmParams& p, hipStream_t stream) {
 
 // ------------------------------------------------------------------ 8-phase form (R_CONTIG x R_CONTIG), after the guide's 256^2 template
 // 256 x 256 tile, BK = 64, two 64-KiB tile buffers, 8 waves (2 x 4), each wave's 128 x 64 output in four quadrants.  A K-tile
-// is four phases { LDS reads of the quadrant's fragments + ONE quarter of the NEXT tile by LDS-DMA (2 instructions) | barrier |
-// 16 MFMAs | barrier }; the next tile's quarters are issued in the order the phases will need them
-//   A(mh0) B(nh0) B(nh1) A(mh1)      (mh / nh: upper / lower 64 rows, left / right 32 columns of every wave's tile)
-// so one counted wait per two phases suffices: vmcnt(4) in phase 2 (retires A(mh1) of this tile, read in phase 3) and
-// vmcnt(2) in phase 4 (retires the first three quarters of the next tile).  Waves 4-7 run one barrier behind waves 0-3, so
-// each SIMD alternates one wave reading / issuing with one wave in its MFMA cluster.
+// is four phases { LDS reads of the quadrant's fragments + ONE quarter of a later tile by LDS-DMA (2 instructions) | barrier |
+// 16 MFMAs | barrier } over the quadrants (mh0, nh0) (mh0, nh1) (mh1, nh1) (mh1, nh0)   (mh / nh: upper / lower 64 rows, left /
+// right 32 columns of every wave's tile).  The quarter a phase has just read is dead, so it is refilled at once with the tile TWO
+// ahead (first form of this loop: the tile one ahead, issued during the iteration before its use -- its third quarter then had one
+// phase, ~0.35 us, to arrive before the counted wait in front of it, less than a loaded L2 / HBM round trip, and every K-tile
+// stalled there: -4 ... -7 % on K >= 768).  Waves 4-7 run one barrier behind waves 0-3, so each SIMD alternates one wave
+// reading / issuing with one wave in its MFMA cluster.
 template <int LAYOUT> struct QuarterLoader;
 template <> struct QuarterLoader<FH_R_CONTIG> {  // 256 rows x 64 k, image = 16-row x 32-k sub-tiles (st_16x32), as RingLoader
   const bf16* base;
@@ -1737,43 +1738,58 @@ __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char
     }
     ++issued;
   };
-  // prologue: tile 0 in need order; its last quarter may still be in flight when the loop starts
+  // prologue: K-tiles 0 and 1, each in need order; K-tile 1 may still be in flight when the loop starts
   const unsigned lds0 = lds_addr_of(lds);
-  advance();
-  lx.issue_half(lds0, 0);
-  ly.issue_half(lds0 + XT, 0);
-  ly.issue_half(lds0 + XT, 1);
-  lx.issue_half(lds0, 1);
-  asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+  for (int k = 0; k < (nt > 1 ? 2 : 1); ++k) {
+    const unsigned b = lds0 + k * STAGE;
+    advance();
+    lx.issue_half(b, 0);
+    ly.issue_half(b + XT, 0);
+    ly.issue_half(b + XT, 1);
+    lx.issue_half(b, 1);
+  }
+  if (nt > 1)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   bf16x8 fa[2][4], fb[2][2];  // [ks][m-tile of the half], [ks][n-tile of the half]
+  // a quarter of a stage is dead once the phase that reads it has passed, so K-tile it + 2 goes into the stage K-tile it is being
+  // read from: A(mh0) in phase 2, B(nh1) in phase 3, A(mh1) in phase 4, B(nh0) -- which phase 4 reads again -- in phase 1 of the
+  // next iteration; every piece has 3 to 7 phases to land and ONE counted wait per K-tile (phase 4: all but the six instructions
+  // of this iteration's phases 2 - 4, i.e. the whole of K-tile it + 1) orders the data; the last two iterations issue nothing
   for (int it = 0; it < nt; ++it) {
     const unsigned char* bx = lds + (it & 1) * STAGE;
     const unsigned char* by = bx + XT;
-    const unsigned wx = lds0 + ((it + 1) & 1) * STAGE, wy = wx + XT;
-    // phase 1: quadrant (mh0, nh0); next tile's A(mh0)
+    const unsigned wc = lds0 + (it & 1) * STAGE, wo = lds0 + ((it + 1) & 1) * STAGE;
+    const bool more = it + 2 < nt;
     FH_READ_B(0)
     FH_READ_A(0)
-    advance();
-    lx.issue_half(wx, 0);
+    if (it >= 1 && it + 1 < nt) ly.issue_half(wo + XT, 0);
     FH_PHASE_TAIL("")
     FH_PHASE_MMA(0, 0)
-    // phase 2: (mh0, nh1); next tile's B(nh0); this tile's A(mh1) must have landed for phase 3
     FH_READ_B(1)
-    ly.issue_half(wy, 0);
-    FH_PHASE_TAIL("s_waitcnt vmcnt(4)")
+    if (more) {
+      advance();
+      lx.issue_half(wc, 0);
+    }
+    FH_PHASE_TAIL("")
     FH_PHASE_MMA(0, 1)
-    // phase 3: (mh1, nh1); next tile's B(nh1)
     FH_READ_A(1)
-    ly.issue_half(wy, 1);
+    if (more) ly.issue_half(wc + XT, 1);
     FH_PHASE_TAIL("")
     FH_PHASE_MMA(1, 1)
-    // phase 4: (mh1, nh0); next tile's A(mh1); the next tile's first three quarters must have landed
     FH_READ_B(0)
-    lx.issue_half(wx, 1);
-    FH_PHASE_TAIL("s_waitcnt vmcnt(2)")
+    if (more) {
+      lx.issue_half(wc, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    FH_PHASE_TAIL("")
     FH_PHASE_MMA(1, 0)
   }
   if (!late) __builtin_amdgcn_s_barrier();
@@ -1835,7 +1851,7 @@ __device__ __forceinline__ void glds4(const float* gsrc, unsigned dst) {  // 64 
 __device__ __forceinline__ void wait_vm_upto(int n) {
   switch (__builtin_amdgcn_readfirstlane(n)) {
 #define FH_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    FH_W(8) FH_W(16) FH_W(24)
+    FH_W(6) FH_W(8) FH_W(14) FH_W(16) FH_W(22) FH_W(24)
 #undef FH_W
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
@@ -2008,45 +2024,64 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {  // iteration 0: both K-tiles are resident or on their way, nothing to issue, one wait (K-tile 1) at the end
+    // a quarter of a stage is dead once the phase that reads it has passed, so K-tile it + 2 goes into the stage K-tile it is being
+    // read from: A(mh0) in phase 2, B(nh1) in phase 3, A(mh1) in phase 4, B(nh0) in phase 1 of the next iteration (phase 4 reads it
+    // again) -- every piece has 3 to 7 phases to land, and ONE counted wait per K-tile (phase 4: all but the six instructions of
+    // this iteration's phases 2 - 4, i.e. the whole of K-tile it + 1) orders the data; the last two iterations issue nothing
+    {
       const unsigned char* bx = lds;
       const unsigned char* by = bx + XT;
+      const bool more = nt > 2;
       FH_READ_B(0)
       FH_READ_A(0)
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(0, 0)
       FH_READ_B(1)
+      if (more) {
+        advance();
+        lx.issue_half(lds0, 0);
+      }
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(0, 1)
       FH_READ_A(1)
+      if (more) ly.issue_half(lds0 + XT, 1);
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 1)
       FH_READ_B(0)
-      wait_vm_upto(younger < 0 ? 0 : younger);
+      if (more) lx.issue_half(lds0, 1);
+      wait_vm_upto(younger < 0 ? 0 : younger + (more ? 6 : 0));
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 0)
     }
     for (int it = 1; it < nt; ++it) {
       const unsigned char* bx = lds + (it & 1) * STAGE;
       const unsigned char* by = bx + XT;
-      const unsigned wx = lds0 + ((it + 1) & 1) * STAGE, wy = wx + XT;
+      const unsigned wc = lds0 + (it & 1) * STAGE, wo = lds0 + ((it + 1) & 1) * STAGE;
+      const bool more = it + 2 < nt;
       FH_READ_B(0)
       FH_READ_A(0)
-      advance();
-      lx.issue_half(wx, 0);
+      if (it + 1 < nt) ly.issue_half(wo + XT, 0);
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(0, 0)
       FH_READ_B(1)
-      ly.issue_half(wy, 0);
-      FH_PHASE_TAIL("s_waitcnt vmcnt(4)")
+      if (more) {
+        advance();
+        lx.issue_half(wc, 0);
+      }
+      FH_PHASE_TAIL("")
       FH_PHASE_MMA(0, 1)
       FH_READ_A(1)
-      ly.issue_half(wy, 1);
+      if (more) ly.issue_half(wc + XT, 1);
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 1)
       FH_READ_B(0)
-      lx.issue_half(wx, 1);
-      FH_PHASE_TAIL("s_waitcnt vmcnt(2)")
+      if (more) {
+        lx.issue_half(wc, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 0)
     }
     if (!late) __builtin_amdgcn_s_barrier();
@@ -2133,23 +2168,16 @@ int launch_8ph_stream(const GemmParams& p, hipStream_t stream) {
   if (pgrid < 8) pgrid = 8;
   dim3 grid((unsigned)(total < pgrid ? total : pgrid), 1, 1), block(512);
   const size_t smem = 131072 + 8 * EPS_WAVE;
+  typedef void (*kern_t)(const GemmParams, int, int);
+  static const kern_t kerns[2][2] = {{gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_CONTIG>, gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_STRIDED>},
+                                     {gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_CONTIG>, gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_STRIDED>}};
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_STRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) hipFuncSetAttribute((const void*)kerns[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  const int xl = p.X.layout, yl = p.Y.layout;
-  if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
-    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p, tiles, (int)total);
-  else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
-    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_CONTIG, FH_R_STRIDED>), grid, block, smem, stream, p, tiles, (int)total);
-  else if (xl == FH_R_STRIDED && yl == FH_R_CONTIG)
-    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_CONTIG>), grid, block, smem, stream, p, tiles, (int)total);
-  else
-    hipLaunchKernelGGL((gemm_8ph_stream_kernel<FH_R_STRIDED, FH_R_STRIDED>), grid, block, smem, stream, p, tiles, (int)total);
+  hipLaunchKernelGGL(kerns[p.X.layout == FH_R_STRIDED][p.Y.layout == FH_R_STRIDED], grid, block, smem, stream, p, tiles, (int)total);
   FH_CHECK_LAUNCH();
   return 0;
 }
