@@ -2319,7 +2319,7 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
   hipEventCreate(&a);
   hipEventCreate(&b);
   TuneChoice best = cand[0];
-  float best_ms = 1e30f;
+  float best_ms = 1e30f, ms8 = 1e30f;
   for (auto& c : cand) {
     GemmParams q = p;
     q.splitk = c.splitk;
@@ -2335,7 +2335,19 @@ TuneChoice tune_measure(const GemmParams& p, hipStream_t stream) {
       ms = t < ms ? t : ms;
     }
     if (ms < best_ms) { best_ms = ms; best = c; }
+    if (c.path == 8) ms8 = ms;
   }
+  // loops 7 and 8 share their main loop and are within a few percent of each other when timed alone, so timing noise decided
+  // between them.  Loop 8 takes the launch unless loop 7 wins by more than FH_GEMM_PREFER8 percent (default 4): in the step these
+  // launches run beside another stream's kernels, and the persistent form keeps its CUs and its XCD-local tile order for the whole
+  // launch (its launches stay near their stand-alone duration; loop 7's workgroups interleave with the other stream's and stretch
+  // 2 - 4 x, which packs the step 0.5 - 1 % tighter but leaves no per-kernel figure one can read: DESIGN.md section 5)
+  static int prefer8 = -1;
+  if (prefer8 < 0) {
+    const char* e = getenv("FH_GEMM_PREFER8");
+    prefer8 = e ? atoi(e) : 4;
+  }
+  if (best.path == 7 && ms8 < best_ms * (1.f + 0.01f * prefer8)) best = {8, p.splitk};
   hipEventDestroy(a);
   hipEventDestroy(b);
   return best;
