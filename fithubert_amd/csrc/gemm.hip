@@ -1669,6 +1669,12 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
   __builtin_amdgcn_sched_barrier(0);                             \
   __builtin_amdgcn_s_setprio(1);
+// Before a quarter that the previous phase read is handed to the LDS-DMA again: this wave's FIRST fragment read of the current
+// phase has returned.  The waves of the other group issued their reads of that quarter before the barrier this wave has just
+// passed; the LDS serves requests in arrival order, so a read issued behind them having returned means theirs have been served
+// (the DMA data could only overtake them through an L1 hit on the zero chunk, ~150 cycles; N = this phase's LDS reads - 1,
+// at most 15; scalar loads in flight only make the wait stricter).
+#define FH_REFILL_GUARD(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((N) > 15 ? 15 : (N)) : "memory");
 #define FH_PHASE_MMA(MH, NH)                                                                                          \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m)                       \
       _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[(NH) * 2 + n][(MH) * 4 + m] =                                  \
@@ -1689,6 +1695,7 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
 template <int XL, int YL>
 __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char* lds, const LogicalBlock lblk, int nsplit, int g) {
   constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
+  constexpr int RA = XL == FH_R_STRIDED ? 16 : 8, RB = YL == FH_R_STRIDED ? 8 : 4;  // LDS reads of an A / B fragment phase
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_j = (p.N + 255) / 256;
   const int lb = lblk.lb;
@@ -1768,22 +1775,30 @@ __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char
     const bool more = it + 2 < nt;
     FH_READ_B(0)
     FH_READ_A(0)
-    if (it >= 1 && it + 1 < nt) ly.issue_half(wo + XT, 0);
+    if (it >= 1 && it + 1 < nt) {
+      FH_REFILL_GUARD(RA + RB - 1)
+      ly.issue_half(wo + XT, 0);
+    }
     FH_PHASE_TAIL("")
     FH_PHASE_MMA(0, 0)
     FH_READ_B(1)
     if (more) {
       advance();
+      FH_REFILL_GUARD(RB - 1)
       lx.issue_half(wc, 0);
     }
     FH_PHASE_TAIL("")
     FH_PHASE_MMA(0, 1)
     FH_READ_A(1)
-    if (more) ly.issue_half(wc + XT, 1);
+    if (more) {
+      FH_REFILL_GUARD(RA - 1)
+      ly.issue_half(wc + XT, 1);
+    }
     FH_PHASE_TAIL("")
     FH_PHASE_MMA(1, 1)
     FH_READ_B(0)
     if (more) {
+      FH_REFILL_GUARD(RB - 1)
       lx.issue_half(wc, 1);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
@@ -1941,6 +1956,7 @@ template <int XL, int YL>
 __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p, int tiles, int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
+  constexpr int RA = XL == FH_R_STRIDED ? 16 : 8, RB = YL == FH_R_STRIDED ? 8 : 4;  // LDS reads of an A / B fragment phase
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool late = wave >= 4;
   const int tiles_j = (p.N + 255) / 256;
@@ -2039,16 +2055,23 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
       FH_READ_B(1)
       if (more) {
         advance();
+        FH_REFILL_GUARD(RB - 1)
         lx.issue_half(lds0, 0);
       }
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(0, 1)
       FH_READ_A(1)
-      if (more) ly.issue_half(lds0 + XT, 1);
+      if (more) {
+        FH_REFILL_GUARD(RA - 1)
+        ly.issue_half(lds0 + XT, 1);
+      }
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 1)
       FH_READ_B(0)
-      if (more) lx.issue_half(lds0, 1);
+      if (more) {
+        FH_REFILL_GUARD(RB - 1)
+        lx.issue_half(lds0, 1);
+      }
       wait_vm_upto(younger < 0 ? 0 : younger + (more ? 6 : 0));
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 0)
@@ -2060,22 +2083,30 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
       const bool more = it + 2 < nt;
       FH_READ_B(0)
       FH_READ_A(0)
-      if (it + 1 < nt) ly.issue_half(wo + XT, 0);
+      if (it + 1 < nt) {
+        FH_REFILL_GUARD(RA + RB - 1)
+        ly.issue_half(wo + XT, 0);
+      }
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(0, 0)
       FH_READ_B(1)
       if (more) {
         advance();
+        FH_REFILL_GUARD(RB - 1)
         lx.issue_half(wc, 0);
       }
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(0, 1)
       FH_READ_A(1)
-      if (more) ly.issue_half(wc + XT, 1);
+      if (more) {
+        FH_REFILL_GUARD(RA - 1)
+        ly.issue_half(wc + XT, 1);
+      }
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 1)
       FH_READ_B(0)
       if (more) {
+        FH_REFILL_GUARD(RB - 1)
         lx.issue_half(wc, 1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
