@@ -456,6 +456,45 @@ def test_streaming_8_phase_loop(M, N, K, groups, opts):
 
 
 
+@pytest.mark.parametrize("loop", [7, 8])
+@pytest.mark.parametrize("K,ys", [(1000, False), (3072 + 24, False), (1000, True)])
+def test_8_phase_refill_is_race_free(loop, K, ys):
+    """Loops 7 / 8 hand a quarter of a tile buffer back to the LDS-DMA one phase after it was read (K-tile it + 2 lands in the buffer
+    K-tile it is being read from; gemm.hip).  A refill that overtook a pending read, or a wait that counted one piece too few, would
+    show as a result that changes from launch to launch: 40 launches of a shape with a K tail (zero pieces, the fastest to arrive),
+    ragged rows and more tiles than CUs must be bit-identical, and right against fp64."""
+    dev = "cuda"
+    torch.manual_seed(11)
+    M, N = 256 * 300 + 19, 512
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    Wm = W.t().contiguous() if ys else W
+    bias = torch.randn(N, device=dev)
+    outs = [torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16) for _ in range(4)]
+    L.lib().fh_gemm_set_path(loop)
+    try:
+        first = None
+        for i in range(40):
+            out = outs[i % 4]
+            d = L.GemmDesc()
+            d.X = L.operand(X.data_ptr(), 0, K)
+            d.Y = L.operand(Wm.data_ptr(), 1 if ys else 0, N if ys else K)
+            d.C = out.data_ptr()
+            d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+            d.ep = L.epilogue(bias=bias.data_ptr())
+            _run(d, L.DT_BF16)
+            assert L.lib().fh_gemm_last_loop() == loop
+            if first is None:
+                first = out.clone()
+            elif i % 4 == 3:
+                for o in outs:
+                    assert torch.equal(o, first)
+    finally:
+        L.lib().fh_gemm_set_path(9)
+    ref = X.double() @ W.double().t() + bias.double()
+    assert (first.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("loop", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_saved_gelu_derivative_forward_and_backward(loop):
     """fh_gemm_epilogue.aux_factor: the forward stores GELU'(pre-activation) through `preact` (not the pre-activation) and the
