@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fithubert_amd import _lib as L
+if os.environ.get('FH_LIB_PATH'): L.LIB_PATH = os.environ['FH_LIB_PATH']  # A/B of two builds on one box
 lib = L.lib(); st = lambda: torch.cuda.current_stream().cuda_stream
 def run(B, T, cin, cout, kk, sd, path, sk, groups=1, reps=6):
     lib.fh_gemm_set_path(path)
@@ -35,7 +36,7 @@ for name, B, T, cin, cout, kk, sd, G in shapes:
     sk0 = max(1, min(256, K // 512, (512 + tiles - 1) // tiles))
     t, lp = run(B, T, cin, cout, kk, sd, 9, sk0, G)
     line = f"{name:15s} {M}x{N}x{K} g{G}: tuned loop {lp} {t*1e3:7.1f} us {fl/t/1e9:5.0f} TF/s {by/t/1e9:5.2f} TB/s |"
-    for path in (3, 5, 7):
+    for path in (3, 4, 5, 7):
         for sk in sorted({sk0, 64, 85, 128, 170, 256}):
             if G > 1 and sk > 32: continue
             try:
