@@ -693,6 +693,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+// Output tile (ti, tj) of logical block lb of the 256 x 256 loops.  Row-major over a wide output (tj fastest) makes the 32 CUs of an
+// XCD walk ALL column tiles of 2 - 3 row tiles at a time: every K step they pull one 32 KiB slice per column tile through the XCD's
+// 4 MiB L2 and come back to it a full round later, when it is gone (N = 3072, K = 768: 4.7 MB of weights per round).  Column PANELS
+// of cb tiles with the rows fastest inside a panel keep a panel's weights (<= 1.5 MiB, at least 4 tiles, panels of equal width)
+// resident while the rows stream: teacher fc1 -4.5 %, the q|k|v shape -9 %, 8192^3 -7 % (1.44 PFLOP/s); outputs of up to cb
+// column tiles keep the row-major order (narrower panels lose: fewer row tiles share a weight slice).
+__device__ __forceinline__ void tile_coords(int lb, int tiles_i, int tiles_j, int kred, int& ti, int& tj) {
+  int cbmax = 3072 / (kred > 0 ? kred : 1);
+  cbmax = cbmax < 4 ? 4 : cbmax;
+  if (tiles_j <= cbmax) {
+    ti = lb / tiles_j;
+    tj = lb - ti * tiles_j;
+    return;
+  }
+  const int np = (tiles_j + cbmax - 1) / cbmax, cb = (tiles_j + np - 1) / np;
+  const int panel = tiles_i * cb;
+  const int pn = lb / panel, r = lb - pn * panel;
+  const int w = min(cb, tiles_j - pn * cb);
+  ti = r / w;
+  tj = pn * cb + (r - ti * w);
+}
 // (logical tile, reduction split) of this workgroup.  A split-K launch is a (tiles, splits) grid dispatched x-fastest, so the
 // tiles of ONE split -- which re-read the same reduction slab of an operand (a weight gradient with 3 column tiles read dY three
 // times) -- would sit on different XCDs; remapping the flattened id keeps them back to back on one XCD's L2.
@@ -1699,7 +1720,8 @@ __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_j = (p.N + 255) / 256;
   const int lb = lblk.lb;
-  const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
+  int ti, tj;
+  tile_coords(lb, (p.M + 255) / 256, tiles_j, p.Kseg * p.X.nseg, ti, tj);
   const int i0 = ti * 256, j0 = tj * 256;
   const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
   const int ntiles = tiles_per_seg * tile_nseg(p, j0);
@@ -1998,7 +2020,8 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
   auto start_tile = [&](int f) {
     g = f / tiles;
     const int lb = xcd_remap(f - g * tiles, tiles);
-    const int ti = lb / tiles_j, tj = lb - ti * tiles_j;
+    int ti, tj;
+    tile_coords(lb, tiles / tiles_j, tiles_j, p.Kseg * p.X.nseg, ti, tj);
     i0 = ti * 256;
     j0 = tj * 256;
     nt = tiles_per_seg * tile_nseg(p, j0);
