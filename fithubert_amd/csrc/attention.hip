@@ -203,6 +203,20 @@ __device__ __forceinline__ float xor_sum(float v) {
 // if-converted into the one loop body -- the teacher (no dropout, full tiles) executed the dropout hash (16 quarter-rate
 // v_mul_lo_u32 per tile and wave) and 32 compare / select pairs per tile for nothing: 249 VALU instructions per 64-key tile and
 // wave where the softmax itself needs ~100 (s_memtime: 1630 cycles per wave and tile against 512 of MFMA).
+// (batch, head, block) of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), which would
+// put the query / key blocks of one (batch, head) -- readers of the same K / V (Q / dO) rows -- on as many L2s as there are blocks:
+// XCD k takes a contiguous range of the logical order instead (as the GEMM loops' xcd_remap), so those rows come through ONE L2.
+__device__ __forceinline__ void attn_block(int& b, int& h, int& blk) {
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * (int)gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int per = nwg >> 3, rem = nwg & 7, xcd = lin & 7;
+  const int lg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (lin >> 3);
+  blk = lg % gx;
+  const int bh = lg / gx;
+  h = bh % gy;
+  b = bh / gy;
+}
+
 template <typename T, int NDT, int NW, bool DROP>
 __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, const int* __restrict__ key_len, int B,
@@ -219,7 +233,9 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) attn_fwd_kernel(cons
   constexpr int NK = AT<T>::NK;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
+  int b, h, blk;
+  attn_block(b, h, blk);
+  const int q0 = blk * (32 * NW) + wave * 32;
   const int D = H * dh;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
@@ -478,7 +494,9 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
   constexpr int VEC = ElemTraits<T>::VEC;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (32 * NW) + wave * 32;
+  int b, h, blk;
+  attn_block(b, h, blk);
+  const int q0 = blk * (32 * NW) + wave * 32;
   const int D = H * dh;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
@@ -610,7 +628,9 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
   constexpr int NK = AT<T>::NK;
   typedef typename AT<T>::frag frag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * (32 * NW) + wave * 32;
+  int b, h, blk;
+  attn_block(b, h, blk);
+  const int k0 = blk * (32 * NW) + wave * 32;
   const int D = H * dh;
   const long ld = 3L * D;
   const T* base = qkv + (long)b * Tn * ld + h * dh;

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fithubert_amd import _lib as L
+if os.environ.get('FH_LIB_PATH'): L.LIB_PATH = os.environ['FH_LIB_PATH']  # A/B of two builds on one box
 lib = L.lib(); st = lambda: torch.cuda.current_stream().cuda_stream
 B = int(os.environ.get("B", "128")); H = 12
 def timeit(fn, n=10):
