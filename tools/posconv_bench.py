@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fithubert_amd import _lib as L
+if os.environ.get('FH_LIB_PATH'): L.LIB_PATH = os.environ['FH_LIB_PATH']  # A/B of two builds on one box
 lib = L.lib(); st = lambda: torch.cuda.current_stream().cuda_stream
 B, T, D, G, K = int(os.environ.get("B", "128")), 499, int(os.environ.get("D", "768")), 16, 128
 cg = D // G; CP = 32 if cg <= 32 else 64
