@@ -1865,8 +1865,9 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
 //   * vmcnt counts loads, stores and LDS-DMA in ONE in-order queue: `s_waitcnt vmcnt(n)` with n = the operations issued AFTER the
 //     piece waited for (K-tile 1's pieces, the second half's stores) retires it without waiting for those stores'
 //     acknowledgement (~2.5 us under load); the first half's stores are older, but ~4 us old by then;
-//   * the loop's own counted waits are younger than all stores: with two K-tiles resident its first iteration issues nothing and
-//     waits once (K-tile 1), and by the second iteration's first counted wait the stores have been acknowledged;
+//   * the loop's own counted waits are younger than all stores: its first iteration (K-tiles 0 and 1 resident or on their way)
+//     issues the first three quarters of K-tile 2 and waits once -- for K-tile 1, counting those six pieces and the stores behind
+//     it --, and by the second iteration's counted wait the stores have been acknowledged;
 //   * nothing the compiler can see may be a vector-memory LOAD between the LDS-DMA and the stores (it would be waited for with
 //     a count that ignores the asm-issued DMA, i.e. drain them): the bias row comes in by LDS-DMA as well (256 B per wave into a
 //     stash next to the staging rows), every other epilogue operand is a kernel argument (scalar loads); the kernels must not
