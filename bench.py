@@ -33,18 +33,21 @@ GF_STUDENT_FWD, GF_TEACHER_BASE = 35.23, 148.1
 GF_STEP = 3 * GF_STUDENT_FWD + GF_TEACHER_BASE  # 253.8
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 LAYOUTS = {0: "0, 0", 1: "0, 1", 2: "1, 0", 3: "1, 1"}  # <X layout, Y layout>: 0 = R_CONTIG, 1 = R_STRIDED
-LOOPS = {0: "gemm_kernel<bf16, {l}>", 1: "gemm_small_kernel<0>", 2: "gemm32_kernel<{l}>", 3: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 64, 2>",
-         4: "gemm_ring_kernel<{l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{l}>", 7: "gemm_8ph_kernel<{l}>"}
+LOOPS = {0: "gemm_kernel<{t}, {l}>", 1: "gemm_small_kernel<{t}>", 2: "gemm32_kernel<{t}, {l}>", 3: "gemm_ring_kernel<{t}, {l}, 256, 256, 2, 4, 64, 2>",
+         4: "gemm_ring_kernel<{t}, {l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{t}, {l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{t}, {l}>",
+         7: "gemm_8ph_kernel<{t}, {l}>"}
+ELEM_NAME = {"bf16": "__bf16", "float16": "_Float16", "float32": "float"}   # the element type as rocprofv3 prints the template argument
 
 
-def kernel_name(slot: int) -> str:
+def kernel_name(slot: int, dtype: str = "bf16") -> str:
     """fh_prof_collect slot -> the kernel's name as rocprofv3 prints it (anonymous namespace prefix dropped)."""
     loop, var = slot // 8, slot % 8
+    t = ELEM_NAME[dtype]
     if loop == 1 and var < 4:
-        return "gemm_8ph_stream_kernel<%s>" % LAYOUTS[var]
+        return "gemm_8ph_stream_kernel<%s, %s>" % (t, LAYOUTS[var])
     if var < 4:
         return "gemm_kernel<float, %s>" % LAYOUTS[var]
-    return LOOPS[loop].format(l=LAYOUTS[var - 4])
+    return LOOPS[loop].format(t=t, l=LAYOUTS[var - 4])
 
 
 def cpu_baseline(cfg, seconds_budget: float = 28.0):
@@ -204,11 +207,34 @@ def spawn_ranks(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out.decode())
+    # supervise every rank: a rank that dies (build failure, OOM, device fault) would leave the others waiting in a collective until
+    # the backend's timeout -- on the first non-zero exit the rest are terminated and that code is returned; overall limit FH_BENCH_TIMEOUT
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("FH_BENCH_TIMEOUT", "3600"))
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = bad[0] if bad else 124
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            print(f"bench.py: rank exit codes {codes}" + (" (timeout)" if not bad else "") + "; remaining ranks terminated", file=sys.stderr)
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     return rc
 
@@ -219,7 +245,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FH_BENCH_BATCH", "128")), help="utterances per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "float32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "float16", "float32"],
+                    help="compute precision: bf16 (BASELINE.json configs[1]), float16 (IEEE half operands + dynamic loss scaling: the "
+                         "reference's own precision=16 AMP, same MFMA rate), float32 (exact-fp32 parity mode)")
     ap.add_argument("--config", default=os.path.join(ROOT, "conf", "fithubert.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=0, help="variant: student encoder_layers (default: the yaml's 12; BASELINE.json "
@@ -326,9 +354,10 @@ def main():
     if tot_ms > 0:
         v = max(range(64), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
-                "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
-                "kernel": kernel_name(v), "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
+        peak = PEAK_BF16_TFLOPS if args.dtype != "float32" else 157.3   # the f16 MFMA forms run at the bf16 rate (MI355X_MICROARCH.md)
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "kernel": kernel_name(v, args.dtype), "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
                 "avg_gflop_per_launch": round(fl[v] / ln[v] / 1e9, 3),
                 "all_gemm": {"achieved": round(sum(fl) / (tot_ms * 1e-3) / 1e12, 2), "launches": int(sum(ln)),
                              "ms_per_step": round(tot_ms / max(1, min(args.prof_steps, args.steps)), 3)},
@@ -391,7 +420,7 @@ def main():
                                    ("VARIANT: fithubert.yaml student with %d layers + HuBERT-%s-shaped teacher (random init), fixed 10 s clips"
                                     % (cfg["distiller"]["encoder_layers"], "Large" if args.teacher == "large" else "Base")),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": SAMPLES_10S, "parallelism": f"dp{world}",
-                       "teacher": "bf16; " + ("conv frontend, pos-conv, attention, add+LayerNorm, fc1 + GELU: HIP kernels shared with the student; "
+                       "teacher": ("fp16" if args.dtype == "float16" else "bf16") + "; " + ("conv frontend, pos-conv, attention, add+LayerNorm, fc1 + GELU: HIP kernels shared with the student; "
                                               "q|k|v / out-proj / fc2 GEMMs: hipBLASLt via PyTorch-ROCm" if args.teacher_frontend == "native"
                                               else "stock PyTorch-ROCm (MIOpen convs, hipBLASLt, SDPA)"), "optimizer": "fused AdamW every step"},
             "step_tflops": None if variant else round(value * GF_STEP / 1e3, 1),

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libfithubert_hip.so")
 
 R_CONTIG, R_STRIDED = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 
 class Drop(C.Structure):
@@ -150,6 +150,7 @@ SIGNATURES = {
     "fh_kd_loss": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _P]),
     "fh_kd_loss_rows_nblk": (_I, [_I, _I]),
     "fh_kd_loss_rows": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _F, _P]),
+    "fh_kd_loss_rows_scaled": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F, _P]),
     "fh_relation_tensor": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fh_relation_kd_nblk": (_I, [_I, _I, _I]),
     "fh_relation_kd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
@@ -159,6 +160,7 @@ SIGNATURES = {
     "fh_cast": (_I, [_I, _P, _P, _L, _P]),
     "fh_permute3_cast": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fh_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "fh_adamw_amp": (_I, [_P, _P, _P, _P, _L, _F, _I, _I, _F, _F, _F, _F, _F, _P, _P]),
 }
 
 

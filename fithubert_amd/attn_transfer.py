@@ -31,7 +31,9 @@ def _dt(t: torch.Tensor) -> int:
         return L.DT_F32
     if t.dtype == torch.bfloat16:
         return L.DT_BF16
-    raise NotImplementedError(f"relation kernels take fp32 or bf16 q|k|v projections, got {t.dtype}")
+    if t.dtype == torch.float16:
+        return L.DT_F16
+    raise NotImplementedError(f"relation kernels take fp32, bf16 or fp16 q|k|v projections, got {t.dtype}")
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -96,7 +98,7 @@ def v_rel_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
 
 def relation_losses(student_qkv: torch.Tensor, teacher_qkv: torch.Tensor, s_heads: int, t_heads: int,
                     s_key_len: Optional[torch.Tensor], t_key_len: Optional[torch.Tensor], attn_w: float, attn_type: str,
-                    vrel_w: float) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+                    vrel_w: float, grad_scale: float = 1.0) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """The training step's form: student_qkv [B][T][3 Ds], teacher_qkv [B][T][3 Dt] ->
     (weighted loss (fp64 device scalar), {'attn_loss', 'v_rel_loss'} unweighted, d weighted loss / d student_qkv in its dtype).
     One fused kernel per enabled term; no T x T tensor, no host synchronisation."""
@@ -125,4 +127,6 @@ def relation_losses(student_qkv: torch.Tensor, teacher_qkv: torch.Tensor, s_head
                                    float(w), _stream(student_qkv)), "fh_relation_kd")
         losses[name] = out[0]
         total = total + float(w) * out[0]
+    if grad_scale != 1.0:   # the fp16 mode's loss scale, applied in fp32 before the cast
+        d = d * grad_scale
     return total, losses, d.to(student_qkv.dtype)

@@ -22,8 +22,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <typename T> struct AT;
-template <> struct AT<bf16> {
+template <typename T> struct AT {           // 16-bit element types (bf16 / f16)
   static constexpr int DP = 64;             // padded head dim in LDS
   static constexpr int RS = DP * 2 + 16;    // LDS row stride (bytes)
   static constexpr int NK = 2;              // fragments per row over d (32 d-values each)
@@ -63,10 +62,8 @@ template <typename T>
 __device__ __forceinline__ typename AT<T>::frag lfrag(const unsigned char* lds, int row, int ks, int lane) {
   return *reinterpret_cast<const typename AT<T>::frag*>(lds + row * AT<T>::RS + ks * 64 + (lane >> 4) * 16);
 }
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
+template <typename T> __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16<T>(a, b, c); }
+template <typename T> __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
   return c;
@@ -79,11 +76,11 @@ __device__ __forceinline__ void mma_transposed(const unsigned char* tile, int m2
                                                f32x4 (&acc)[NDT], int lane) {
   const int i = lane & 15, q = lane >> 4;
   if constexpr (sizeof(T) == 2) {
-    union { bf16x8 v; bf16 e[8]; } pb;
+    union { bf16x8 v; T e[8]; } pb;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      pb.e[e] = (bf16)P0[e];
-      pb.e[4 + e] = (bf16)P1[e];
+      pb.e[e] = (T)P0[e];
+      pb.e[4 + e] = (T)P1[e];
     }
     const int qq = i >> 2, pp = i & 3;
 #pragma unroll
@@ -92,7 +89,7 @@ __device__ __forceinline__ void mma_transposed(const unsigned char* tile, int m2
       union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
       u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
       u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * AT<bf16>::RS));
-      acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pb.v, acc[dt], 0, 0, 0);
+      acc[dt] = mfma16<T>(u.v, pb.v, acc[dt]);
     }
   } else {
 #pragma unroll
@@ -303,8 +300,8 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) attn_fwd_kernel(cons
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) {
         const frag a = lfrag<T>(Ks, 16 * kb + r, ks, lane);
-        s[kb][0] = mma(a, qf[0][ks], s[kb][0]);
-        s[kb][1] = mma(a, qf[1][ks], s[kb][1]);
+        s[kb][0] = mma<T>(a, qf[0][ks], s[kb][0]);
+        s[kb][1] = mma<T>(a, qf[1][ks], s[kb][1]);
       }
     }
 #pragma unroll
@@ -386,14 +383,18 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) attn_fwd_kernel(cons
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // one v_cvt_pk_bf16_f32
-  union { bf16x2 v; uint32_t u; } c;
-  c.v = __builtin_convertvector(f32x2{a, b}, bf16x2);
-  return c.u;
+template <typename T> __device__ __forceinline__ uint32_t pack_h2(float a, float b) {  // one v_cvt_pk_{bf16,f16}_f32
+  if constexpr (ElemTraits<T>::DT == 2) {
+    return pack2<f16>(a, b);
+  } else {
+    union { bf16x2 v; uint32_t u; } c;
+    c.v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    return c.u;
+  }
 }
 // acc[dt] += Tile^T[d-tile dt][rows] * P with P already packed: lo / hi = the 4 bf16 of the two C tiles covering tile rows
 // [32 m2, 32 m2 + 16) and [32 m2 + 16, 32 m2 + 32)  (mma_transposed<bf16> without its conversions)
-template <int NDT>
+template <typename T, int NDT>
 __device__ __forceinline__ void mma_transposed_packed(const unsigned char* tile, int m2, uint2 lo, uint2 hi, f32x4 (&acc)[NDT], int lane) {
   const int i = lane & 15, q = lane >> 4, qq = i >> 2, pp = i & 3;
   union { struct { uint2 lo, hi; } s; bf16x8 v; } pb;
@@ -405,7 +406,7 @@ __device__ __forceinline__ void mma_transposed_packed(const unsigned char* tile,
     union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
     u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
     u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * AT<bf16>::RS));
-    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pb.v, acc[dt], 0, 0, 0);
+    acc[dt] = mfma16<T>(u.v, pb.v, acc[dt]);
   }
 }
 // Per-lane state of a wave that owns 32 keys (two 16-key C tiles, lane <-> key) and walks 16-query blocks: the dK/dV side of
@@ -442,7 +443,7 @@ struct KeyScore {
   }
   // q16 = first query of the 16-query block; lse4 / dl4 = log-sum-exp (log2 domain, +inf for rows past Tn) and delta of this
   // lane's four queries q16 + 4q .. 4q + 3
-  template <bool DROP>
+  template <typename T, bool DROP>
   __device__ __forceinline__ void block(int q16, const f32x4 (&s)[2], const f32x4 (&dp)[2], f32x4 lse4, f32x4 dl4, uint2 (&pdp)[2],
                                         uint2 (&dsp)[2]) const {
     uint32_t hw[2][4];  // [kt][e] hash words
@@ -475,8 +476,8 @@ struct KeyScore {
         pdv[e] = p * dsc;
         dsv[e] = (p * scale) * fmaf(dp[kt][e], dsc, -dl4[e]);
       }
-      pdp[kt] = make_uint2(pack_bf16x2(pdv[0], pdv[1]), pack_bf16x2(pdv[2], pdv[3]));
-      dsp[kt] = make_uint2(pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3]));
+      pdp[kt] = make_uint2(pack_h2<T>(pdv[0], pdv[1]), pack_h2<T>(pdv[2], pdv[3]));
+      dsp[kt] = make_uint2(pack_h2<T>(dsv[0], dsv[1]), pack_h2<T>(dsv[2], dsv[3]));
     }
   }
 };
@@ -572,8 +573,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const T* __restric
           const frag av = lfrag<T>(Vs, 16 * kb + r, ks, lane);
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
-            s[qt] = mma(ak, qf[qt][ks], s[qt]);
-            dp[qt] = mma(av, dof[qt][ks], dp[qt]);
+            s[qt] = mma<T>(ak, qf[qt][ks], s[qt]);
+            dp[qt] = mma<T>(av, dof[qt][ks], dp[qt]);
           }
         }
 #pragma unroll
@@ -715,19 +716,19 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
             const frag ao = lfrag<T>(Os, 16 * qb + r, ks, lane);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-              s[kt] = mma(aq, kf[kt][ks], s[kt]);
-              dp[kt] = mma(ao, vf[kt][ks], dp[kt]);
+              s[kt] = mma<T>(aq, kf[kt][ks], s[kt]);
+              dp[kt] = mma<T>(ao, vf[kt][ks], dp[kt]);
             }
           }
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(L2s + 16 * qb + 4 * q);
           const f32x4 dl = *reinterpret_cast<const f32x4*>(Dls + 16 * qb + 4 * q);
-          if (drop.p > 0.f) ksc.template block<true>(qt0 + 16 * qb, s, dp, l4, dl, pdp[half], dsp[half]);
-          else ksc.template block<false>(qt0 + 16 * qb, s, dp, l4, dl, pdp[half], dsp[half]);
+          if (drop.p > 0.f) ksc.template block<T, true>(qt0 + 16 * qb, s, dp, l4, dl, pdp[half], dsp[half]);
+          else ksc.template block<T, false>(qt0 + 16 * qb, s, dp, l4, dl, pdp[half], dsp[half]);
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-          mma_transposed_packed<NDT>(Os, m2, pdp[0][kt], pdp[1][kt], dv[kt], lane);
-          mma_transposed_packed<NDT>(Qs, m2, dsp[0][kt], dsp[1][kt], dk[kt], lane);
+          mma_transposed_packed<T, NDT>(Os, m2, pdp[0][kt], pdp[1][kt], dv[kt], lane);
+          mma_transposed_packed<T, NDT>(Qs, m2, dsp[0][kt], dsp[1][kt], dk[kt], lane);
         }
       }
     } else {
@@ -745,8 +746,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
           const frag ao = lfrag<T>(Os, 16 * qb + r, ks, lane);
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            s[kt] = mma(aq, kf[kt][ks], s[kt]);
-            dp[kt] = mma(ao, vf[kt][ks], dp[kt]);
+            s[kt] = mma<T>(aq, kf[kt][ks], s[kt]);
+            dp[kt] = mma<T>(ao, vf[kt][ks], dp[kt]);
           }
         }
 #pragma unroll
@@ -807,13 +808,12 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
 // buffered, so the step costs ONE barrier and the dQ MFMAs overlap the next step's exp / hash work.
 // LDS: 4 x (Q | dO | lse | delta) tiles 75,776 B + K 36,864 B + 2 x dS^T scratch 36,864 B = 149,504 B.
 constexpr int FUSED_SRS = 72;  // scratch row: 32 queries x 2 B + 8 B pad (conflict-free transposing reads)
-template <int NDT, bool DROP>
-__global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                             float* __restrict__ delta, bf16* __restrict__ dqkv,
+template <typename T, int NDT, bool DROP>
+__global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                             const T* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, T* __restrict__ dqkv,
                                                              const int* __restrict__ key_len, int B, int Tn, int H, int dh,
                                                              float scale, float scale_log2e, DropCfg drop) {
-  typedef bf16 T;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int RS = AT<T>::RS;
   constexpr int PAIR = 2 * 64 * RS + 512;  // Q tile | dO tile | 64 x LSE | 64 x delta
@@ -902,13 +902,13 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
         const frag ao = lfrag<T>(Os, 16 * qb + r, ks, lane);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-          s[kt] = mma(aq, kf[kt][ks], s[kt]);
-          dp[kt] = mma(ao, vf[kt][ks], dp[kt]);
+          s[kt] = mma<T>(aq, kf[kt][ks], s[kt]);
+          dp[kt] = mma<T>(ao, vf[kt][ks], dp[kt]);
         }
       }
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(L2s + 16 * qb + 4 * q);  // lse of queries 4q .. 4q + 3
       const f32x4 dl = *reinterpret_cast<const f32x4*>(Dls + 16 * qb + 4 * q);
-      ks_.template block<DROP>(st * 32 + 16 * half, s, dp, l4, dl, pdp[half], dsp[half]);
+      ks_.template block<T, DROP>(st * 32 + 16 * half, s, dp, l4, dl, pdp[half], dsp[half]);
       // dS^T block of this wave: row = key, 4 consecutive queries per lane
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -916,8 +916,8 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      mma_transposed_packed<NDT>(Os, m2, pdp[0][kt], pdp[1][kt], dv[kt], lane);
-      mma_transposed_packed<NDT>(Qs, m2, dsp[0][kt], dsp[1][kt], dk[kt], lane);
+      mma_transposed_packed<T, NDT>(Os, m2, pdp[0][kt], pdp[1][kt], dv[kt], lane);
+      mma_transposed_packed<T, NDT>(Qs, m2, dsp[0][kt], dsp[1][kt], dk[kt], lane);
     }
     __syncthreads();
     if (wave < 2 * NDT) {  // dQ^T tile (16 d x 16 queries) of this step: K^T [d][keys] . dS^T [keys][queries], all 256 key rows
@@ -935,8 +935,8 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const bf16* __restr
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};  // two chains: half the MFMA dependency latency
 #pragma unroll
       for (int kc = 0; kc < 8; kc += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua[kc].v, ub[kc].v, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua[kc + 1].v, ub[kc + 1].v, acc1, 0, 0, 0);
+        acc0 = mfma16<T>(ua[kc].v, ub[kc].v, acc0);
+        acc1 = mfma16<T>(ua[kc + 1].v, ub[kc + 1].v, acc1);
       }
       const int query = st * 32 + 16 * qb2 + r, d = 16 * dt + 4 * q;
       if (query < Tn && d < dh) {
@@ -1020,17 +1020,17 @@ int bwd_launch_t(const T* qkv, const T* out, const T* dout, const float* lse, fl
   FH_CHECK_LAUNCH();
   return 0;
 }
-template <int NDT>
-int bwd_fused_launch(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, float* delta, bf16* dqkv,
+template <typename T, int NDT>
+int bwd_fused_launch(const T* qkv, const T* out, const T* dout, const float* lse, float* delta, T* dqkv,
                      const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
   const size_t smem = 4 * (2 * 64 * AT<bf16>::RS + 512) + 256 * AT<bf16>::RS + 2 * 256 * FUSED_SRS;
   if (drop.p > 0.f) {
-    set_lds(attn_bwd_fused_kernel<NDT, true>, smem);
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NDT, true>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
+    set_lds(attn_bwd_fused_kernel<T, NDT, true>, smem);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, true>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
                        B, Tn, H, dh, scale, sl2, drop);
   } else {
-    set_lds(attn_bwd_fused_kernel<NDT, false>, smem);
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NDT, false>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
+    set_lds(attn_bwd_fused_kernel<T, NDT, false>, smem);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, false>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
                        B, Tn, H, dh, scale, sl2, drop);
   }
   FH_CHECK_LAUNCH();
@@ -1057,6 +1057,47 @@ int wide_waves(int res, int Tn, int max_nw = 16) {  // waves per workgroup: FH_A
 }
 }  // namespace
 
+// 16-bit launchers (T = bf16 | f16)
+namespace {
+template <typename T>
+int fwd16(const void* qkv, void* out, float* lse, const int* key_len, int B, int Tn, int H, int dh, float sl2, fh_drop drop, hipStream_t st) {
+  const T* q = (const T*)qkv;
+  // Workgroup width: 16 waves share one stream of K / V tiles, but at small batches the grid must still cover the chip -- halve
+  // the width while the launch has fewer workgroups than CUs (B = 4, T = 499: 48 workgroups of 16 waves -> 192 of 4)
+  int nw = wide_waves(1, Tn);
+  while (nw > 4 && (long)B * H * ((Tn + 32 * nw - 1) / (32 * nw)) < 256) nw >>= 1;
+  if (dh > 48) {  // 64-wide heads: the teacher (HuBERT Base 768 / 12, Large 1024 / 16), the ex.yaml student
+    switch (nw) {
+      case 16: return fwd_launch_t<T, 4, 16>(q, (T*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+      case 8: return fwd_launch_t<T, 4, 8>(q, (T*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+      default: return fwd_launch_t<T, 4, 4>(q, (T*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+    }
+  }
+  switch (nw) {
+    case 16: return fwd_launch_t<T, 3, 16>(q, (T*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+    case 8: return fwd_launch_t<T, 3, 8>(q, (T*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+    default: return fwd_launch_t<T, 3, 4>(q, (T*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
+  }
+}
+template <typename T>
+int bwd16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, const int* key_len, int B, int Tn,
+          int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
+  const int res = resident_tiles<T>(Tn);
+  const int nw = wide_waves(res, Tn, 8);  // the 16-wave backward builds spill under the 128-VGPR cap
+  const T *q = (const T*)qkv, *o = (const T*)out, *d = (const T*)dout;
+  if (res && Tn <= 256 && Tn > 64 && fused_bwd_enabled()) {
+    if (dh > 48) return bwd_fused_launch<T, 4>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+    return bwd_fused_launch<T, 3>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+  }
+  if (dh > 48) {
+    if (nw == 8) return bwd_launch_t<T, 4, 8>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+    return bwd_launch_t<T, 4, 4>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+  }
+  if (nw == 8) return bwd_launch_t<T, 3, 8>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+  return bwd_launch_t<T, 3, 4>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+}
+}  // namespace
+
 int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int Tn, int H,
                             int dh, float scale, fh_drop drop, hipStream_t st) {
   if (int rc = check_dims(dtype, H, dh, 64)) return rc;
@@ -1066,23 +1107,8 @@ int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, c
     if (dh > 48) return fwd_launch_t<float, 4, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
     return fwd_launch_t<float, 3, 4>(q, (float*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
   }
-  const bf16* q = (const bf16*)qkv;
-  // Workgroup width: 16 waves share one stream of K / V tiles, but at small batches the grid must still cover the chip -- halve
-  // the width while the launch has fewer workgroups than CUs (B = 4, T = 499: 48 workgroups of 16 waves -> 192 of 4)
-  int nw = wide_waves(1, Tn);
-  while (nw > 4 && (long)B * H * ((Tn + 32 * nw - 1) / (32 * nw)) < 256) nw >>= 1;
-  if (dh > 48) {  // 64-wide heads: the teacher (HuBERT Base 768 / 12, Large 1024 / 16), the ex.yaml student
-    switch (nw) {
-      case 16: return fwd_launch_t<bf16, 4, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
-      case 8: return fwd_launch_t<bf16, 4, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
-      default: return fwd_launch_t<bf16, 4, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
-    }
-  }
-  switch (nw) {
-    case 16: return fwd_launch_t<bf16, 3, 16>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
-    case 8: return fwd_launch_t<bf16, 3, 8>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
-    default: return fwd_launch_t<bf16, 3, 4>(q, (bf16*)out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
-  }
+  return dtype == 2 ? fwd16<f16>(qkv, out, lse, key_len, B, Tn, H, dh, sl2, drop, st)
+                    : fwd16<bf16>(qkv, out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
 }
 
 int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
@@ -1096,17 +1122,6 @@ int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const v
       return bwd_launch_t<float, 4, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
     return bwd_launch_t<float, 3, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
   }
-  const int res = resident_tiles<bf16>(Tn);
-  const int nw = wide_waves(res, Tn, 8);  // the 16-wave backward builds spill under the 128-VGPR cap
-  const bf16 *q = (const bf16*)qkv, *o = (const bf16*)out, *d = (const bf16*)dout;
-  if (res && Tn <= 256 && Tn > 64 && fused_bwd_enabled()) {
-    if (dh > 48) return bwd_fused_launch<4>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
-    return bwd_fused_launch<3>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
-  }
-  if (dh > 48) {
-    if (nw == 8) return bwd_launch_t<bf16, 4, 8>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-    return bwd_launch_t<bf16, 4, 4>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-  }
-  if (nw == 8) return bwd_launch_t<bf16, 3, 8>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-  return bwd_launch_t<bf16, 3, 4>(q, o, d, lse, delta, (bf16*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+  return dtype == 2 ? bwd16<f16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st)
+                    : bwd16<bf16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
 }

@@ -102,6 +102,12 @@ int fh_kd_loss_rows(int dtype, int teacher_dtype, const void* pred, const void* 
   return fh_kd_loss_rows_launch(dtype, teacher_dtype, pred, teacher, dpred, layer_w, teacher_layer, partials, out_losses, L,
                                 B, Tp, Tt, P, teacher_lstride, loss_type, rec_weight, sim_weight, ST(stream));
 }
+int fh_kd_loss_rows_scaled(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
+                           const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,
+                           long teacher_lstride, int loss_type, float rec_weight, float sim_weight, float grad_scale, fh_stream_t stream) {
+  return fh_kd_loss_rows_launch(dtype, teacher_dtype, pred, teacher, dpred, layer_w, teacher_layer, partials, out_losses, L,
+                                B, Tp, Tt, P, teacher_lstride, loss_type, rec_weight, sim_weight, ST(stream), grad_scale);
+}
 
 int fh_cast(int dtype, const float* src, void* dst, long n, fh_stream_t stream) {
   return fh_cast_launch(dtype, src, dst, n, ST(stream));
@@ -113,6 +119,11 @@ int fh_permute3_cast(int dtype, const float* src, void* dst, int d0, int d1, int
 int fh_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
              float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, fh_stream_t stream) {
   return fh_adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale, decay_mask, ST(stream));
+}
+
+int fh_adamw_amp(float* p, const float* g, float* m, float* v, long n, float lr_peak, int warmup_steps, int total_steps, float beta1,
+                 float beta2, float eps, float wd, float grad_scale, fh_amp_state* state, fh_stream_t stream) {
+  return fh_adamw_amp_launch(p, g, m, v, n, lr_peak, warmup_steps, total_steps, beta1, beta2, eps, wd, grad_scale, state, ST(stream));
 }
 
 int fh_conv1d_forward(int dtype, const void* x, const void* wf, const float* bias, void* y, int B, int T, int Cin, int Cout,

@@ -1,5 +1,6 @@
 // Common device helpers for the FitHuBERT gfx950 kernels.
-// Element type T is either float (exact-parity mode, f32 MFMA) or bf16 (bf16 MFMA, f32 accumulate).
+// Element type T is float (exact-parity mode, f32 MFMA), bf16 (bf16 MFMA, f32 accumulate) or f16 (IEEE half -- the reference's
+// own AMP dtype, train.py:469,496 -- on the f16 MFMA forms, which run at the bf16 rate; f32 accumulate).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -10,6 +11,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 #define FH_WAVE 64
 
@@ -28,12 +31,21 @@ template <> struct ElemTraits<bf16> {
   static constexpr int VEC = 8;
   static constexpr int DT = 1;
 };
+template <> struct ElemTraits<f16> {
+  static constexpr int VEC = 8;
+  static constexpr int DT = 2;
+};
+// dtype code -> element size / elements per 16 bytes (host side)
+static inline int fh_esize(int dtype) { return dtype == 0 ? 4 : 2; }
+static inline int fh_vec(int dtype) { return dtype == 0 ? 4 : 8; }
 
 __device__ __forceinline__ float to_f(float x) { return x; }
 __device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+__device__ __forceinline__ float to_f(f16 x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+template <> __device__ __forceinline__ f16 from_f<f16>(float x) { return (f16)x; }
 
 // 16-byte vector of T, as 4 dwords
 struct alignas(16) V16 {
@@ -60,9 +72,41 @@ template <> __device__ __forceinline__ void unpack16<bf16>(const V16& v, float* 
     f[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u);
   }
 }
+template <> __device__ __forceinline__ void unpack16<f16>(const V16& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    union { uint32_t u; f16 h[2]; } c;
+    c.u = v.w[i];
+    f[2 * i] = (float)c.h[0];
+    f[2 * i + 1] = (float)c.h[1];
+  }
+}
 __device__ __forceinline__ uint32_t bf16_bits(float x) {
   bf16 b = (bf16)x;
   return (uint32_t) * reinterpret_cast<uint16_t*>(&b);
+}
+// two floats -> one dword of 16-bit elements of type T (round to nearest even), low half first
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2<bf16>(float a, float b) { return bf16_bits(a) | (bf16_bits(b) << 16); }
+template <> __device__ __forceinline__ uint32_t pack2<f16>(float a, float b) {
+  union { uint32_t u; f16 h[2]; } c;
+  c.h[0] = (f16)a;
+  c.h[1] = (f16)b;
+  return c.u;
+}
+// 16 x 16 x 32 and 32 x 32 x 16 MFMA on 16-bit operands of type T (fragments travel as opaque 16-byte vectors typed bf16x8)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <typename T> __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (ElemTraits<T>::DT == 2)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ f32x16_t mfma32(const bf16x8& a, const bf16x8& b, const f32x16_t& c) {
+  if constexpr (ElemTraits<T>::DT == 2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 template <typename T> __device__ __forceinline__ V16 pack16(const float* f);
 template <> __device__ __forceinline__ V16 pack16<float>(const float* f) {
@@ -77,6 +121,12 @@ template <> __device__ __forceinline__ V16 pack16<bf16>(const float* f) {
   for (int i = 0; i < 4; ++i) v.w[i] = bf16_bits(f[2 * i]) | (bf16_bits(f[2 * i + 1]) << 16);
   return v;
 }
+template <> __device__ __forceinline__ V16 pack16<f16>(const float* f) {
+  V16 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v.w[i] = pack2<f16>(f[2 * i], f[2 * i + 1]);
+  return v;
+}
 
 // load / store 4 consecutive T elements as floats (8 B for bf16, 16 B for float)
 __device__ __forceinline__ void ld4(const float* p, float* f) {
@@ -89,6 +139,18 @@ __device__ __forceinline__ void ld4(const bf16* p, float* f) {
   f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16);
   f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void ld4(const f16* p, float* f) {
+  union { uint2 v; f16 h[4]; } c;
+  c.v = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = (float)c.h[i];
+}
+__device__ __forceinline__ void st4(f16* p, const float* f) {
+  uint2 v;
+  v.x = pack2<f16>(f[0], f[1]);
+  v.y = pack2<f16>(f[2], f[3]);
+  *reinterpret_cast<uint2*>(p) = v;
 }
 __device__ __forceinline__ void st4(float* p, const float* f) {
   *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);

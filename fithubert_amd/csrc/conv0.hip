@@ -345,6 +345,7 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
   static const bool wide_env = getenv("FH_CONV0_WIDE") && getenv("FH_CONV0_WIDE")[0] == '1';
   const bool wide = wide_env && C0 / 8 <= 256 && 256 % (C0 / 8) == 0;
   if (dtype == 0) { if (K == 10) FH_C0_APPLY(float, 10, 4); else FH_C0_APPLY(float, MAXK, 4); }
+  else if (dtype == 2) { if (K == 10) FH_C0_APPLY(f16, 10, 4); else FH_C0_APPLY(f16, MAXK, 4); }
   else if (wide) { if (K == 10) FH_C0_APPLY(bf16, 10, 8); else FH_C0_APPLY(bf16, MAXK, 8); }
   else { if (K == 10) FH_C0_APPLY(bf16, 10, 4); else FH_C0_APPLY(bf16, MAXK, 4); }
 #undef FH_C0_APPLY
@@ -375,6 +376,7 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
 #define FH_C0_WG(T, KT) \
   hipLaunchKernelGGL((conv0_bwd_onepass_kernel<T, KT>), wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (const T*)dy, wpart)
   if (dtype == 0) { if (K == 10) FH_C0_WG(float, 10); else FH_C0_WG(float, MAXK); }
+  else if (dtype == 2) { if (K == 10) FH_C0_WG(f16, 10); else FH_C0_WG(f16, MAXK); }
   else { if (K == 10) FH_C0_WG(bf16, 10); else FH_C0_WG(bf16, MAXK); }
 #undef FH_C0_WG
   FH_CHECK_LAUNCH();

@@ -70,6 +70,74 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---- fp16 mode (the reference's AMP, train.py:469,496: GradScaler): the gradients carry a loss scale, a step whose gradient holds a
+// non-finite value is skipped.  Detection, the skip and the step bookkeeping are device side (fh_amp_state), so no host sync:
+//   amp_check   : found_inf |= any non-finite element of the flat gradient
+//   amp_prepare : lr (linear warm-up / linear decay, distill.py lr_at) and the Adam bias corrections of step good_steps + 1
+//   adamw_dev   : the AdamW update with those scalars read from the state; a no-op when found_inf
+//   amp_update  : good_steps++ or skipped++, found_inf = 0
+__global__ void amp_check_kernel(const float* __restrict__ g, long n, fh_amp_state* __restrict__ st) {
+  bool bad = false;
+  for (long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < n; i4 += (long)gridDim.x * blockDim.x * 4) {
+    if (i4 + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i4);
+      // x - x is 0 for finite x and NaN for inf / NaN
+      const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+      bad |= !(t == 0.f);
+    } else {
+      for (long i = i4; i < n; ++i) bad |= !((g[i] - g[i]) == 0.f);
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->found_inf, 1);
+}
+__global__ void amp_prepare_kernel(fh_amp_state* st, float lr_peak, int warm, int total, float b1, float b2) {
+  const int t = st->good_steps + 1, step = t - 1;
+  double lr = lr_peak;
+  if (total > 0) {
+    const int w = warm > 1 ? warm : 1;
+    if (step < w) lr = (double)lr_peak * (step + 1) / w;
+    else {
+      const int den = total - w > 1 ? total - w : 1;
+      const double f = (double)(total - step) / den;
+      lr = (double)lr_peak * (f > 0.0 ? f : 0.0);
+    }
+  }
+  st->lr = (float)lr;
+  st->bc1 = (float)(1.0 - pow((double)b1, (double)t));
+  st->bc2 = (float)(1.0 - pow((double)b2, (double)t));
+}
+__global__ void amp_update_kernel(fh_amp_state* st) {
+  if (st->found_inf) st->skipped += 1; else st->good_steps += 1;
+  st->found_inf = 0;
+}
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                 float b1, float b2, float eps, float wd, float gscale, const fh_amp_state* __restrict__ st) {
+  if (st->found_inf) return;
+  const float lr = st->lr, bc1 = st->bc1, bc2 = st->bc2;
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const int cnt = (int)min((long)4, n - i4);
+  float pv[4], gv[4], mv[4], vv[4];
+  if (cnt == 4) {
+    ld4(p + i4, pv); ld4(g + i4, gv); ld4(m + i4, mv); ld4(v + i4, vv);
+  } else {
+    for (int e = 0; e < cnt; ++e) { pv[e] = p[i4 + e]; gv[e] = g[i4 + e]; mv[e] = m[i4 + e]; vv[e] = v[i4 + e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gr = gv[e] * gscale;
+    mv[e] = b1 * mv[e] + (1.f - b1) * gr;
+    vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+    const float mh = mv[e] / bc1, vh = vv[e] / bc2;
+    pv[e] -= lr * (mh / (sqrtf(vh) + eps) + wd * pv[e]);
+  }
+  if (cnt == 4) {
+    st4(p + i4, pv); st4(m + i4, mv); st4(v + i4, vv);
+  } else {
+    for (int e = 0; e < cnt; ++e) { p[i4 + e] = pv[e]; m[i4 + e] = mv[e]; v[i4 + e] = vv[e]; }
+  }
+}
+
 // dst = src * gelu'(aux) * scale   (factor != 0: aux already holds gelu' -- the forward saved it, fh_gemm_epilogue.aux_factor)
 template <typename T>
 __global__ void mul_gelu_grad_kernel(const T* __restrict__ src, const T* __restrict__ aux, T* __restrict__ dst, long nvec,
@@ -158,6 +226,8 @@ int fh_unary_launch(int dtype, const void* src, void* dst, long n, int mode, hip
   dim3 grid((unsigned)min((long)4096, (nvec + 255) / 256)), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(unary_kernel<float>, grid, block, 0, st, (const float*)src, (float*)dst, nvec, mode);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(unary_kernel<f16>, grid, block, 0, st, (const f16*)src, (f16*)dst, nvec, mode);
   else
     hipLaunchKernelGGL(unary_kernel<bf16>, grid, block, 0, st, (const bf16*)src, (bf16*)dst, nvec, mode);
   FH_CHECK_LAUNCH();
@@ -174,6 +244,9 @@ int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* d
   if (dtype == 0)
     hipLaunchKernelGGL(mul_gelu_grad_kernel<float>, grid, block, 0, st, (const float*)src, (const float*)aux, (float*)dst,
                        nvec, scale, factor);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(mul_gelu_grad_kernel<f16>, grid, block, 0, st, (const f16*)src, (const f16*)aux, (f16*)dst, nvec,
+                       scale, factor);
   else
     hipLaunchKernelGGL(mul_gelu_grad_kernel<bf16>, grid, block, 0, st, (const bf16*)src, (const bf16*)aux, (bf16*)dst, nvec,
                        scale, factor);
@@ -191,6 +264,8 @@ int fh_mask_drop_launch(int dtype, const void* src, void* dst, long rows, int C,
   if (dtype == 0)
     hipLaunchKernelGGL(mask_drop_kernel<float>, grid, block, 0, st, (const float*)src, (float*)dst, rows, C, rpb, row_len,
                        drop);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(mask_drop_kernel<f16>, grid, block, 0, st, (const f16*)src, (f16*)dst, rows, C, rpb, row_len, drop);
   else
     hipLaunchKernelGGL(mask_drop_kernel<bf16>, grid, block, 0, st, (const bf16*)src, (bf16*)dst, rows, C, rpb, row_len, drop);
   FH_CHECK_LAUNCH();
@@ -202,6 +277,8 @@ int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t s
   dim3 grid((unsigned)((n / 4 + 1 + 255) / 256)), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(cast_kernel<float>, grid, block, 0, st, src, (float*)dst, n);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(cast_kernel<f16>, grid, block, 0, st, src, (f16*)dst, n);
   else
     hipLaunchKernelGGL(cast_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, n);
   FH_CHECK_LAUNCH();
@@ -215,6 +292,8 @@ int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int 
   dim3 grid((unsigned)((n + 255) / 256), groups), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(permute3_kernel<float>, grid, block, 0, st, src, (float*)dst, d0, d1, d2, p0, p1, p2, src_gstride, dst_gstride);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(permute3_kernel<f16>, grid, block, 0, st, src, (f16*)dst, d0, d1, d2, p0, p1, p2, src_gstride, dst_gstride);
   else
     hipLaunchKernelGGL(permute3_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, d0, d1, d2, p0, p1, p2, src_gstride, dst_gstride);
   FH_CHECK_LAUNCH();
@@ -227,6 +306,21 @@ int fh_adamw_launch(float* p, const float* g, float* m, float* v, long n, float 
   dim3 grid((unsigned)(((n + 3) / 4 + 255) / 256)), block(256);
   hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale,
                      decay_mask);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_adamw_amp_launch(float* p, const float* g, float* m, float* v, long n, float lr_peak, int warmup_steps, int total_steps,
+                        float beta1, float beta2, float eps, float wd, float grad_scale, fh_amp_state* state, hipStream_t st) {
+  if (n <= 0 || !state) return n <= 0 ? 0 : -703;
+  hipLaunchKernelGGL(amp_check_kernel, dim3(2048), dim3(256), 0, st, g, n, state);
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(amp_prepare_kernel, dim3(1), dim3(1), 0, st, state, lr_peak, warmup_steps, total_steps, beta1, beta2);
+  FH_CHECK_LAUNCH();
+  dim3 grid((unsigned)(((n + 3) / 4 + 255) / 256)), block(256);
+  hipLaunchKernelGGL(adamw_dev_kernel, grid, block, 0, st, p, g, m, v, n, beta1, beta2, eps, wd, grad_scale, state);
+  FH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, st, state);
   FH_CHECK_LAUNCH();
   return 0;
 }

@@ -91,14 +91,15 @@ struct LayerTArgs {
   int rows[4], cols[4];         // of the source matrix [rows][cols]
   long src_stride, dst_stride, src0;
 };
-__global__ void __launch_bounds__(256) layer_transpose_kernel(const float* __restrict__ params, bf16* __restrict__ dst, LayerTArgs a) {
+template <typename H>
+__global__ void __launch_bounds__(256) layer_transpose_kernel(const float* __restrict__ params, H* __restrict__ dst, LayerTArgs a) {
   __shared__ float tile[32][33];
   const int l = blockIdx.z >> 2, m = blockIdx.z & 3;
   const int R = a.rows[m], C = a.cols[m];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   if (c0 >= C || r0 >= R) return;
   const float* src = params + a.src0 + (long)l * a.src_stride + a.src_off[m];
-  bf16* out = dst + (long)l * a.dst_stride + a.dst_off[m];
+  H* out = dst + (long)l * a.dst_stride + a.dst_off[m];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256) layer_transpose_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (c < C && r < R) out[(long)c * R + r] = (bf16)tile[tx][ty + 8 * i];
+    if (c < C && r < R) out[(long)c * R + r] = from_f<H>(tile[tx][ty + 8 * i]);
   }
 }
 
@@ -443,7 +444,7 @@ struct Plan {
 };
 
 inline int validate(const fh_student_config& c) {
-  if (c.dtype != 0 && c.dtype != 1) return -810;
+  if (c.dtype < 0 || c.dtype > 2) return -810;
   if (c.n_conv < 1 || c.n_conv > FH_MAX_CONV) return -811;
   if (c.conv_k[0] > 16) return -812;
   const int vec = c.dtype == 0 ? 4 : 8;
@@ -649,8 +650,12 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
     a.src_off[2] = p.pl.l_fc1_w; a.dst_off[2] = p.wl.t_fc1; a.rows[2] = Fd;    a.cols[2] = D;
     a.src_off[3] = p.pl.l_fc2_w; a.dst_off[3] = p.wl.t_fc2; a.rows[3] = D;     a.cols[3] = Fd;
     const int maxc = D > Fd ? D : Fd, maxr = 3 * D > Fd ? 3 * D : Fd;
-    hipLaunchKernelGGL(layer_transpose_kernel, dim3((maxc + 31) / 32, (maxr + 31) / 32, c.layers * 4), dim3(256), 0, st, params,
-                       (bf16*)(wc + p.wl.layT), a);
+    if (dt == 2)
+      hipLaunchKernelGGL(layer_transpose_kernel<f16>, dim3((maxc + 31) / 32, (maxr + 31) / 32, c.layers * 4), dim3(256), 0, st, params,
+                         (f16*)(wc + p.wl.layT), a);
+    else
+      hipLaunchKernelGGL(layer_transpose_kernel<bf16>, dim3((maxc + 31) / 32, (maxr + 31) / 32, c.layers * 4), dim3(256), 0, st, params,
+                         (bf16*)(wc + p.wl.layT), a);
     FH_CHECK_LAUNCH();
   }
   return 0;

@@ -54,7 +54,7 @@ int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void
 int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
                            const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L,
                            int B, int Tp, int Tt, int P, long teacher_lstride, int loss_type, float rec_weight,
-                           float sim_weight, hipStream_t st);
+                           float sim_weight, hipStream_t st, float grad_scale = 1.0f);  // grad_scale: on dpred only (loss scaling)
 
 // ---- elementwise.hip
 int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t st);
@@ -62,6 +62,8 @@ int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int 
                             hipStream_t st, int groups = 1, long src_gstride = 0, long dst_gstride = 0);  // strides in elements
 int fh_adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                     float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, hipStream_t st);
+int fh_adamw_amp_launch(float* p, const float* g, float* m, float* v, long n, float lr_peak, int warmup_steps, int total_steps,
+                        float beta1, float beta2, float eps, float wd, float grad_scale, fh_amp_state* state, hipStream_t st);
 int fh_unary_launch(int dtype, const void* src, void* dst, long n, int mode, hipStream_t st);  // 0: dst = gelu(src), 1: dst += src
 int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* dst, long n, float scale, hipStream_t st,
                             int factor = 0);

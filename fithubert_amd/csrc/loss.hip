@@ -21,6 +21,8 @@ template <> __device__ __forceinline__ void load_teacher<float, 8>(const float* 
   ld4(p, f);
   ld4(p + 4, f + 4);
 }
+template <> __device__ __forceinline__ void load_teacher<f16, 4>(const f16* p, float* f) { ld4(p, f); }
+template <> __device__ __forceinline__ void load_teacher<f16, 8>(const f16* p, float* f) { unpack16<f16>(ld16(p), f); }
 template <> __device__ __forceinline__ void load_teacher<bf16, 4>(const bf16* p, float* f) { ld4(p, f); }
 template <> __device__ __forceinline__ void load_teacher<bf16, 8>(const bf16* p, float* f) {
   unpack16<bf16>(ld16(p), f);
@@ -246,10 +248,16 @@ int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void
 #define FH_LAUNCH_LOSS(T, TT)                                                                                       \
   hipLaunchKernelGGL((kd_loss_kernel<T, TT>), grid, block, 0, st, (const T*)pred, (const TT*)teacher, (T*)dpred,     \
                      layer_w, teacher_layer, partials, B, Tp, Tt, P, teacher_lstride, loss_type, grad_scale, nblk)
-  if (dtype == 0 && teacher_dtype == 0) FH_LAUNCH_LOSS(float, float);
-  else if (dtype == 0) FH_LAUNCH_LOSS(float, bf16);
-  else if (teacher_dtype == 0) FH_LAUNCH_LOSS(bf16, float);
-  else FH_LAUNCH_LOSS(bf16, bf16);
+#define FH_LOSS_T(T)                                        \
+  do {                                                      \
+    if (teacher_dtype == 0) FH_LAUNCH_LOSS(T, float);       \
+    else if (teacher_dtype == 2) FH_LAUNCH_LOSS(T, f16);    \
+    else FH_LAUNCH_LOSS(T, bf16);                           \
+  } while (0)
+  if (dtype == 0) FH_LOSS_T(float);
+  else if (dtype == 2) FH_LOSS_T(f16);
+  else FH_LOSS_T(bf16);
+#undef FH_LOSS_T
 #undef FH_LAUNCH_LOSS
   FH_CHECK_LAUNCH();
   hipLaunchKernelGGL(kd_loss_final_kernel, dim3(1), dim3(256), 0, st, partials, layer_w, out_losses, L, nblk,
@@ -263,7 +271,7 @@ extern "C" int fh_kd_loss_rows_nblk(int B, int Tp) { return (int)(((long)B * Tp 
 int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
                            const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L,
                            int B, int Tp, int Tt, int P, long teacher_lstride, int loss_type, float rec_weight,
-                           float sim_weight, hipStream_t st) {
+                           float sim_weight, hipStream_t st, float grad_scale) {
   const int vec = dtype == 0 ? 4 : 8;
   if (P % 8 || Tp > Tt) return -401;
   const int nch = (P / vec + 63) / 64;
@@ -272,14 +280,21 @@ int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const
   dim3 grid(nblk, L), block(256);
 #define FH_LAUNCH_ROWS(T, TT, N)                                                                                       \
   hipLaunchKernelGGL((kd_loss_rows_kernel<T, TT, N>), grid, block, 0, st, (const T*)pred, (const TT*)teacher, (T*)dpred, \
-                     layer_w, teacher_layer, partials, B, Tp, Tt, P, teacher_lstride, loss_type, rec_weight, sim_weight, nblk)
+                     layer_w, teacher_layer, partials, B, Tp, Tt, P, teacher_lstride, loss_type, rec_weight * grad_scale, \
+                     sim_weight * grad_scale, nblk)
 #define FH_ROWS_N(T, TT)                    \
   if (nch <= 2) FH_LAUNCH_ROWS(T, TT, 2);   \
   else FH_LAUNCH_ROWS(T, TT, 4)
-  if (dtype == 0 && teacher_dtype == 0) { FH_ROWS_N(float, float); }
-  else if (dtype == 0) { FH_ROWS_N(float, bf16); }
-  else if (teacher_dtype == 0) { FH_ROWS_N(bf16, float); }
-  else { FH_ROWS_N(bf16, bf16); }
+#define FH_ROWS_T(T)                                     \
+  do {                                                   \
+    if (teacher_dtype == 0) { FH_ROWS_N(T, float); }     \
+    else if (teacher_dtype == 2) { FH_ROWS_N(T, f16); }  \
+    else { FH_ROWS_N(T, bf16); }                         \
+  } while (0)
+  if (dtype == 0) FH_ROWS_T(float);
+  else if (dtype == 2) FH_ROWS_T(f16);
+  else FH_ROWS_T(bf16);
+#undef FH_ROWS_T
 #undef FH_ROWS_N
 #undef FH_LAUNCH_ROWS
   FH_CHECK_LAUNCH();

@@ -331,6 +331,7 @@ int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const 
                             float* rstd, int M, int C, float eps, fh_drop drop, hipStream_t st) {
   if (M <= 0) return 0;
   return dtype == 0 ? ln_fwd_t<float>((const float*)x, gamma, beta, (float*)y, mean, rstd, M, C, eps, drop, st)
+                    : dtype == 2 ? ln_fwd_t<f16>((const f16*)x, gamma, beta, (f16*)y, mean, rstd, M, C, eps, drop, st)
                     : ln_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, C, eps, drop, st);
 }
 
@@ -339,6 +340,7 @@ int fh_add_layernorm_fwd_launch(int dtype, const void* x, const void* res, const
   if (M <= 0) return 0;
   fh_drop nodrop{0.f, 0u, 0u};
   return dtype == 0 ? ln_fwd_t<float>((const float*)x, gamma, beta, (float*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const float*)res, gelu)
+                    : dtype == 2 ? ln_fwd_t<f16>((const f16*)x, gamma, beta, (f16*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const f16*)res, gelu)
                     : ln_fwd_t<bf16>((const bf16*)x, gamma, beta, (bf16*)y, nullptr, nullptr, M, C, eps, nodrop, st, (const bf16*)res, gelu);
 }
 
@@ -348,6 +350,8 @@ int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const vo
   if (M <= 0) return 0;
   return dtype == 0 ? ln_bwd_t<float>((const float*)dy, (const float*)dy2, (const float*)x, mean, rstd, gamma,
                                       (float*)dx, (float*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st)
+                    : dtype == 2 ? ln_bwd_t<f16>((const f16*)dy, (const f16*)dy2, (const f16*)x, mean, rstd, gamma, (f16*)dx,
+                                     (f16*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st)
                     : ln_bwd_t<bf16>((const bf16*)dy, (const bf16*)dy2, (const bf16*)x, mean, rstd, gamma, (bf16*)dx,
                                      (bf16*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st);
 }
@@ -360,6 +364,9 @@ int fh_colsum_launch(int dtype, const void* X, float* out, int M, int N, long ld
   dim3 grid((N / vec + 63) / 64, (M + 511) / 512, groups), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)X, out, M, N, ldx, x_gstride, out_gstride,
+                       mod, scale);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(colsum_kernel<f16>, grid, block, 0, st, (const f16*)X, out, M, N, ldx, x_gstride, out_gstride,
                        mod, scale);
   else
     hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, st, (const bf16*)X, out, M, N, ldx, x_gstride, out_gstride,
@@ -376,6 +383,8 @@ int fh_zero_rows_launch(int dtype, void* x, int B, int Tn, int C, int from, hipS
   dim3 grid((unsigned)min((long)2048, (total + 255) / 256)), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(zero_rows_kernel<float>, grid, block, 0, st, (float*)x, B, Tn, C, from);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(zero_rows_kernel<f16>, grid, block, 0, st, (f16*)x, B, Tn, C, from);
   else
     hipLaunchKernelGGL(zero_rows_kernel<bf16>, grid, block, 0, st, (bf16*)x, B, Tn, C, from);
   FH_CHECK_LAUNCH();

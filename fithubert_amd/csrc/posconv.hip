@@ -88,19 +88,16 @@ __global__ void wn_layout_kernel(const float* __restrict__ gsc, const float* __r
 }
 
 // ---------------------------------------------------------------- fragment helpers
-template <typename T, int CP> struct Frag;
-template <int CP> struct Frag<bf16, CP> {
+template <typename T, int CP> struct Frag {  // 16-bit element types (bf16 / f16)
   typedef bf16x8 type;
   static constexpr int NK = CP / 32;  // fragment loads per group reduction (32 channels each)
   static __device__ __forceinline__ type lds_row(const unsigned char* lds, int row, int lane, int kr) {
-    return *reinterpret_cast<const bf16x8*>(lds + row * PC<bf16, CP>::RS + kr * 64 + (lane >> 4) * 16);
+    return *reinterpret_cast<const bf16x8*>(lds + row * PC<T, CP>::RS + kr * 64 + (lane >> 4) * 16);
   }
-  static __device__ __forceinline__ type gmem_frag(const bf16* wtap, int cb, int lane, int kr) {  // fragment-order layout
+  static __device__ __forceinline__ type gmem_frag(const T* wtap, int cb, int lane, int kr) {  // fragment-order layout
     return *reinterpret_cast<const bf16x8*>(wtap + ((kr * (CP / 16) + cb) * 64 + lane) * 8);
   }
-  static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
+  static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) { return mfma16<T>(a, b, c); }
 };
 template <int CP> struct Frag<float, CP> {
   typedef f32x4 type;
@@ -127,6 +124,13 @@ __device__ __forceinline__ void ld2(const bf16* p, float* f) {
   f[0] = __uint_as_float(v << 16);
   f[1] = __uint_as_float(v & 0xffff0000u);
 }
+__device__ __forceinline__ void ld2(const f16* p, float* f) {
+  union { uint32_t u; f16 h[2]; } c;
+  c.u = *reinterpret_cast<const uint32_t*>(p);
+  f[0] = (float)c.h[0];
+  f[1] = (float)c.h[1];
+}
+__device__ __forceinline__ void st2(f16* p, const float* f) { *reinterpret_cast<uint32_t*>(p) = pack2<f16>(f[0], f[1]); }
 __device__ __forceinline__ void st2(float* p, const float* f) { *reinterpret_cast<float2*>(p) = make_float2(f[0], f[1]); }
 __device__ __forceinline__ void st2(bf16* p, const float* f) {
   *reinterpret_cast<uint32_t*>(p) = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int ib = 0; ib < CB; ++ib)
-              acc[jj][cb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], fb[ib], acc[jj][cb][ib], 0, 0, 0);
+              acc[jj][cb][ib] = mfma16<T>(fa[cb], fb[ib], acc[jj][cb][ib]);
         }
       }
     } else {
@@ -499,8 +503,10 @@ int fh_posconv_prep_launch(int dtype, const float* g, const float* v, void* w_fw
   hipLaunchKernelGGL(wn_norm2_final_kernel, dim3((K + 127) / 128), dim3(128), 0, st, (const float*)w_bwd, norm2, WN_NB, K);
   FH_CHECK_LAUNCH();
   if (cp == 32) return dtype == 0 ? prep_t<float, 32>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st)
+                                  : dtype == 2 ? prep_t<f16, 32>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st)
                                   : prep_t<bf16, 32>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st);
   return dtype == 0 ? prep_t<float, 64>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st)
+                    : dtype == 2 ? prep_t<f16, 64>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st)
                     : prep_t<bf16, 64>(g, v, norm2, w_fwd, w_bwd, norm, groups, cg, K, st);
 }
 
@@ -509,8 +515,10 @@ int fh_posconv_fwd_launch(int dtype, const void* x, const void* w_fwd, const flo
   const int cg = D / groups, cp = fh_posconv_cp(cg);
   if (!cp || cg % 2 || K % 2) return -501;
   if (cp == 32) return dtype == 0 ? conv_t<float, 32, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st)
+                                  : dtype == 2 ? conv_t<f16, 32, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st)
                                   : conv_t<bf16, 32, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st);
   return dtype == 0 ? conv_t<float, 64, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st)
+                    : dtype == 2 ? conv_t<f16, 64, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st)
                     : conv_t<bf16, 64, false>(x, nullptr, w_fwd, bias, zc, y, B, Tn, D, groups, K, K / 2, st);
 }
 
@@ -520,8 +528,10 @@ int fh_posconv_bwd_data_launch(int dtype, const void* dsum, const void* zc, cons
   if (!cp || cg % 2 || K % 2) return -501;
   const int pl = K - 1 - K / 2;
   if (cp == 32) return dtype == 0 ? conv_t<float, 32, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st)
+                                  : dtype == 2 ? conv_t<f16, 32, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st)
                                   : conv_t<bf16, 32, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st);
   return dtype == 0 ? conv_t<float, 64, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st)
+                    : dtype == 2 ? conv_t<f16, 64, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st)
                     : conv_t<bf16, 64, true>(dsum, zc, w_bwd, nullptr, dzc, dx, B, Tn, D, groups, K, pl, st);
 }
 
@@ -530,9 +540,9 @@ int fh_posconv_bwd_weight_launch(int dtype, const void* dzc, const void* x, floa
   const int cg = D / groups, cp = fh_posconv_cp(cg);
   if (!cp || cg % 2 || K % 32) return -501;
   int rc;
-  if (cp == 32) rc = dtype == 0 ? wgrad_t<float, 32, 2, 8>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 32, 2, 8>(dzc, x, dws, B, Tn, D, groups, K, st);
-  else if (cg <= 48) rc = dtype == 0 ? wgrad_t<float, 64, 3, 4>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64, 3, 4>(dzc, x, dws, B, Tn, D, groups, K, st);
-  else rc = dtype == 0 ? wgrad_t<float, 64, 4, 2>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64, 4, 2>(dzc, x, dws, B, Tn, D, groups, K, st);
+  if (cp == 32) rc = dtype == 0 ? wgrad_t<float, 32, 2, 8>(dzc, x, dws, B, Tn, D, groups, K, st) : dtype == 2 ? wgrad_t<f16, 32, 2, 8>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 32, 2, 8>(dzc, x, dws, B, Tn, D, groups, K, st);
+  else if (cg <= 48) rc = dtype == 0 ? wgrad_t<float, 64, 3, 4>(dzc, x, dws, B, Tn, D, groups, K, st) : dtype == 2 ? wgrad_t<f16, 64, 3, 4>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64, 3, 4>(dzc, x, dws, B, Tn, D, groups, K, st);
+  else rc = dtype == 0 ? wgrad_t<float, 64, 4, 2>(dzc, x, dws, B, Tn, D, groups, K, st) : dtype == 2 ? wgrad_t<f16, 64, 4, 2>(dzc, x, dws, B, Tn, D, groups, K, st) : wgrad_t<bf16, 64, 4, 2>(dzc, x, dws, B, Tn, D, groups, K, st);
   if (rc) return rc;
   if (dbias) return fh_colsum_launch(dtype, dzc, dbias, B * Tn, D, D, 1, 0, 0, 0, 1.0f, st);
   return 0;

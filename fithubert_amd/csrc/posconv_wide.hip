@@ -63,6 +63,13 @@ __device__ __forceinline__ void ld2w(const bf16* p, float* f) {
   f[0] = __uint_as_float(v << 16);
   f[1] = __uint_as_float(v & 0xffff0000u);
 }
+__device__ __forceinline__ void ld2w(const f16* p, float* f) {
+  union { uint32_t u; f16 h[2]; } c;
+  c.u = *reinterpret_cast<const uint32_t*>(p);
+  f[0] = (float)c.h[0];
+  f[1] = (float)c.h[1];
+}
+__device__ __forceinline__ void st2w(f16* p, const float* f) { *reinterpret_cast<uint32_t*>(p) = pack2<f16>(f[0], f[1]); }
 __device__ __forceinline__ void st2w(float* p, const float* f) { *reinterpret_cast<float2*>(p) = make_float2(f[0], f[1]); }
 __device__ __forceinline__ void st2w(bf16* p, const float* f) {
   *reinterpret_cast<uint32_t*>(p) = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
             if (cb < ncb) {
 #pragma unroll
               for (int tt = 0; tt < NTT; ++tt)
-                acc[cb][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[u][ks][cb], xf[tt], acc[cb][tt], 0, 0, 0);
+                acc[cb][tt] = mfma16<T>(wr[u][ks][cb], xf[tt], acc[cb][tt]);
             }
           }
         }
@@ -190,6 +197,9 @@ extern "C" int fh_posconv_wide_prepare(int dtype, const float* g, const float* v
   if (dtype == 0)
     hipLaunchKernelGGL(wnw_layout_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2, (float*)w_fwd,
                        groups, cg, K);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(wnw_layout_kernel<f16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2, (f16*)w_fwd,
+                       groups, cg, K);
   else
     hipLaunchKernelGGL(wnw_layout_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2, (bf16*)w_fwd,
                        groups, cg, K);
@@ -218,6 +228,8 @@ extern "C" int fh_posconv_wide_forward(int dtype, const void* x, const void* w_f
                        cg, K, K / 2);                                                                                        \
   } while (0)
   if (dtype == 0) FH_PW_LAUNCH(float, 4);
+  else if (dtype == 2 && ntt == 8) FH_PW_LAUNCH(f16, 8);
+  else if (dtype == 2) FH_PW_LAUNCH(f16, 4);
   else if (ntt == 8) FH_PW_LAUNCH(bf16, 8);
   else FH_PW_LAUNCH(bf16, 4);
 #undef FH_PW_LAUNCH

@@ -362,10 +362,16 @@ static int relation_launch(int dtype, int teacher_dtype, const RelArgs& a, hipSt
     }                                                                                                                        \
     hipLaunchKernelGGL((relation_kd_kernel<TS, TT>), grid, block, smem, st, a);                                              \
   } while (0)
-  if (dtype == 0 && teacher_dtype == 0) FH_REL(float, float);
-  else if (dtype == 0) FH_REL(float, bf16);
-  else if (teacher_dtype == 0) FH_REL(bf16, float);
-  else FH_REL(bf16, bf16);
+#define FH_REL_T(TS)                                  \
+  do {                                                \
+    if (teacher_dtype == 0) FH_REL(TS, float);        \
+    else if (teacher_dtype == 2) FH_REL(TS, f16);     \
+    else FH_REL(TS, bf16);                            \
+  } while (0)
+  if (dtype == 0) FH_REL_T(float);
+  else if (dtype == 2) FH_REL_T(f16);
+  else FH_REL_T(bf16);
+#undef FH_REL_T
 #undef FH_REL
   FH_CHECK_LAUNCH();
   return 0;

@@ -59,15 +59,25 @@ def _make_low_priority_stream(device: torch.device) -> "torch.cuda.Stream":
 
 
 class W2V2Distil:
-    def __init__(self, cfg: dict, dtype: str = "bf16", device: str = "cuda", teacher: Optional[TeacherWrapper] = None,
-                 teacher_cfg: Optional[TeacherConfig] = None, seed: int = 0, teacher_dtype=torch.bfloat16,
+    def __init__(self, cfg: dict, dtype: Optional[str] = None, device: str = "cuda", teacher: Optional[TeacherWrapper] = None,
+                 teacher_cfg: Optional[TeacherConfig] = None, seed: int = 0, teacher_dtype=None,
                  teacher_native_frontend: bool = False, student_model=None, dump_dir: Optional[str] = None):
-        """``student_model``: an already built student (tests inject a stub with the engine's interface to drive the
+        """``dtype``: compute precision of the student -- 'float16' (IEEE half operands, fp32 accumulation, dynamic loss scaling: the
+        reference's own ``precision=16`` AMP, train.py:469,496), 'bf16' or 'float32' (exact-fp32 parity mode).  ``None`` follows the
+        yaml: ``train.use_fp16: True`` -> 'float16', else 'bf16'.  ``teacher_dtype`` (torch dtype) defaults to the student's 16-bit
+        type (bf16 beside an fp32 student).  ``student_model``: an already built student (tests inject a stub with the engine's interface to drive the
         accumulation / gradient-exchange ordering on CPU).  ``dump_dir``: write the effective yaml there on rank 0, as the
         reference's constructor does (train.py:47, utils/utils.py:153-180)."""
         import torch.distributed as dist
         self.yaml_cfg = cfg
         self.train_cfg = cfg["train"]
+        if dtype is None:
+            dtype = "float16" if self.train_cfg.get("use_fp16") else "bf16"
+        from .engine import DTYPES
+        self.dtype_name = dtype
+        self.amp = DTYPES[dtype] == L.DT_F16
+        if teacher_dtype is None:
+            teacher_dtype = torch.float16 if self.amp else torch.bfloat16
         self.device = torch.device(device)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.seed = seed
@@ -140,6 +150,18 @@ class W2V2Distil:
         self.opt_v = torch.zeros_like(self.engine.params)
         self.opt_step = 0
         self.num_training_steps = None
+        # fp16 mode: dynamic loss scaling as torch.cuda.amp.GradScaler (Lightning precision=16, train.py:469,496): the scale is a host
+        # scalar folded into the loss kernels' gradient and un-folded by the optimizer kernel; overflow detection, the skipped step and
+        # the applied-step count are device side (fh_adamw_amp) and the host reads the skip counter back without synchronising
+        # initial scale 2^20 (GradScaler's default is 2^16 and doubles every 2000 clean steps): d loss / d pred of a mean over
+        # B x T x 768 x 12 elements is ~1e-8, and at 2^16 the attention-score gradients of long utterances are subnormal in half
+        # precision; a scale that is too high costs one skipped step per halving, one that is too low costs gradient bits for 2000s of steps
+        self.loss_scale = float(os.environ.get("FH_LOSS_SCALE", 2.0 ** 20)) if self.amp else 1.0
+        self.amp_growth_interval, self.amp_growth, self.amp_backoff = 2000, 2.0, 0.5
+        self._amp_since_growth = 0
+        self._amp_seen_skipped = 0
+        self.amp_state = torch.zeros(8, dtype=torch.int32, device=self.device) if self.amp else None
+        self._amp_host = torch.zeros(8, dtype=torch.int32).pin_memory() if (self.amp and self.device.type == "cuda") else None
         self.sync = GradSync(self.engine.grads)
         if self.sync.active and self.device.type == "cuda":
             # data parallel: RCCL's collective kernels run beside the step; the persistent GEMM loop (which otherwise owns every CU
@@ -337,15 +359,17 @@ class W2V2Distil:
         if self._rows_loss:
             out, d_pred = self.engine.kd_loss_rows(ws, hid, self.layer_w, self.teacher_layer,
                                                    loss_type=0 if self.rec_loss_type == "mse" else 1,
-                                                   rec_weight=float(self.rec_loss_weight), sim_weight=float(self.sim_loss_weight))
+                                                   rec_weight=float(self.rec_loss_weight), sim_weight=float(self.sim_loss_weight),
+                                                   grad_scale=self.loss_scale)
         else:
             out, d_pred = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer,
-                                              loss_type=0 if self.rec_loss_type == "mse" else 1, grad_scale=float(self.rec_loss_weight))
+                                              loss_type=0 if self.rec_loss_type == "mse" else 1,
+                                              grad_scale=float(self.rec_loss_weight) * self.loss_scale)
         d_cnn = None
         if self.cnn_loss_weight > 0:   # train.py:241-246: l1 between results["features"] and the teacher's projected CNN features
             featd = self.engine.features_to_distill(ws)
             cout, d_cnn = self.engine.kd_loss(ws, hid._fh_post.unsqueeze(0), self._one, self._zero_i, loss_type=1,
-                                              grad_scale=float(self.cnn_loss_weight), pred=featd.unsqueeze(0))
+                                              grad_scale=float(self.cnn_loss_weight) * self.loss_scale, pred=featd.unsqueeze(0))
             d_cnn = d_cnn[0]
             self.last_cnn_loss = cout[0]           # device scalar, for logging (losses['cnn_loss'], train.py:244)
             feat_total = out[-1] if self._rows_loss else float(self.rec_loss_weight) * out[-1]
@@ -358,7 +382,7 @@ class W2V2Distil:
             key_len = ws.lens[1] if ws.lens is not None else None
             tot, parts, d_qkv = relation_losses(s_qkv, hid._fh_qkv, self.engine.c.heads, self.teacher_model.model.cfg.encoder_attention_heads,
                                                 key_len, getattr(hid, "_fh_key_len", None), float(self.attn_loss_weight),
-                                                self.attn_loss_type, float(self.v_rel_loss_weight))
+                                                self.attn_loss_type, float(self.v_rel_loss_weight), grad_scale=self.loss_scale)
             d_qkv = d_qkv.view(-1, D3)
             self.last_transfer_losses = parts
             feat_total = out[-1] if (self._rows_loss or self.cnn_loss_weight > 0) else float(self.rec_loss_weight) * out[-1]
@@ -381,17 +405,62 @@ class W2V2Distil:
         return out
 
     @torch.no_grad()
+    def flush_accumulation(self):
+        """End of an epoch with a partial accumulation window: reduce and apply what has been summed, as Lightning does on the last
+        batches of an epoch (the divisor stays ``accumulate_grad_batches``) -- so ``_micro`` is 0 whenever ``last.ckpt`` is written
+        and a data-parallel resume never re-reduces one rank's partial sum."""
+        if self._micro == 0:
+            return
+        if self.sync.active:
+            self.sync.launch()
+            self.sync.wait()
+        self.optimizer_step()
+
+    @torch.no_grad()
     def optimizer_step(self):
         o = self.yaml_cfg["optimizer"]
         b1, b2 = [float(v) for v in o.get("betas", (0.9, 0.999))]
         self.opt_step += 1
         t = self.opt_step
-        self.engine.adamw(self.opt_m, self.opt_v, self.lr_at(t - 1), b1, b2, float(o.get("eps", 1e-8)),
-                          float(o.get("weight_decay", 0.0)), t, self.sync.scale / self.accumulate)
+        if self.amp:
+            total = int(self.num_training_steps or 0)
+            warm = max(1, int(total * float(o.get("warmup_proportion", 0.0)))) if total else 0
+            self.engine.adamw_amp(self.opt_m, self.opt_v, self.amp_state, float(o["lr"]), warm, total, b1, b2, float(o.get("eps", 1e-8)),
+                                  float(o.get("weight_decay", 0.0)), self.sync.scale / self.accumulate / self.loss_scale)
+            self._amp_after_step()
+        else:
+            self.engine.adamw(self.opt_m, self.opt_v, self.lr_at(t - 1), b1, b2, float(o.get("eps", 1e-8)),
+                              float(o.get("weight_decay", 0.0)), t, self.sync.scale / self.accumulate)
         self._micro = 0
         self.student_model.mark_params_updated()
         if hasattr(self.student_model, "flat"):
             self.student_model._flat_version = self.student_model.flat._version
+
+    def _amp_after_step(self):
+        """GradScaler.update without a sync: the device state is copied to pinned memory behind the optimizer kernels and the copy
+        of an EARLIER step is read here; a skip seen there halves the scale (once per skipped step), 2000 steps without one double it.
+        The scale only changes between optimizer steps, so an accumulation window is summed under one scale."""
+        if self._amp_host is not None:
+            skipped = int(self._amp_host[2])          # whatever copy has landed (at worst one step old)
+            self._amp_host.copy_(self.amp_state, non_blocking=True)
+        else:
+            skipped = int(self.amp_state[2])
+        if skipped > self._amp_seen_skipped:
+            self.loss_scale = max(1.0, self.loss_scale * self.amp_backoff ** (skipped - self._amp_seen_skipped))
+            self._amp_seen_skipped = skipped
+            self._amp_since_growth = 0
+        else:
+            self._amp_since_growth += 1
+            if self._amp_since_growth >= self.amp_growth_interval:
+                self.loss_scale = min(self.loss_scale * self.amp_growth, 2.0 ** 24)
+                self._amp_since_growth = 0
+
+    def amp_counters(self) -> Dict[str, float]:
+        """(synchronising) applied / skipped optimizer steps and the current loss scale of the fp16 mode."""
+        if not self.amp:
+            return {"applied": self.opt_step, "skipped": 0, "loss_scale": 1.0}
+        st = self.amp_state.cpu()
+        return {"applied": int(st[1]), "skipped": int(st[2]), "loss_scale": self.loss_scale}
 
     # ------------------------------------------------------------------ validation / epoch loop (train.py:179-199, 475-501)
     @torch.no_grad()
@@ -424,7 +493,8 @@ class W2V2Distil:
         import os as _os
         from .dataset import rank_buckets, to_device
         num_epochs = int(num_epochs if num_epochs is not None else self.train_cfg["num_epochs"])
-        steps_per_epoch = max(1, len(train_data) // max(1, world)) // max(1, self.accumulate)
+        per_rank = max(1, len(train_data) // max(1, world))
+        steps_per_epoch = -(-per_rank // max(1, self.accumulate))   # the partial window at the epoch end is stepped too (flush_accumulation)
         if not self.num_training_steps:
             self.configure_optimizers(max(1, steps_per_epoch * num_epochs))
         first_epoch = 0
@@ -435,6 +505,11 @@ class W2V2Distil:
         to_dev = lambda b: to_device(b, self.device)
         best: List[tuple] = []
         history, bad_epochs, best_v = [], 0, float("inf")
+        cb = getattr(self, "_callback_state", None) or {}
+        if first_epoch > 0 and cb:   # trainer.fit(ckpt_path=...) restores EarlyStopping / ModelCheckpoint state too (train.py:485-490)
+            es, mc = cb.get("EarlyStopping", {}), cb.get("ModelCheckpoint", {})
+            bad_epochs, best_v = int(es.get("wait_count", 0)), float(es.get("best_score", float("inf")))
+            best = [(float(v), str(pth)) for v, pth in mc.get("best_k_models", [])]
         for epoch in range(first_epoch, num_epochs):
             order = rank_buckets(len(train_data), epoch, rank, world, seed=0, shuffle=True)
             nxt = to_dev(train_data[order[0]])
@@ -443,6 +518,7 @@ class W2V2Distil:
                 cur = nxt
                 nxt = to_dev(train_data[order[i + 1]]) if i + 1 < len(order) else None
                 tl = self.training_step(cur, batch_idx=i, next_batch=nxt)
+            self.flush_accumulation()
             self.training_epoch_end()
             rec = {"epoch": epoch, "train_loss": float(tl[-1].item()) if tl is not None else float("nan")}
             if eval_data is not None and len(eval_data) > 0:
@@ -467,6 +543,8 @@ class W2V2Distil:
                     best_v, bad_epochs = rec["v_loss"], 0
                 else:
                     bad_epochs += 1
+            self._callback_state = {"EarlyStopping": {"wait_count": bad_epochs, "best_score": best_v, "patience": patience},
+                                    "ModelCheckpoint": {"best_k_models": [[v, pth] for v, pth in best], "monitor": "v_loss"}}
             if output_dir and rank == 0:
                 _os.makedirs(output_dir, exist_ok=True)
                 self.save_checkpoint(_os.path.join(output_dir, "last.ckpt"), epoch=epoch)
@@ -488,17 +566,35 @@ class W2V2Distil:
         prefixes -- what ``fithubert/expert.py:40-45`` loads -- plus everything an exact resume needs (train.py:466,506-509:
         ``trainer.fit(ckpt_path=...)`` restores optimizer, schedule position and loop state): AdamW moments, the optimizer step,
         the schedule length, the accumulation phase, the current random-layer draw and its RNG state."""
+        o = self.yaml_cfg.get("optimizer", {})
+        amp = self.amp_counters() if self.amp else None
+        applied = amp["applied"] if amp else self.opt_step
+        # ``optimizer_states`` in torch's own AdamW ``state_dict()`` layout (what Lightning writes: train.py:407-421 returns ONE
+        # optimizer over ONE parameter list -- here the flat buffer is that one parameter)
+        opt_sd = {"state": {0: {"step": torch.tensor(float(applied)), "exp_avg": self.opt_m.cpu(), "exp_avg_sq": self.opt_v.cpu()}},
+                  "param_groups": [{"lr": float(o.get("lr", 0.0)), "betas": tuple(float(b) for b in o.get("betas", (0.9, 0.999))),
+                                    "eps": float(o.get("eps", 1e-8)), "weight_decay": float(o.get("weight_decay", 0.0)),
+                                    "amsgrad": False, "maximize": False, "params": [0]}]}
         torch.save({"state_dict": {k: v.cpu() for k, v in self.state_dict().items()}, "epoch": epoch,
                     "global_step": self.opt_step, "hyper_parameters": {"cfg": self.yaml_cfg},
-                    "optimizer_states": [{"exp_avg": self.opt_m.cpu(), "exp_avg_sq": self.opt_v.cpu(), "step": self.opt_step}],
-                    "fithubert_amd": {"num_training_steps": self.num_training_steps, "micro": self._micro,
-                                      "rand_l": list(self.rand_l), "rng_state": self._rng.getstate(),
-                                      "grads": self.engine.grads.cpu() if self._micro else None}}, path)
+                    "optimizer_states": [opt_sd], "lr_schedulers": [],
+                    "callbacks": dict(getattr(self, "_callback_state", {})),
+                    "fithubert_amd": {"num_training_steps": self.num_training_steps, "micro": self._micro, "opt_step": self.opt_step,
+                                      "flat_optimizer": True, "rand_l": list(self.rand_l), "rng_state": self._rng.getstate(),
+                                      "grads": self.engine.grads.cpu() if self._micro else None,
+                                      "amp": ({"loss_scale": self.loss_scale, "applied": amp["applied"], "skipped": amp["skipped"],
+                                               "since_growth": self._amp_since_growth} if amp else None)}}, path)
 
     def load_checkpoint(self, path: str, strict: bool = True) -> int:
         """Restore a checkpoint written by ``save_checkpoint`` (or any Lightning-convention ``.ckpt`` of this student: then only the
         weights).  Returns the epoch stored in it."""
-        ck = torch.load(path, map_location="cpu", weights_only=True)   # tensors + plain containers only: nothing in it needs unpickling code
+        try:
+            ck = torch.load(path, map_location="cpu", weights_only=True)   # tensors + plain containers only: nothing in it needs unpickling code
+        except Exception:
+            # a foreign Lightning checkpoint may pickle callback / hyper-parameter objects: fall back to a full load only on request
+            if os.environ.get("FH_TRUST_CKPT", "0") != "1":
+                raise
+            ck = torch.load(path, map_location="cpu", weights_only=False)
         sd = {k[len("student_model."):]: v for k, v in ck["state_dict"].items() if k.startswith("student_model.")}
         self.student_model.load_state_dict(sd, strict=strict)
         self.student_model.mark_params_updated()
@@ -507,13 +603,33 @@ class W2V2Distil:
         if tsd and set(tsd) == set(own) and all(tuple(tsd[k].shape) == tuple(own[k].shape) for k in own):
             self.teacher_model.model.load_state_dict({k: v.to(own[k].dtype) for k, v in tsd.items()})   # Lightning restores the frozen teacher too
             self.teacher_model.model._native = None    # prepared native copies of the old weights
-        opt = ck.get("optimizer_states")
-        if opt:
-            self.opt_m.copy_(opt[0]["exp_avg"].to(self.opt_m.device))
-            self.opt_v.copy_(opt[0]["exp_avg_sq"].to(self.opt_v.device))
-            self.opt_step = int(opt[0]["step"])
         ex = ck.get("fithubert_amd")
+        opt = ck.get("optimizer_states")
+        # the moments are restored only from a checkpoint of THIS optimizer layout (one flat parameter); a reference / Lightning
+        # checkpoint (per-parameter AdamW state of s3prl's optimizer) restores the weights only, as the docstring says
+        st0 = None
+        if opt and isinstance(opt[0], dict):
+            if "exp_avg" in opt[0]:                                   # round-2 layout
+                st0 = opt[0]
+            elif ex and ex.get("flat_optimizer") and isinstance(opt[0].get("state"), dict) and len(opt[0]["state"]) == 1:
+                st0 = next(iter(opt[0]["state"].values()))
+        if st0 is not None and tuple(st0["exp_avg"].shape) == tuple(self.opt_m.shape):
+            self.opt_m.copy_(st0["exp_avg"].to(self.opt_m.device))
+            self.opt_v.copy_(st0["exp_avg_sq"].to(self.opt_v.device))
+            self.opt_step = int(float(st0["step"]))
+        self._callback_state = dict(ck.get("callbacks") or {})
         if ex:
+            self.opt_step = int(ex.get("opt_step", self.opt_step))
+            a = ex.get("amp")
+            if a and self.amp:
+                self.loss_scale = float(a["loss_scale"])
+                self._amp_since_growth = int(a.get("since_growth", 0))
+                self._amp_seen_skipped = int(a["skipped"])
+                self.amp_state.zero_()
+                self.amp_state[1] = int(a["applied"])
+                self.amp_state[2] = int(a["skipped"])
+                if self._amp_host is not None:
+                    self._amp_host.copy_(self.amp_state.cpu())
             self.num_training_steps = ex["num_training_steps"]
             self._micro = int(ex["micro"])
             self.rand_l = list(ex["rand_l"])
@@ -543,6 +659,12 @@ class W2V2Distil:
         return d
 
 
+# fp16 mode, autograd (module-API) path: d loss / d pred of a mean over ~5e7 elements is ~4e-8 per element, below half precision's
+# smallest subnormal; the fused loss kernel therefore writes it times this constant and backward() divides the incoming gradient by
+# it in fp32 -- with a GradScaler-style upstream gradient of 2^16 the product is exact, with 1.0 it underflows as any fp16 autograd would
+_API_GRAD_SCALE = 65536.0
+
+
 class _L1Fn(torch.autograd.Function):
     """mean |a - b| with the fused loss kernel (one 'layer'); gradient w.r.t. a."""
 
@@ -553,21 +675,24 @@ class _L1Fn(torch.autograd.Function):
         b4 = b.contiguous().unsqueeze(0)
         _, B, Tp, P = a4.shape
         lib = L.lib()
-        tdt = L.DT_F32 if b4.dtype == torch.float32 else L.DT_BF16
+        from .engine import tensor_dtype_code
+        tdt = tensor_dtype_code(b4)
+        k = _API_GRAD_SCALE if eng.c.dtype == L.DT_F16 else 1.0
         nblk = lib.fh_kd_loss_nblk(eng.c.dtype, B, Tp, P)
         partials = torch.empty(nblk, device=a.device, dtype=torch.float32)
         out = torch.empty(2, device=a.device, dtype=torch.float64)
         d = torch.empty_like(a4)
         L.check(lib.fh_kd_loss(eng.c.dtype, tdt, a4.data_ptr(), b4.data_ptr(), d.data_ptr(), task._one.data_ptr(), task._zero_i.data_ptr(),
-                               partials.data_ptr(), out.data_ptr(), 1, B, Tp, b4.shape[2], P, B * b4.shape[2] * P, 1, 1.0, eng.stream()),
+                               partials.data_ptr(), out.data_ptr(), 1, B, Tp, b4.shape[2], P, B * b4.shape[2] * P, 1, k, eng.stream()),
                 "fh_kd_loss")
         ctx.save_for_backward(d[0])
+        ctx.k = k
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        return d * g.to(d.dtype), None, None
+        return (d.float() * (g.float() / ctx.k)).to(d.dtype), None, None
 
 
 class _KDLossFn(torch.autograd.Function):
@@ -578,17 +703,19 @@ class _KDLossFn(torch.autograd.Function):
         eng = task.engine
         pred = pred.contiguous()
         Lh, B, Tp, P = pred.shape
-        tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16
+        from .engine import tensor_dtype_code
+        tdt = tensor_dtype_code(teacher)
         lib = L.lib()
+        k = ctx.k = _API_GRAD_SCALE if eng.c.dtype == L.DT_F16 else 1.0
         if task._rows_loss:
             nblk = lib.fh_kd_loss_rows_nblk(B, Tp)
             partials = torch.empty(2 * Lh * nblk, device=pred.device, dtype=torch.float32)
             out = torch.empty(Lh + 1, device=pred.device, dtype=torch.float64)
             d_pred = torch.empty_like(pred)
-            L.check(lib.fh_kd_loss_rows(eng.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(), d_pred.data_ptr(), task.layer_w.data_ptr(),
-                                        task.teacher_layer.data_ptr(), partials.data_ptr(), out.data_ptr(), Lh, B, Tp, teacher.shape[2], P,
-                                        B * teacher.shape[2] * P, 0 if task.rec_loss_type == "mse" else 1, float(task.rec_loss_weight),
-                                        float(task.sim_loss_weight), eng.stream()), "fh_kd_loss_rows")
+            L.check(lib.fh_kd_loss_rows_scaled(eng.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(), d_pred.data_ptr(), task.layer_w.data_ptr(),
+                                               task.teacher_layer.data_ptr(), partials.data_ptr(), out.data_ptr(), Lh, B, Tp, teacher.shape[2], P,
+                                               B * teacher.shape[2] * P, 0 if task.rec_loss_type == "mse" else 1, float(task.rec_loss_weight),
+                                               float(task.sim_loss_weight), k, eng.stream()), "fh_kd_loss_rows")
             ctx.save_for_backward(d_pred)
             return out
         nblk = lib.fh_kd_loss_nblk(eng.c.dtype, B, Tp, P)
@@ -597,11 +724,11 @@ class _KDLossFn(torch.autograd.Function):
         d_pred = torch.empty_like(pred)
         L.check(lib.fh_kd_loss(eng.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(), d_pred.data_ptr(), task.layer_w.data_ptr(),
                                task.teacher_layer.data_ptr(), partials.data_ptr(), out.data_ptr(), Lh, B, Tp, teacher.shape[2], P,
-                               B * teacher.shape[2] * P, 0 if task.rec_loss_type == "mse" else 1, 1.0, eng.stream()), "fh_kd_loss")
+                               B * teacher.shape[2] * P, 0 if task.rec_loss_type == "mse" else 1, k, eng.stream()), "fh_kd_loss")
         ctx.save_for_backward(d_pred)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (d_pred,) = ctx.saved_tensors
-        return d_pred * g[-1].to(d_pred.dtype), None, None
+        return (d_pred.float() * (g[-1].float() / ctx.k)).to(d_pred.dtype), None, None

@@ -18,7 +18,17 @@ from ._lib import FH_MAX_CONV, StudentCallC, StudentConfigC
 
 _I, _L = C.c_int, C.c_long
 
-DTYPES = {"float32": L.DT_F32, "fp32": L.DT_F32, "f32": L.DT_F32, "bfloat16": L.DT_BF16, "bf16": L.DT_BF16}
+DTYPES = {"float32": L.DT_F32, "fp32": L.DT_F32, "f32": L.DT_F32, "bfloat16": L.DT_BF16, "bf16": L.DT_BF16,
+          "float16": L.DT_F16, "fp16": L.DT_F16, "f16": L.DT_F16, "half": L.DT_F16}
+TORCH_ELEM = {L.DT_F32: torch.float32, L.DT_BF16: torch.bfloat16, L.DT_F16: torch.float16}
+
+
+def tensor_dtype_code(t: torch.Tensor) -> int:
+    """dtype code of the C ABI (include/fithubert_hip.h) for a tensor handed to a kernel as its element type."""
+    for code, td in TORCH_ELEM.items():
+        if t.dtype == td:
+            return code
+    raise NotImplementedError(f"fithubert_amd kernels take fp32, bf16 or fp16 tensors, got {t.dtype}")
 
 
 def unsupported(cfg: CustomStudentModelConfig) -> Optional[str]:
@@ -120,9 +130,7 @@ class Workspace:
         n = 1
         for s in shape:
             n *= s
-        dt = torch.float32 if eb.value == 4 else torch.bfloat16
-        if eb.value == 4 and self.eng.c.dtype == L.DT_F32:
-            dt = torch.float32
+        dt = torch.float32 if eb.value == 4 else self.eng.elem
         raw = self.buf[off.value: off.value + n * eb.value]
         return raw.view(dt).view(shape)
 
@@ -144,7 +152,7 @@ class StudentEngine:
         self.params = torch.zeros(self.n_params, device=self.device, dtype=torch.float32)
         self.grads = torch.zeros_like(self.params)
         self.wc = torch.empty(self.lib.fh_student_wc_bytes(C.byref(self.c)), device=self.device, dtype=torch.uint8)
-        self.elem = torch.float32 if self.c.dtype == L.DT_F32 else torch.bfloat16
+        self.elem = TORCH_ELEM[self.c.dtype]
         self._prepared_version = -1
         self.version = 0
         self.layers = cfg.conv_layers()
@@ -296,23 +304,33 @@ class StudentEngine:
         L.check(self.lib.fh_adamw(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(), self.n_params, lr, b1, b2,
                                   eps, wd, 1.0 - b1 ** step, 1.0 - b2 ** step, grad_scale, None, self.stream()), "fh_adamw")
 
+    def adamw_amp(self, m: torch.Tensor, v: torch.Tensor, state: torch.Tensor, lr_peak: float, warmup_steps: int, total_steps: int,
+                  b1: float, b2: float, eps: float, wd: float, grad_scale: float) -> None:
+        """The fp16 mode's optimizer step (fh_adamw_amp): non-finite check of the flat gradient, device-side skip, schedule and bias
+        correction from the applied-step count in ``state`` (int32[8] on the device, see fh_amp_state) -- no host sync."""
+        assert state.is_cuda and state.dtype == torch.int32 and state.numel() >= 8
+        L.check(self.lib.fh_adamw_amp(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(), self.n_params,
+                                      float(lr_peak), int(warmup_steps), int(total_steps), b1, b2, eps, wd, float(grad_scale),
+                                      state.data_ptr(), self.stream()), "fh_adamw_amp")
+
     def kd_loss_rows(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
-                     loss_type: int = 1, rec_weight: float = 1.0, sim_weight: float = 1.0, want_grad: bool = True):
+                     loss_type: int = 1, rec_weight: float = 1.0, sim_weight: float = 1.0, want_grad: bool = True,
+                     grad_scale: float = 1.0):
         """rec (l1 | mse) + cosine loss of the DistilHuBERT-style recipe (train.py:284-314, 372-378), fused with its
         gradient.  Returns (out fp64 [L+1]: per-task rec+sim means, weighted total; d_pred = d total / d pred or None)."""
         pred = ws.view("pred")
         Lh, B, Tp, P = pred.shape
         assert teacher.is_cuda and teacher.is_contiguous() and teacher.dim() == 4 and teacher.shape[1] == B and teacher.shape[3] == P
-        tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16
+        tdt = tensor_dtype_code(teacher)
         Tt = teacher.shape[2]
         nblk = self.lib.fh_kd_loss_rows_nblk(B, Tp)
         partials = torch.empty(2 * Lh * nblk, device=self.device, dtype=torch.float32)
         out = torch.empty(Lh + 1, device=self.device, dtype=torch.float64)
         d_pred = torch.empty_like(pred) if want_grad else None
-        L.check(self.lib.fh_kd_loss_rows(self.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(),
+        L.check(self.lib.fh_kd_loss_rows_scaled(self.c.dtype, tdt, pred.data_ptr(), teacher.data_ptr(),
                                          d_pred.data_ptr() if want_grad else None, layer_w.data_ptr(), teacher_layer.data_ptr(),
                                          partials.data_ptr(), out.data_ptr(), Lh, B, Tp, Tt, P, B * Tt * P, loss_type,
-                                         float(rec_weight), float(sim_weight), self.stream()), "fh_kd_loss_rows")
+                                         float(rec_weight), float(sim_weight), float(grad_scale), self.stream()), "fh_kd_loss_rows")
         return out, d_pred
 
     def kd_loss(self, ws: Workspace, teacher: torch.Tensor, layer_w: torch.Tensor, teacher_layer: torch.Tensor,
@@ -322,7 +340,7 @@ class StudentEngine:
         pred = ws.view("pred") if pred is None else pred
         Lh, B, Tp, P = pred.shape
         assert teacher.is_cuda and teacher.is_contiguous() and teacher.dim() == 4 and teacher.shape[1] == B and teacher.shape[3] == P
-        tdt = L.DT_F32 if teacher.dtype == torch.float32 else L.DT_BF16
+        tdt = tensor_dtype_code(teacher)
         Tt = teacher.shape[2]
         nblk = self.lib.fh_kd_loss_nblk(self.c.dtype, B, Tp, P)
         partials = torch.empty(Lh * nblk, device=self.device, dtype=torch.float32)

@@ -164,9 +164,9 @@ class _NativeFrontend:
         self.L, self.lib = L, L.lib()
         p0 = model.post_extract_proj.weight
         self.dev, self.tdt = p0.device, p0.dtype
-        if self.tdt not in (torch.bfloat16, torch.float32):
-            raise NotImplementedError("native teacher frontend: bf16 or fp32 only")
-        self.dt = L.DT_BF16 if self.tdt == torch.bfloat16 else L.DT_F32
+        if self.tdt not in (torch.bfloat16, torch.float16, torch.float32):
+            raise NotImplementedError("native teacher frontend: bf16, fp16 or fp32 only")
+        self.dt = {torch.bfloat16: L.DT_BF16, torch.float16: L.DT_F16, torch.float32: L.DT_F32}[self.tdt]
         fe = model.feature_extractor
         self.spec = fe.spec
         self.mode = fe.mode
@@ -429,7 +429,7 @@ class TeacherModel(nn.Module):
             S_ = int(source.shape[1])
             lg = max(S_, 1).bit_length() - 1
             key = (int(source.shape[0]), lg * 4 + (((S_ - (1 << lg)) * 4) >> lg))   # (batch, quarter-octave class of the length)
-            if key not in native._tuned and dt == torch.bfloat16 and os.environ.get("FH_GEMM_AUTOTUNE", "1") != "0":
+            if key not in native._tuned and dt in (torch.bfloat16, torch.float16) and os.environ.get("FH_GEMM_AUTOTUNE", "1") != "0":
                 # first forward of this shape: the HIP GEMMs (conv layers, fc1) measure their main-loop candidates.  Their
                 # outputs are overwritten, not accumulated, so measuring inside a real forward is harmless; it blocks once.
                 native._tuned.add(key)

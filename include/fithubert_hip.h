@@ -7,7 +7,9 @@
  * allocate nothing, never synchronise, and return 0 on success (a hipError_t or a negative
  * argument-check code otherwise).
  *
- * dtype: 0 = float (exact fp32 MFMA, parity mode), 1 = bf16 storage / bf16 MFMA / fp32 accumulate.
+ * dtype: 0 = float (exact fp32 MFMA, parity mode), 1 = bf16 storage / bf16 MFMA / fp32 accumulate,
+ *        2 = IEEE half storage / f16 MFMA / fp32 accumulate -- the reference's own AMP precision (train.py:469,496,
+ *            data/conf/fithubert.yaml:11 use_fp16), same MFMA rate as bf16, three more significand bits.
  */
 #ifndef FITHUBERT_HIP_H
 #define FITHUBERT_HIP_H
@@ -206,6 +208,11 @@ int fh_kd_loss_rows_nblk(int B, int Tp);
 int fh_kd_loss_rows(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
                     const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,
                     long teacher_lstride, int loss_type, float rec_weight, float sim_weight, fh_stream_t stream);
+/* the same with dpred multiplied by grad_scale (the fp16 mode's loss scale; the reported losses are not scaled) */
+int fh_kd_loss_rows_scaled(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
+                           const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,
+                           long teacher_lstride, int loss_type, float rec_weight, float sim_weight, float grad_scale,
+                           fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight preparation and optimizer (train.py:407-421; AMP casts implicit at train.py:469,496).
@@ -215,6 +222,21 @@ int fh_permute3_cast(int dtype, const float* src, void* dst, int d0, int d1, int
                      fh_stream_t stream);
 int fh_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
              float wd, float bc1, float bc2, float grad_scale, const float* decay_mask, fh_stream_t stream);
+/* The optimizer step of the fp16 mode -- torch.cuda.amp.GradScaler.step/update as Lightning's precision=16 drives it
+ * (train.py:469,496) -- without a host sync: the flat gradient (which carries the loss scale; grad_scale un-folds it together with
+ * 1/world and 1/accumulation) is checked for non-finite values, a step that has one is skipped, and the applied-step count that
+ * the schedule (linear warm-up to lr_peak over warmup_steps, linear decay to 0 at total_steps; total_steps = 0: constant) and the
+ * Adam bias corrections follow lives in `state` (device memory, zero-initialised by the caller, 32 bytes).  The caller reads
+ * `skipped` back whenever convenient and lowers its loss scale. */
+typedef struct {
+  int found_inf;   /* scratch of the current step */
+  int good_steps;  /* optimizer steps applied so far */
+  int skipped;     /* steps skipped because of a non-finite gradient */
+  int reserved;
+  float lr, bc1, bc2, reserved2; /* scalars of the step in flight (written by the library) */
+} fh_amp_state;
+int fh_adamw_amp(float* p, const float* g, float* m, float* v, long n, float lr_peak, int warmup_steps, int total_steps, float beta1,
+                 float beta2, float eps, float wd, float grad_scale, fh_amp_state* state, fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Student engine: the whole CustomStudentModel forward (modules/model.py:420-552) and its backward as ONE

@@ -58,16 +58,18 @@ def test_gemm_kernels_keep_their_accumulators_in_registers():
     epilogues run at half speed -- without any warning and with correct results (it happened in round 2 when the epilogue gained two
     option blocks; build.py raises the budget).  The compiled code object says so: no such kernel may own more than a few spill
     slots."""
-    scratch = _kernel_scratch_bytes(os.path.join(ROOT, "fithubert_amd", "csrc", "_obj", "gemm.hip.o"))
-    if scratch is None:
-        import pytest
-        pytest.skip("no built object file / LLVM tools")
-    big = {k: v for k, v in scratch.items() if re.search(r"gemm_(ring|pp|8ph|8ph_stream|small)_kernel|gemm32_kernel|gemm_kernel", k)}
-    assert len(big) >= 20, sorted(scratch)
-    bad = {k: v for k, v in big.items() if v > 128}
-    assert not bad, bad
-    hot = [v for k, v in big.items() if "gemm_8ph_stream_kernelILi0ELi0E" in k or "gemm_8ph_kernelILi0ELi0E" in k]
-    assert hot and max(hot) == 0, hot     # the forward loops: no scratch at all (a scratch access drains loop 8's counted vmcnt queue)
+    # the 16-bit main loops are instantiated per element type in their own translation units (bf16: "DF16b", IEEE half: "DF16_")
+    for unit in ("gemm_bf16.hip.o", "gemm_f16.hip.o"):
+        scratch = _kernel_scratch_bytes(os.path.join(ROOT, "fithubert_amd", "csrc", "_obj", unit))
+        if scratch is None:
+            import pytest
+            pytest.skip("no built object file / LLVM tools")
+        big = {k: v for k, v in scratch.items() if re.search(r"gemm_(ring|pp|8ph|8ph_stream|small)_kernel|gemm32_kernel|gemm_kernel", k)}
+        assert len(big) >= 20, (unit, sorted(scratch))
+        bad = {k: v for k, v in big.items() if v > 128}
+        assert not bad, (unit, bad)
+        hot = [v for k, v in big.items() if re.search(r"gemm_8ph(_stream)?_kernelI\w+?Li0ELi0E", k)]
+        assert len(hot) >= 2 and max(hot) == 0, (unit, hot)  # the forward loops: no scratch at all (a scratch access drains loop 8's counted vmcnt queue)
     # every other kernel of the library: a handful of spill slots at most (the 4-wave attention forward once carried 404 bytes
     # under a register cap meant for its 8- and 16-wave builds)
     import glob

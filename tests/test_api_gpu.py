@@ -492,3 +492,60 @@ def test_three_training_steps_follow_the_oracle_trajectory():
         num += float((d_got - d_ref).pow(2).sum())
         den += float(d_ref.pow(2).sum())
     assert den > 0 and (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+def test_fp16_mode_follows_use_fp16_trains_and_skips_overflowed_steps(tmp_path):
+    """The reference's own precision (train.py:469,496 ``precision=16`` when ``train.use_fp16``; fithubert.yaml:11): the task built
+    WITHOUT a dtype follows the yaml, computes on IEEE-half operands (student engine dtype 2, fp16 teacher), trains on a fixed batch,
+    and behaves as GradScaler does: a step whose gradient holds a non-finite value is skipped on the device (parameters and Adam
+    moments untouched, the applied-step count -- which the schedule and the bias corrections follow -- not advanced) and the loss
+    scale is halved once the host has seen the skip counter move; the next clean step applies."""
+    from fithubert_amd import _lib as L
+    from fithubert_amd.dataset import fixed_length_batch
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+
+    y = _cfg(encoder_layers=3)
+    y["train"].update(distil_random_layer=2, accumulate_grad_batches=1)
+    assert y["train"]["use_fp16"] is True                     # the shipped yaml trains in fp16
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 3
+    task = W2V2Distil(y, device=DEV, teacher_cfg=tc, seed=0)   # no dtype given
+    assert task.amp and task.engine.c.dtype == L.DT_F16 and task.engine.elem == torch.float16
+    assert next(task.teacher_model.model.parameters()).dtype == torch.float16
+    y2 = _cfg(encoder_layers=3)
+    y2["train"]["use_fp16"] = False
+    assert not W2V2Distil(y2, device=DEV, teacher_cfg=tc, seed=0).amp
+    task.configure_optimizers(num_training_steps=40)
+    batch = fixed_length_batch(4, 16000, seed=0, device=DEV)
+    losses = [task.training_step(batch, batch_idx=i, next_batch=batch)[-1].item() for i in range(12)]
+    assert losses[-1] < 0.9 * losses[0], losses
+    c = task.amp_counters()
+    assert c == {"applied": 12, "skipped": 0, "loss_scale": 2.0 ** 20}, c
+    # the same 12 steps in bf16 land on nearly the same loss (same seeds, same masks; different rounding)
+    tb = W2V2Distil(y, dtype="bf16", device=DEV, teacher_cfg=tc, seed=0)
+    tb.configure_optimizers(num_training_steps=40)
+    lb = [tb.training_step(batch, batch_idx=i, next_batch=batch)[-1].item() for i in range(12)]
+    assert abs(lb[-1] - losses[-1]) < 0.05 * abs(lb[-1]), (lb[-1], losses[-1])
+    # ---- overflow: an absurd scale makes the fp16 data gradients overflow -> inf in the flat gradient -> the step is skipped
+    p0, m0 = task.engine.params.clone(), task.opt_m.clone()
+    task.loss_scale = 2.0 ** 40
+    task.training_step(batch, batch_idx=12, next_batch=batch)
+    torch.cuda.synchronize()
+    assert torch.equal(task.engine.params, p0) and torch.equal(task.opt_m, m0)
+    c = task.amp_counters()
+    assert c["applied"] == 12 and c["skipped"] == 1, c
+    task.loss_scale = 2.0 ** 20
+    task.training_step(batch, batch_idx=13, next_batch=batch)   # the host copy of the counters from the skipped step has landed by now
+    torch.cuda.synchronize()
+    assert task.loss_scale == 2.0 ** 19, task.loss_scale        # halved once for the one skipped step
+    c = task.amp_counters()
+    assert c["applied"] == 13 and c["skipped"] == 1, c
+    assert not torch.equal(task.engine.params, p0)
+    # resume: the counters and the scale travel in the checkpoint
+    ck = str(tmp_path / "amp.ckpt")
+    task.save_checkpoint(ck, epoch=1)
+    t2 = W2V2Distil(y, device=DEV, teacher_cfg=tc, seed=4)
+    t2.load_checkpoint(ck)
+    assert t2.amp_counters() == task.amp_counters() and t2.opt_step == task.opt_step
+    assert torch.equal(t2.opt_m, task.opt_m)

@@ -4,7 +4,10 @@ captured from the reference.
 Tolerances: dtype float (exact-fp32 MFMA): hidden states <= 2e-4 of the tensor scale, KD loss <= 1e-4 absolute
 (the north star's parity figure), gradients <= 2e-3 relative.  dtype bf16: hidden states rel-L2 <= 2e-2, KD loss
 <= 1.5e-3 relative on the full config (measured 0.7-2.5e-4; 2.3-5.6e-4 of it is the rounding of the WEIGHTS to bf16 alone,
-DESIGN.md section 2), gradient norms <= 6e-2 relative (bf16 keeps 8 significant bits)."""
+DESIGN.md section 2), gradient norms <= 6e-2 relative (bf16 keeps 8 significant bits).  dtype float16 (IEEE half operands, the
+reference's own AMP precision, train.py:469,496): hidden states rel-L2 <= 4e-3, KD loss within FP16_LOSS_TOL ABSOLUTE of the fp32
+reference -- the bound is the deviation of the reference's own AMP arithmetic from its fp32 arithmetic on the same inputs
+(profiles/r03_reference_amp_delta.txt) --, gradient norms <= 1e-2 relative."""
 import os
 
 import numpy as np
@@ -20,6 +23,11 @@ from oracle import loss_ref as LR  # noqa: E402
 from oracle import student_ref as S  # noqa: E402
 
 DEV = "cuda"
+# fp16 KD-loss deviation from the reference's fp32 loss, ABSOLUTE (eval forward, identical weights / inputs).  The reference's own AMP
+# arithmetic (the unmodified reference under torch.autocast(float16), tools/ref_amp_delta.py -> profiles/r03_reference_amp_delta.txt)
+# deviates by -1.78e-4 on the 2 s fixture: no fp16 computation can promise less than the reference's own.  Measured values of this
+# build are printed by the tests (pytest -s) and recorded in DESIGN.md section 2.
+FP16_LOSS_TOL = {"student_full_2s": 3e-4, "student_full_10s": 3e-4, "student_full_libri_max": 3e-4}
 
 
 def _rel_max(a, b):
@@ -62,7 +70,7 @@ def _check_forward(eng, ws, ref, L, tol_max, tol_l2, padded_check=None):
     return worst
 
 
-@pytest.mark.parametrize("dtype,tol_max,tol_l2", [("float32", 3e-4, 1e-4), ("bf16", 8e-2, 2e-2)])
+@pytest.mark.parametrize("dtype,tol_max,tol_l2", [("float32", 3e-4, 1e-4), ("bf16", 8e-2, 2e-2), ("float16", 1e-2, 2.5e-3)])
 def test_small_config_forward_matches_golden_and_oracle(dtype, tol_max, tol_l2, golden_dir):
     fx = np.load(os.path.join(golden_dir, "student_small.npz"))
     cfg = yaml.safe_load(str(fx["cfg_yaml"]))
@@ -97,7 +105,7 @@ def test_small_config_forward_matches_golden_and_oracle(dtype, tol_max, tol_l2, 
     assert _rel_l2(ws.view("features").float(), torch.from_numpy(fx["features_padded"])) < tol_l2
 
 
-@pytest.mark.parametrize("dtype", ["float32", "bf16"])
+@pytest.mark.parametrize("dtype", ["float32", "bf16", "float16"])
 def test_small_config_loss_and_gradients(dtype, golden_dir):
     fx = np.load(os.path.join(golden_dir, "student_small.npz"))
     cfg = yaml.safe_load(str(fx["cfg_yaml"]))
@@ -114,9 +122,11 @@ def test_small_config_loss_and_gradients(dtype, golden_dir):
     w[rand_l] = 0.1
     w[L - 1] = 1.0
     ws = eng.forward(wav.to(DEV), None, training=True, seed=1)
-    out, d_pred = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(L, dtype=torch.int32, device=DEV))
+    gscale = 2.0 ** 20 if dtype == "float16" else 1.0   # fp16: loss-scaled gradient, un-scaled in the fp32 gradient buffer (as fh_adamw_amp does)
+    out, d_pred = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(L, dtype=torch.int32, device=DEV), grad_scale=gscale)
     eng.grads.zero_()
     eng.backward(ws, d_pred=d_pred)
+    eng.grads.mul_(1.0 / gscale)
     torch.cuda.synchronize()
     loss = out[L].item()
     ref_loss = float(fx["loss"])
@@ -129,9 +139,9 @@ def test_small_config_loss_and_gradients(dtype, golden_dir):
         want[L - 1] = fx["layer_losses"][-1]
         np.testing.assert_allclose(per_layer, want, rtol=2e-4)
     else:
-        assert abs(loss - ref_loss) < 4e-3 * ref_loss, (loss, ref_loss)   # 3-layer model, loss ~2.2: measured 2e-4 relative
+        assert abs(loss - ref_loss) < (4e-3 if dtype == "bf16" else 5e-4) * ref_loss, (loss, ref_loss)   # 3-layer model, loss ~2.2: bf16 measured 2e-4 relative
     grads = eng.param_views(eng.grads)
-    tol = 3e-3 if dtype == "float32" else 6e-2
+    tol = {"float32": 3e-3, "bf16": 6e-2, "float16": 1e-2}[dtype]
     no_grad = set(str(s) for s in fx["no_grad_params"])
     bad = []
     for k, gv in grads.items():
@@ -149,7 +159,7 @@ def test_small_config_loss_and_gradients(dtype, golden_dir):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("dtype,tol_l2", [("float32", 1e-4), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("dtype,tol_l2", [("float32", 1e-4), ("bf16", 2.5e-2), ("float16", 4e-3)])
 def test_full_fithubert_config_2s(dtype, tol_l2, golden_dir):
     fx = np.load(os.path.join(golden_dir, "student_full_2s.npz"))
     cfg = yaml.safe_load(str(fx["cfg_yaml"]))
@@ -171,7 +181,9 @@ def test_full_fithubert_config_2s(dtype, tol_l2, golden_dir):
     out, _ = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(12, dtype=torch.int32, device=DEV), want_grad=False)
     loss = out[12].item()
     ref = float(fx["loss"])
-    assert abs(loss - ref) < (1e-4 if dtype == "float32" else 1.5e-3 * ref), (loss, ref)   # bf16 measured 2.4e-4 relative
+    print(f"\n[KD-loss parity] student_full_2s {dtype}: loss {loss:.6f} reference {ref:.6f} delta {loss - ref:+.2e}")
+    tol = {"float32": 1e-4, "bf16": 1.5e-3 * ref, "float16": FP16_LOSS_TOL["student_full_2s"]}[dtype]   # bf16 measured 2.4e-4 relative
+    assert abs(loss - ref) < tol, (loss, ref)
     # padded pair
     lens = [int(n) for n in fx["pad_from"]]
     wav_p = wav.clone()
@@ -504,7 +516,7 @@ BF16_LOSS_TOL = {"student_full_10s": 1.5e-3, "student_full_libri_max": 1.5e-3}  
 
 
 @pytest.mark.parametrize("name", ["student_full_10s", "student_full_libri_max"])
-@pytest.mark.parametrize("dtype,tol_l2,tol_g", [("float32", 1e-4, 3e-3), ("bf16", 2.5e-2, 6e-2)])
+@pytest.mark.parametrize("dtype,tol_l2,tol_g", [("float32", 1e-4, 3e-3), ("bf16", 2.5e-2, 6e-2), ("float16", 4e-3, 1e-2)])
 def test_full_config_at_baseline_and_librispeech_sizes(name, dtype, tol_l2, tol_g, golden_dir):
     """The full fithubert.yaml student at BASELINE.json's utterance size (2 x 10 s) and on LibriSpeech train-clean-100's longest
     utterance beside its median (392,400 / 223,920 samples, right-padded; T' = 1226, T2 = 613 -- the tiled attention kernels, the
@@ -538,10 +550,17 @@ def test_full_config_at_baseline_and_librispeech_sizes(name, dtype, tol_l2, tol_
     w = torch.zeros(12)
     w[[int(v) for v in fx["rand_l"]]] = 0.1
     w[11] = 1.0
-    out, d_pred = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(12, dtype=torch.int32, device=DEV))
+    # fp16: the gradient leaves the loss kernel times a loss scale (d loss / d pred of a mean over ~1e6 elements is below half
+    # precision's range) and the flat fp32 gradient is un-scaled afterwards, as the training step does (fh_adamw_amp folds it)
+    # (2^20: where the dynamic scale of a training run settles for this loss -- at GradScaler's initial 2^16 the attention score
+    # gradients of a 613-frame utterance, p * scale * (dP - delta) ~ 1e-3 * 0.16 * 1e-3 * 2^16, sit in half precision's subnormals)
+    gscale = 2.0 ** 20 if dtype == "float16" else 1.0
+    out, d_pred = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(12, dtype=torch.int32, device=DEV), grad_scale=gscale)
     eng.grads.zero_()
     eng.backward(ws, d_pred=d_pred)
+    eng.grads.mul_(1.0 / gscale)
     torch.cuda.synchronize()
+    assert torch.isfinite(eng.grads).all()
     loss, ref = out[12].item(), float(fx["loss"])
     print(f"\n[KD-loss parity] {name} {dtype}: loss {loss:.6f} reference {ref:.6f} delta {loss - ref:+.2e} ({abs(loss - ref) / ref:.2e} rel)")
     if dtype == "float32":
@@ -551,6 +570,8 @@ def test_full_config_at_baseline_and_librispeech_sizes(name, dtype, tol_l2, tol_
             want[l] = fx["layer_losses"][j] / 0.1
         want[11] = fx["layer_losses"][-1]
         np.testing.assert_allclose(out[:12].cpu().numpy(), want, rtol=2e-4)
+    elif dtype == "float16":
+        assert abs(loss - ref) < FP16_LOSS_TOL[name], (loss, ref)            # ABSOLUTE
     else:
         assert abs(loss - ref) < BF16_LOSS_TOL[name] * ref, (loss, ref)
     bad = []
@@ -562,7 +583,7 @@ def test_full_config_at_baseline_and_librispeech_sizes(name, dtype, tol_l2, tol_
         rn, got = float(fx[key]), gv.double().norm().item()
         # floor: the q / k projections of a randomly initialised deep stack have gradient norms of 4e-4 .. 3e-3 (near-uniform attention
         # over 250-600 keys) and k_proj.bias an analytically zero one; in bf16 those are rounding noise of the larger terms
-        if abs(got - rn) > tol_g * max(rn, 1e-3 if dtype == "float32" else 5e-2):
+        if abs(got - rn) > tol_g * max(rn, {"float32": 1e-3, "bf16": 5e-2, "float16": 1e-2}[dtype]):
             bad.append((k, got, rn))
     assert not bad, bad
 

@@ -1,7 +1,8 @@
-"""Where the bf16 KD-loss deviation comes from: the reference's loss on the full-size golden fixtures against
+"""Where the 16-bit KD-loss deviation comes from: the reference's loss on the full-size golden fixtures against
   (1) the fp32 engine (exact-fp32 MFMA),
-  (2) the fp32 engine fed weights ROUNDED to bf16 (isolates weight rounding: arithmetic and activations stay fp32),
-  (3) the bf16 engine (bf16 weights, bf16 activation storage, fp32 accumulation / LayerNorm / softmax / loss arithmetic).
+  (2) the fp32 engine fed weights ROUNDED to bf16 / fp16 (isolates weight rounding: arithmetic and activations stay fp32),
+  (3) the bf16 engine (bf16 weights, bf16 activation storage, fp32 accumulation / LayerNorm / softmax / loss arithmetic),
+  (4) the fp16 engine (IEEE half, the reference's own AMP precision: three more significand bits, same MFMA rate).
     python tools/bf16_delta.py [fixture ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,9 +31,11 @@ for name in names:
     w = torch.zeros(12); w[rl] = 0.1; w[11] = 1.0
     ref = float(fx["loss"])
     row = []
-    for tag, dtype, round_w in (("fp32", "float32", False), ("fp32 arithmetic, bf16-rounded weights", "float32", True), ("bf16", "bf16", False)):
+    for tag, dtype, round_w in (("fp32", "float32", None), ("fp32 arithmetic, bf16-rounded weights", "float32", torch.bfloat16),
+                                ("fp32 arithmetic, fp16-rounded weights", "float32", torch.float16), ("bf16", "bf16", None),
+                                ("fp16", "float16", None)):
         eng = StudentEngine(CustomStudentModelConfig(**cfg), dtype=dtype)
-        eng.load_state_dict({k: (v.to(torch.bfloat16).float() if round_w else v) for k, v in sd.items()})
+        eng.load_state_dict({k: (v.to(round_w).float() if round_w is not None else v) for k, v in sd.items()})
         ws = eng.forward(wav.cuda(), lens if min(lens) < S_ else None, training=False)
         out, _ = eng.kd_loss(ws, teacher, w.cuda(), torch.arange(12, dtype=torch.int32, device="cuda"), want_grad=False)
         row.append((tag, out[12].item() - ref))
