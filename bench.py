@@ -420,8 +420,10 @@ def main():
                                    ("VARIANT: fithubert.yaml student with %d layers + HuBERT-%s-shaped teacher (random init), fixed 10 s clips"
                                     % (cfg["distiller"]["encoder_layers"], "Large" if args.teacher == "large" else "Base")),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": SAMPLES_10S, "parallelism": f"dp{world}",
-                       "teacher": ("fp16" if args.dtype == "float16" else "bf16") + "; " + ("conv frontend, pos-conv, attention, add+LayerNorm, fc1 + GELU: HIP kernels shared with the student; "
-                                              "q|k|v / out-proj / fc2 GEMMs: hipBLASLt via PyTorch-ROCm" if args.teacher_frontend == "native"
+                       "teacher": ("fp16" if args.dtype == "float16" else "bf16") + "; " + (("conv frontend, pos-conv, attention, add+LayerNorm and every Linear (q|k|v, out-proj, fc1 + GELU, fc2): the library's own "
+                                               "HIP kernels, shared with the student; torch only holds the tensors" if os.environ.get("FH_TEACHER_LINEAR", "native") == "native" else
+                                               "conv frontend, pos-conv, attention, add+LayerNorm, fc1 + GELU: HIP kernels shared with the student; "
+                                               "q|k|v / out-proj / fc2 GEMMs: hipBLASLt via PyTorch-ROCm (FH_TEACHER_LINEAR=torch)") if args.teacher_frontend == "native"
                                               else "stock PyTorch-ROCm (MIOpen convs, hipBLASLt, SDPA)"), "optimizer": "fused AdamW every step"},
             "step_tflops": None if variant else round(value * GF_STEP / 1e3, 1),
             "step_frac_of_mfma_peak": None if variant else round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),

@@ -123,6 +123,7 @@ _ENGINE_SIGS = {
 SIGNATURES = {
     "fh_gemm": (_I, [C.POINTER(GemmDesc), _I, _P]),
     "fh_gemm_set_path": (_I, [_I]),
+    "fh_gemm_stream_loops": (_I, [_P, C.c_uint]),
     "fh_gemm_last_loop": (_I, []),
     "fh_gemm_reserve_cus": (_I, [_I]),
     "fh_gemm_tune": (_I, [_I]),

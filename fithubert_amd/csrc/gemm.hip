@@ -20,6 +20,16 @@ int g_gemm_path = -1;
 int g_tune_mode = 0;
 struct TuneChoice { int path, splitk; };
 std::unordered_map<unsigned long long, TuneChoice> g_tune;
+// Per-stream set of main loops (fh_gemm_stream_loops): bit i = loop i may be chosen for launches on that stream; 0 / absent = all.
+// Every loop of 256 x 256 tiles claims 128 - 160 KiB of a CU's LDS -- one workgroup per CU, nothing of another stream can share it --
+// while loops 2 (40 KiB) and 4 (72 KiB) leave room: a stream restricted to them trades some stand-alone speed for co-residence with
+// the other streams' kernels (the frozen teacher beside the student).
+std::unordered_map<hipStream_t, unsigned> g_stream_mask;
+unsigned stream_mask(hipStream_t st) {
+  if (g_stream_mask.empty()) return 0u;
+  auto it = g_stream_mask.find(st);
+  return it == g_stream_mask.end() ? 0u : it->second;
+}
 
 void resolve_path() {
   if (g_gemm_path < 0) {
@@ -40,7 +50,7 @@ int qoct(long v) {
   while ((v >> (lg + 1)) > 0) ++lg;
   return 100000 + lg * 4 + (int)(((v - (1L << lg)) * 4) >> lg);
 }
-unsigned long long tune_key(const GemmParams& p, int dtype) {
+unsigned long long tune_key(const GemmParams& p, int dtype, unsigned mask = 0u) {
   unsigned long long h = 1469598103934665603ULL;
   auto mix = [&](long v) { h = (h ^ (unsigned long long)v) * 1099511628211ULL; };
   mix(qoct(p.M)); mix(qoct(p.N)); mix(qoct(p.Kseg)); mix(p.X.nseg); mix(p.X.layout); mix(p.Y.layout); mix(p.groups);
@@ -49,6 +59,7 @@ unsigned long long tune_key(const GemmParams& p, int dtype) {
   if (p.ep.aux_factor) mix(104729);
   if (p.Y.seg1_limit > 0) mix(7919 + p.Y.seg1_limit);
   if (dtype == 2) mix(15485863);  // f16 launches keep their own measurements
+  if (mask) mix(0x5bd1e995L + mask);  // ... and so do launches of a stream with a restricted set of loops
   return h;
 }
 int ring_splitk(const GemmParams& p, int tm, int tn, int target) {
@@ -65,8 +76,10 @@ int ring_splitk(const GemmParams& p, int tm, int tn, int target) {
 // several times, so only throw-away passes -- StudentEngine.autotune -- may run with tuning on).
 TuneChoice tune_measure(const GemmParams& p, int dtype, hipStream_t stream) {
   std::vector<TuneChoice> cand;
-  cand.push_back({2, p.splitk});
+  const unsigned mask = stream_mask(stream);
+  cand.push_back({2, p.splitk});   // (loop 2 takes any launch: it stays the fallback of a restricted stream too)
   auto add = [&](int path, int sk) {
+    if (mask && !((mask >> path) & 1u)) return;
     for (auto& c : cand)
       if (c.path == path && c.splitk == sk) return;
     cand.push_back({path, sk});
@@ -141,7 +154,7 @@ TuneChoice tune_measure(const GemmParams& p, int dtype, hipStream_t stream) {
 int launch_16(const GemmParams& p, int dtype, hipStream_t stream) {
   resolve_path();
   if (g_gemm_path != 9) return launch_path(p, g_gemm_path, dtype, stream);
-  const unsigned long long key = tune_key(p, dtype);
+  const unsigned long long key = tune_key(p, dtype, stream_mask(stream));
   auto it = g_tune.find(key);
   if (it == g_tune.end()) {
     if (!g_tune_mode) return launch_path(p, 2, dtype, stream);
@@ -167,6 +180,10 @@ extern "C" int fh_gemm_reserve_cus(int n) {
   const int old = fh_g_reserve_cus;
   if (n >= 0) fh_g_reserve_cus = n;
   return old;
+}
+extern "C" int fh_gemm_stream_loops(fh_stream_t stream, unsigned mask) {
+  if (mask) g_stream_mask[(hipStream_t)stream] = mask; else g_stream_mask.erase((hipStream_t)stream);
+  return 0;
 }
 extern "C" int fh_gemm_set_path(int path) {
   g_gemm_path = path;

@@ -177,6 +177,15 @@ class W2V2Distil:
         self.teacher_stream = _low_priority_stream(self.device) if self.device.type == "cuda" else None
         if os.environ.get("FH_TEACHER_STREAM", "1") == "0":   # A/B: teacher serialised on the main stream
             self.teacher_stream = None
+        # FH_TEACHER_LOOPS / FH_STUDENT_LOOPS = comma-separated GEMM main loops a stream's per-shape choice may use (fh_gemm_stream_loops)
+        if self.device.type == "cuda":
+            for env, st in (("FH_TEACHER_LOOPS", self.teacher_stream), ("FH_STUDENT_LOOPS", torch.cuda.current_stream(self.device))):
+                v = os.environ.get(env)
+                if v and st is not None:
+                    mask = 0
+                    for tok in v.split(","):
+                        mask |= 1 << int(tok)
+                    L.lib().fh_gemm_stream_loops(st.cuda_stream, mask)
 
     # ------------------------------------------------------------------ loss tables
     def _set_loss_tables(self):

@@ -219,9 +219,41 @@ class CustomStudentModel(nn.Module):
                             v.copy_(src[sk].float())
         self.mark_params_updated()
 
+    def _early_exit(self, source, padding_mask, layer: int):
+        """``forward(..., layer=k)`` (modules/model.py:424,554-558 -> modules/module.py:270,303-337): the encoder's module list -- the
+        time-reduction conv at index ``tr_layer_index`` = 0, then the transformer layers -- stops behind module k; ``layer_results``
+        holds the transformer layers run so far and the projection applies to module k's output.  An inference surface: it runs a
+        truncated copy of the student (same weights, cached per k) without autograd."""
+        n_mod = self.cfg.encoder_layers + (1 if self.cfg.enable_tr_layer else 0)
+        k = int(layer) + 1 - (1 if self.cfg.enable_tr_layer else 0)     # transformer layers that run
+        if self.layerwise_proj and self._heads_on:
+            # the reference indexes layer_results with every head's number (model.py:495-499)
+            raise IndexError("list index out of range")
+        if k < 1:
+            raise NotImplementedError("early exit behind the time-reduction conv alone (layer=0 with enable_tr_layer) is not built")
+        import dataclasses
+        key = (k, self._heads_on)
+        cache = self.__dict__.setdefault("_exit_models", {})
+        sub = cache.get(key)
+        if sub is None:
+            cfg = dataclasses.replace(self.cfg, encoder_layers=k, init_conv_layers=False, init_encoder_layers=0)
+            for f in ("_teacher_task_agnostic", "_cnn_weight"):
+                setattr(cfg, f, getattr(self.cfg, f))
+            sub = CustomStudentModel(cfg, dtype=self.engine.dtype_name, device=str(self.engine.device))
+            if not self._heads_on:
+                sub._disable_projection_heads()
+            cache[key] = sub
+        own = self.state_dict()
+        want = sub._name_map()
+        sub.load_state_dict({n: own[n] for n in want if n in own}, strict=False)   # final_proj.* / shared heads keep their names
+        sub.train(self.training)
+        with torch.no_grad():
+            res = sub.forward(source, padding_mask)
+        return res
+
     def forward(self, source, padding_mask=None, layer=None):
-        if layer is not None:
-            raise NotImplementedError("early exit at `layer` is not built")
+        if layer is not None and int(layer) < self.cfg.encoder_layers + (1 if self.cfg.enable_tr_layer else 0) - 1:
+            return self._early_exit(source, padding_mask, int(layer))
         if not source.is_cuda:
             raise RuntimeError("CustomStudentModel (fithubert_amd) computes on the GPU only; move `source` to the device")
         source = source.float().contiguous()

@@ -201,12 +201,13 @@ class _NativeFrontend:
         self.dh = D // self.heads
         self.pre_ln = bool(model.cfg.layer_norm_first)
         self.layers_native = self.dh <= 64 and self.dh % 8 == 0   # head widths the attention kernel is built for
-        # fc1 + GELU: hipBLASLt GEMM + PyTorch GELU kernel measured 0.9 ms / forward faster (B = 128) than the HIP GEMM with the
-        # GELU epilogue on this K = 768, N = 3072 shape; FH_TEACHER_FC1=native selects the fused kernel
+        # fc1 + bias + GELU as ONE own GEMM with the GELU in its epilogue (default since the fast bf16 GELU: 0.2 ms / forward ahead of
+        # hipBLASLt + a GELU pass at B = 128); FH_TEACHER_FC1=torch selects the library GEMM + streaming GELU
         self.fc1_native = os.environ.get("FH_TEACHER_FC1", "native") == "native"
-        # the other three Linear products of a layer (q|k|v, out-proj, fc2): hipBLASLt through F.linear ('torch') or the library's
-        # own MFMA GEMM through fh_conv1d_forward ('native'); FH_TEACHER_LINEAR selects
-        self.linear_native = os.environ.get("FH_TEACHER_LINEAR", "torch") == "native"
+        # the other three Linear products of a layer (q|k|v, out-proj, fc2): the library's own MFMA GEMM through fh_conv1d_forward
+        # ('native', default since round 3: no library GEMM is left on the step's hot path) or hipBLASLt through F.linear ('torch',
+        # kept for A/B: it is 3 - 10 % ahead on these three shapes stand-alone, 0.5 % of the step -- DESIGN.md section 4)
+        self.linear_native = os.environ.get("FH_TEACHER_LINEAR", "native") == "native"
         self.tl = []
         if self.layers_native:
             f32 = lambda t: t.detach().float().contiguous()

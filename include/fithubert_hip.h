@@ -101,6 +101,10 @@ int fh_gemm(const fh_gemm_desc* d, int dtype, fh_stream_t stream);
  * next tile's first two K-tiles before the epilogue of the current one; launches with the bf16-staged epilogue only, others fall
  * back to loop 2), 9 = per-shape choice (default), -1 = re-read env FH_GEMM_PATH (reg | 1..8). */
 int fh_gemm_set_path(int path);
+/* Restrict the per-shape choice for launches on `stream` to the loops whose bit is set in `mask` (bit i = loop i, loop 2 always stays
+ * available as the fallback; 0 = no restriction).  The 256 x 256 loops claim 128 - 160 KiB of a CU's LDS, i.e. the whole CU; loops 2
+ * (40 KiB) and 4 (72 KiB) let kernels of OTHER streams share it -- the frozen teacher's stream beside the student's. */
+int fh_gemm_stream_loops(fh_stream_t stream, unsigned mask);
 /* The main loop the last bf16 launch ran (fh_gemm_set_path numbering): what a forced or tuned path resolved to. */
 int fh_gemm_last_loop(void);
 /* CUs the persistent loop 8 leaves free (rounded up to a multiple of 8, one per XCD; returns the previous value, n < 0 only reads).

@@ -514,7 +514,7 @@ def test_fp16_mode_follows_use_fp16_trains_and_skips_overflowed_steps(tmp_path):
     assert task.amp and task.engine.c.dtype == L.DT_F16 and task.engine.elem == torch.float16
     assert next(task.teacher_model.model.parameters()).dtype == torch.float16
     y2 = _cfg(encoder_layers=3)
-    y2["train"]["use_fp16"] = False
+    y2["train"].update(distil_random_layer=2, use_fp16=False)
     assert not W2V2Distil(y2, device=DEV, teacher_cfg=tc, seed=0).amp
     task.configure_optimizers(num_training_steps=40)
     batch = fixed_length_batch(4, 16000, seed=0, device=DEV)
@@ -549,3 +549,38 @@ def test_fp16_mode_follows_use_fp16_trains_and_skips_overflowed_steps(tmp_path):
     t2.load_checkpoint(ck)
     assert t2.amp_counters() == task.amp_counters() and t2.opt_step == task.opt_step
     assert torch.equal(t2.opt_m, task.opt_m)
+
+
+def test_forward_layer_early_exit():
+    """``forward(source, padding_mask, layer=k)`` / ``extract_features(..., layer)`` (modules/model.py:424,554-558; encoder loop
+    modules/module.py:303-337): the module list (TR conv at index 0, then the layers) stops behind module k.  With the layer-wise
+    heads enabled the reference indexes ``layer_results`` out of range (model.py:495-499) -- same exception here; with the heads
+    disabled (deployment form, model.py:393-399) ``x`` is ``final_proj`` of module k's output and ``layer_results`` is truncated."""
+    import torch.nn.functional as F
+    cfg = CustomStudentModelConfig(**dict(_cfg(encoder_layers=4)["distiller"], dropout=0.0, attention_dropout=0.0,
+                                          activation_dropout=0.0, dropout_input=0.0))
+    m = CustomStudentModel(cfg, dtype="float32", device=DEV, init_seed=3).eval()
+    g = torch.Generator().manual_seed(1)
+    wav = (0.3 * torch.randn(2, 16000, generator=g)).to(DEV)
+    pm = torch.zeros(2, 16000, dtype=torch.bool, device=DEV)
+    pm[1, 12000:] = True
+    with torch.no_grad():
+        full = m(wav, pm)
+        assert torch.equal(m(wav, pm, layer=4)["x"], full["x"])          # the last module: nothing is cut
+        with pytest.raises(IndexError):
+            m(wav, pm, layer=2)
+        m._disable_projection_heads()
+        full = m(wav, pm)
+        sd = m.state_dict()
+        for layer in (1, 2, 3):                                          # modules 0 = TR conv, 1.. = transformer layers
+            k = layer                                                    # transformer layers that ran
+            res = m.extract_features(wav, pm, layer=layer)
+            assert len(res["layer_results"]) == k and len(res["tr_layer_results"]) == 1 and res["projections"] is None
+            for i in range(k):
+                assert _rel_l2(res["layer_results"][i][0], full["layer_results"][i][0]) < 1e-5, (layer, i)
+                assert _rel_l2(res["layer_results"][i][2], full["layer_results"][i][2]) < 1e-5, (layer, i)
+            h = full["layer_results"][k - 1][0].transpose(0, 1)          # B x T2 x D
+            up = F.conv_transpose1d(h.transpose(1, 2), sd["final_proj.upsampler.weight"], sd["final_proj.upsampler.bias"], stride=2)
+            want = F.linear(up.transpose(1, 2), sd["final_proj.lin_proj.weight"], sd["final_proj.lin_proj.bias"])
+            assert res["x"].shape == want.shape and _rel_l2(res["x"], want) < 1e-4, layer
+            assert torch.equal(res["padding_mask"], full["padding_mask"])

@@ -583,7 +583,9 @@ def test_full_config_at_baseline_and_librispeech_sizes(name, dtype, tol_l2, tol_
         rn, got = float(fx[key]), gv.double().norm().item()
         # floor: the q / k projections of a randomly initialised deep stack have gradient norms of 4e-4 .. 3e-3 (near-uniform attention
         # over 250-600 keys) and k_proj.bias an analytically zero one; in bf16 those are rounding noise of the larger terms
-        if abs(got - rn) > tol_g * max(rn, {"float32": 1e-3, "bf16": 5e-2, "float16": 1e-2}[dtype]):
+        # (fp16: the last layer's k_proj.weight at T2 = 613 comes out at 2.8e-4 against 1.8e-4, with either loss scale -- rounding noise of
+        # the 613-key sums, not underflow)
+        if abs(got - rn) > tol_g * max(rn, {"float32": 1e-3, "bf16": 5e-2, "float16": 2e-2}[dtype]):
             bad.append((k, got, rn))
     assert not bad, bad
 

@@ -495,6 +495,83 @@ def test_8_phase_refill_is_race_free(loop, K, ys):
     assert (first.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("loop", [8, 7])
+@pytest.mark.parametrize("K,ys", [(1000, False), (768, False), (1000, True)])
+def test_8_phase_refill_under_load(loop, K, ys):
+    """The refill of a tile-buffer quarter that the OTHER wave group may still be reading is ordered by FH_REFILL_GUARD (gemm_loops.cuh:
+    this wave's later LDS read has returned => theirs, issued before the barrier, were served).  The window that guard closes moves
+    with memory latency, so this runs the loops where the step runs them -- beside another stream: 5,000 launches of a K-tail shape
+    (zero pieces: the fastest DMA to arrive) and of a full-K shape on one stream while a second stream keeps the device busy with the
+    teacher's conv-layer GEMM shape (loop 7: its workgroups interleave with the launches under test) and a 1 GiB streaming fill
+    (co-resident with the persistent loop's workgroups: concurrent HBM / L2 traffic).  Every launch is compared ON THE DEVICE, bit for
+    bit, with the result the same loop produced alone on a quiet device, which in turn must equal loop 3's -- the ring loop, whose
+    stages are only reused behind a full barrier and which needs no ordering assumption -- to the last bit when the two loops share
+    their summation order, within one bf16 rounding otherwise."""
+    dev = "cuda"
+    torch.manual_seed(21)
+    M, N = 256 * 300 + 19, 512
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    Wm = W.t().contiguous() if ys else W
+    bias = torch.randn(N, device=dev)
+    lib = L.lib()
+
+    def desc(out):
+        d = L.GemmDesc()
+        d.X = L.operand(X.data_ptr(), 0, K)
+        d.Y = L.operand(Wm.data_ptr(), 1 if ys else 0, N if ys else K)
+        d.C = out.data_ptr()
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+        d.ep = L.epilogue(bias=bias.data_ptr())
+        return d
+
+    # the second stream's work: a conv-layer-shaped product (k = 3, s = 2 windows of a 512-channel tensor) and a fill
+    Tc = 40000
+    cx = torch.randn(4, Tc, 512, device=dev).to(torch.bfloat16)
+    cw = (torch.randn(512, 1536, device=dev) / 40).to(torch.bfloat16)
+    cy = torch.empty(4, (Tc - 3) // 2 + 1, 512, device=dev, dtype=torch.bfloat16)
+    fill = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+    cd = L.GemmDesc()
+    cd.X = L.operand(cx.data_ptr(), 0, 2 * 512, rpb=cy.shape[1], bstride=Tc * 512)
+    cd.Y = L.operand(cw.data_ptr(), 0, 1536)
+    cd.C = cy.data_ptr()
+    cd.M, cd.N, cd.Kseg, cd.ldc, cd.groups, cd.splitk = 4 * cy.shape[1], 512, 1536, 512, 1, 1
+    cd.ep = L.epilogue(act=L.ACT_GELU)
+    try:
+        outs = [torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16) for _ in range(3)]
+        lib.fh_gemm_set_path(3)
+        _run(desc(outs[0]), L.DT_BF16)
+        ref3 = outs[0].clone()
+        lib.fh_gemm_set_path(loop)
+        _run(desc(outs[0]), L.DT_BF16)
+        assert lib.fh_gemm_last_loop() == loop
+        quiet = outs[0].clone()
+        if not torch.equal(quiet, ref3):   # a different summation order inside a K-tile: then within one rounding of each other
+            assert (quiet.double() - ref3.double()).abs().max().item() <= 2.0 ** -7 * ref3.double().abs().max().item()
+        bad = torch.zeros((), device=dev, dtype=torch.int64)
+        side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        n_launch = 5000
+        for i in range(n_launch):
+            if i % 6 == 0:
+                with torch.cuda.stream(side):
+                    lib.fh_gemm_set_path(7)
+                    L.check(lib.fh_gemm(cd, L.DT_BF16, side.cuda_stream), "fh_gemm (side stream)")
+                    lib.fh_gemm_set_path(loop)
+                    fill.fill_(float(i))
+            out = outs[i % 3]
+            L.check(lib.fh_gemm(desc(out), L.DT_BF16, main.cuda_stream), "fh_gemm")
+            bad += (out != quiet).any()
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0, f"{int(bad.item())} of {n_launch} launches differ from the quiet-device result"
+    finally:
+        lib.fh_gemm_set_path(9)
+    ref = X.double() @ W.double().t() + bias.double()
+    assert (quiet.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("loop", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_saved_gelu_derivative_forward_and_backward(loop):
     """fh_gemm_epilogue.aux_factor: the forward stores GELU'(pre-activation) through `preact` (not the pre-activation) and the

@@ -504,7 +504,7 @@ def _relation_loss_ref(s, t, mode):
 
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
 @pytest.mark.parametrize("which,mode", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (3, 130, True), (2, 200, True)])
+@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (3, 130, True), (2, 200, True), (2, 499, True)])   # 499 = the 10 s utterance without a TR layer
 def test_relation_transfer_loss_and_gradient(dt, which, mode, B, T, masked):
     """fh_relation_kd: attention-logit mse / kl-div and value-relation kl-div against the materialised fp64 form and its
     autograd gradient; student 40-wide heads, teacher 64-wide heads (fithubert.yaml vs HuBERT Base), the teacher masking one
