@@ -36,11 +36,13 @@ LAYOUTS = {0: "0, 0", 1: "0, 1", 2: "1, 0", 3: "1, 1"}  # <X layout, Y layout>: 
 LOOPS = {0: "gemm_kernel<{t}, {l}>", 1: "gemm_small_kernel<{t}>", 2: "gemm32_kernel<{t}, {l}>", 3: "gemm_ring_kernel<{t}, {l}, 256, 256, 2, 4, 64, 2>",
          4: "gemm_ring_kernel<{t}, {l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{t}, {l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{t}, {l}>",
          7: "gemm_8ph_kernel<{t}, {l}>"}
-ELEM_NAME = {"bf16": "__bf16", "float16": "_Float16", "float32": "float"}   # the element type as rocprofv3 prints the template argument
+ELEM_NAME = {"bf16": "bf16", "float16": "f16", "float32": "float"}   # canonical element tag (tools/pmc_summary.py canon_kernel_name maps
+                                                                     # rocprofv3's spellings -- "__bf16", "bool _Accum", mangled DF16b -- onto it)
 
 
 def kernel_name(slot: int, dtype: str = "bf16") -> str:
-    """fh_prof_collect slot -> the kernel's name as rocprofv3 prints it (anonymous namespace prefix dropped)."""
+    """fh_prof_collect slot -> the kernel's canonical name: template name + <element tag, integer arguments> (what
+    tools/pmc_summary.py reduces rocprofv3's kernel names to)."""
     loop, var = slot // 8, slot % 8
     t = ELEM_NAME[dtype]
     if loop == 1 and var < 4:
@@ -48,6 +50,66 @@ def kernel_name(slot: int, dtype: str = "bf16") -> str:
     if var < 4:
         return "gemm_kernel<float, %s>" % LAYOUTS[var]
     return LOOPS[loop].format(t=t, l=LAYOUTS[var - 4])
+
+
+def collect_launches(lib, cap: int = 20000):
+    """fh_prof_collect_launches -> list of dicts (one per recorded GEMM launch)."""
+    ms, fl, rows = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_int * (9 * cap))()
+    n = lib.fh_prof_collect_launches(ms, fl, rows, cap)
+    keys = ("M", "N", "K", "groups", "xl", "yl", "loop", "atomic", "tag")
+    return [dict(zip(keys, rows[9 * i: 9 * i + 9]), ms=ms[i], flops=fl[i]) for i in range(n)]
+
+
+def slot_sums(launches, dtype_is_16: bool):
+    """per-slot sums in fh_prof_collect's numbering (loop * 8 + 4 + layouts; loop 8 -> 8 + layouts; fp32 -> layouts)."""
+    ms, fl, ln = [0.0] * 64, [0.0] * 64, [0] * 64
+    for r in launches:
+        lay = r["xl"] * 2 + r["yl"]
+        v = lay if not dtype_is_16 else (8 + lay if r["loop"] == 8 else 8 * (r["loop"] & 7) + 4 + lay)
+        ms[v] += r["ms"]; fl[v] += r["flops"]; ln[v] += 1
+    return ms, fl, ln
+
+
+CLASS_NOTE = {
+    "student_conv_forward": "conv layers 1-8 of the student frontend as GEMMs over channels-last windows (modules/module.py:94-102): HBM-bound at K = 128 / 256",
+    "student_conv_dgrad": "their data gradients (x saved GELU'): HBM-bound",
+    "weight_gradients": "every weight gradient of the student (atomic fp32 accumulation, side stream): HBM-bound on the conv layers",
+    "student_layer_gemms": "q|k|v, out-proj, fc1, fc2, the merged projection heads and their data gradients (K, N <= 1536, M = B x T2)",
+    "teacher_conv": "the frozen teacher's conv layers (N = 512, K = 1536 / 1024)",
+    "teacher_linear": "the frozen teacher's q|k|v, out-proj, fc1 + GELU, fc2",
+}
+
+
+def classify(r) -> str:
+    if r["atomic"]:
+        return "weight_gradients"
+    big = r["M"] >= 100000
+    if r["tag"] == 1:
+        return "teacher_conv" if big else "teacher_linear"
+    if big:
+        return "student_conv_dgrad" if r["yl"] == 1 else "student_conv_forward"
+    return "student_layer_gemms"
+
+
+def class_table(launches, steps: int, peak: float):
+    out = {}
+    for r in launches:
+        c = out.setdefault(classify(r), {"launches_per_step": 0, "ms_per_step": 0.0, "_fl": 0.0, "_by": 0.0})
+        c["launches_per_step"] += 1
+        c["ms_per_step"] += r["ms"]
+        c["_fl"] += r["flops"]
+        # algorithmic bytes: both operands read once, the output written once, 2 B per element (an fp32 weight gradient counts 2 B too: lower bound)
+        c["_by"] += 2.0 * r["groups"] * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"])
+    for name, c in out.items():
+        t = c["ms_per_step"] * 1e-3
+        c["tflops"] = round(c.pop("_fl") / t / 1e12, 1) if t > 0 else None
+        c["algorithmic_tb_per_s"] = round(c.pop("_by") / t / 1e12, 2) if t > 0 else None
+        c["frac_of_mfma_peak"] = round(c["tflops"] / peak, 4) if c["tflops"] else None
+        c["frac_of_hbm_peak"] = round(c["algorithmic_tb_per_s"] / 8.0, 4) if c["algorithmic_tb_per_s"] else None
+        c["launches_per_step"] = round(c["launches_per_step"] / max(1, steps), 1)
+        c["ms_per_step"] = round(c["ms_per_step"] / max(1, steps), 3)
+        c["what"] = CLASS_NOTE.get(name, "")
+    return out
 
 
 def cpu_baseline(cfg, seconds_budget: float = 28.0):
@@ -166,6 +228,19 @@ def run_variants(task, cfg, args, dev, budget_s: float):
                                       "ms_per_micro_batch": round(dt / 16 * 1e3, 2), "ms_per_optimizer_step": round(dt / 4 * 1e3, 2),
                                       "workload": "fithubert.yaml as shipped: batch_size 3, accumulate_grad_batches 4, fixed 10 s clips"}
         del t3
+    # ---- the same workload in the reference's own precision (train.py:469,496 precision=16): IEEE-half operands, dynamic loss scaling
+    if left() > 40 and args.dtype == "bf16":
+        t16 = W2V2Distil(copy.deepcopy(cfg), dtype="float16", device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native")
+        t16.configure_optimizers(num_training_steps=100)
+        batches = [fixed_length_batch(args.batch, SAMPLES_10S, seed=70 + i, device=dev) for i in range(2)]
+        dt, utt, smp = time_steps(t16, batches, 5, 3)
+        c = t16.amp_counters()
+        out["float16"] = {"per_gpu_batch": args.batch, "utt_per_s": round(utt / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 2),
+                          "optimizer_steps_applied": c["applied"], "skipped_for_overflow": c["skipped"], "loss_scale": c["loss_scale"],
+                          "workload": "the headline workload with --dtype float16 (fp16 student + fp16 teacher, fh_adamw_amp); KD-loss "
+                                      "deviation of this mode from the fp32 reference: DESIGN.md section 2"}
+        del t16
+        torch.cuda.empty_cache()
     # ---- 24-layer student + HuBERT-Large-shaped teacher
     if left() > 45:
         c2 = copy.deepcopy(cfg)
@@ -345,10 +420,9 @@ def main():
     loss = float(out[-1].item())
 
     # ---- roofline of the dominant kernel: the MFMA GEMM, per-launch HIP events on its own stream
-    ms = (C.c_double * 64)()
-    fl = (C.c_double * 64)()
-    ln = (C.c_long * 64)()
-    lib.fh_prof_collect(ms, fl, ln)
+    live = collect_launches(lib)
+    ms, fl, ln = slot_sums(live, args.dtype != "float32")
+    n_prof = max(1, min(args.prof_steps, args.steps))
     roof = None
     tot_ms = sum(ms)
     if tot_ms > 0:
@@ -362,6 +436,13 @@ def main():
                 "all_gemm": {"achieved": round(sum(fl) / (tot_ms * 1e-3) / 1e12, 2), "launches": int(sum(ln)),
                              "ms_per_step": round(tot_ms / max(1, min(args.prof_steps, args.steps)), 3)},
                 "note": "HIP events around every GEMM launch during the last %d timed steps" % min(args.prof_steps, args.steps)}
+        # the same launches by CLASS: the dominant kernel's average hides the K = 480 layer GEMMs and the HBM-bound conv launches
+        roof["classes"] = {"live": class_table(live, n_prof, peak),
+                           "note": "GEMM launches of the last timed steps grouped by role; ms_per_step sums launch durations (three "
+                                   "concurrent streams, so the sum can exceed the step); tflops / algorithmic_tb_per_s = algorithmic "
+                                   "FLOPs / bytes (operands read once, output written once) over that time; frac_of_mfma_peak against "
+                                   "%.0f TFLOP/s, frac_of_hbm_peak against 8 TB/s; 'isolated' = the same on 2 untimed steps with the "
+                                   "teacher serialised on the student's stream" % peak}
 
     # ---- the same measurement with nothing else on the device: 2 extra steps AFTER the timed region with the teacher on
     # the main stream (no concurrent kernels), so the per-launch durations are the GEMM's own rather than its share of
@@ -376,8 +457,9 @@ def main():
         lib.fh_prof_enable(0)
         torch.cuda.synchronize()
         task.teacher_stream = side
-        ms2, fl2, ln2 = (C.c_double * 64)(), (C.c_double * 64)(), (C.c_long * 64)()
-        lib.fh_prof_collect(ms2, fl2, ln2)
+        iso = collect_launches(lib)
+        ms2, fl2, ln2 = slot_sums(iso, args.dtype != "float32")
+        roof["classes"]["isolated"] = class_table(iso, 2, peak)
         if ms2[v] > 0:
             ach2 = fl2[v] / (ms2[v] * 1e-3) / 1e12
             roof["isolated"] = {"achieved": round(ach2, 2), "frac": round(ach2 / roof["peak"], 4),
@@ -396,6 +478,7 @@ def main():
             ent = pmc.get("variants", {}).get(roof["kernel"])
             if ent and pmc.get("batch") == B:
                 roof["traffic"] = ent.get("bytes_per_launch")
+                roof["traffic_source"] = "committed profile (profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on an earlier box; not measured in this run)"
                 roof["traffic_note"] = pmc.get("note")
                 # MFMA-busy of the same kernel (SQ_VALU_MFMA_BUSY_CYCLES over the chip's matrix-pipe cycles) and the launch's
                 # algorithmic bytes beside the measured ones, from the same committed rocprofv3 summary

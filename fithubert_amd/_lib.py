@@ -131,6 +131,8 @@ SIGNATURES = {
     "fh_gemm_tune_import": (_I, [_P, _P, _P, _I]),
     "fh_prof_enable": (_I, [_I]),
     "fh_prof_collect": (_I, [_P, _P, _P]),
+    "fh_prof_collect_launches": (_I, [_P, _P, _P, _I]),
+    "fh_prof_tag": (_I, [_I]),
     "fh_conv0_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
     "fh_conv0_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fh_conv0_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
@@ -156,6 +158,8 @@ SIGNATURES = {
     "fh_relation_kd_nblk": (_I, [_I, _I, _I]),
     "fh_relation_kd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "fh_conv1d_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fh_linear_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fh_conv0_layernorm_gelu_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fh_posconv_wide_prepare": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fh_posconv_wide_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fh_cast": (_I, [_I, _P, _P, _L, _P]),

@@ -142,4 +142,24 @@ int fh_conv1d_forward(int dtype, const void* x, const void* wf, const float* bia
   return fh_gemm_launch(g, dtype, ST(stream));
 }
 
+// y = [gelu](x W^T + bias) [+ residual];  preact (optional) receives x W^T + bias
+int fh_linear_forward(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* preact, void* y, int M,
+                      int K, int N, int gelu, fh_stream_t stream) {
+  GemmParams g = fh_gemm_params();
+  g.X = fh_operand(x, FH_R_CONTIG, K);
+  g.Y = fh_operand(w, FH_R_CONTIG, K);
+  g.C = y;
+  g.M = M; g.N = N; g.Kseg = K; g.ldc = N;
+  g.ep.bias = bias;
+  g.ep.act = gelu ? FH_ACT_GELU : FH_ACT_NONE;
+  g.ep.residual = residual;
+  g.ep.preact = preact;
+  return fh_gemm_launch(g, dtype, ST(stream));
+}
+
+int fh_conv0_layernorm_gelu_forward(int dtype, const float* wave, const float* w, const float* bias, const float* gamma,
+                                    const float* beta, void* y, int B, int S, int C0, int K, int stride, float eps, fh_stream_t stream) {
+  return fh_conv0_ln_gelu_launch(dtype, wave, w, bias, gamma, beta, y, B, S, C0, K, stride, eps, ST(stream));
+}
+
 }  // extern "C"

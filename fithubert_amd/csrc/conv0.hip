@@ -322,6 +322,65 @@ long fh_conv0_scratch_n(int B, int T0, int C0) {
   return 2L * B * nchunk * C0 + 2L * B * C0 + (long)B * fh_conv0_bwd_blocks(B, (int)nchunk) * C0 * (MAXK + 2);
 }
 
+// ---------------------------------------------------------------- layer_norm-mode frontend (HuBERT Large): conv + bias + LayerNorm + GELU
+//   reference: modules/module.py:54-64 (Conv1d(1, C0, k, stride, bias=conv_bias) -> TransposeLast -> Fp32LayerNorm(C0) ->
+//   TransposeLast -> GELU) as the teacher's first block (extractor_mode = layer_norm, utils/utils.py:102-149 loads such a model).
+// One WAVE per output frame: lane l owns the C0 / 64 channels l, l + 64, ... (their taps in registers), the frame's K samples are
+// wave-uniform LDS reads, mean / variance over the channels are two wave reductions, and the normalised, activated row is written
+// once -- the un-normalised conv output (B x T0 x C0, 2.1 GB at B = 64) never exists.
+template <typename T, int KT, int CPL>
+__global__ void __launch_bounds__(256) conv0_ln_gelu_kernel(Conv0Args a, const float* __restrict__ bias, float eps, T* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sw = smem;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int nt = stage_wave(a, b, chunk, sw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float w[CPL][KT], bi[CPL], ga[CPL], be[CPL];
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) {
+    const int c = lane * CPL + e;    // CPL consecutive channels per lane: one 2 * CPL-byte store per frame
+#pragma unroll
+    for (int j = 0; j < KT; ++j) w[e][j] = j < a.K ? a.w[c * a.K + j] : 0.f;
+    bi[e] = bias ? bias[c] : 0.f;
+    ga[e] = a.gamma[c];
+    be[e] = a.beta[c];
+  }
+  const float inv_c = 1.0f / (float)a.C0;
+  for (int t = wave; t < nt; t += 4) {
+    const float* x = sw + t * a.stride;
+    float xs[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) xs[j] = x[j];
+    float v[CPL], s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+      float acc = bi[e];
+#pragma unroll
+      for (int j = 0; j < KT; ++j) acc = fmaf(w[e][j], xs[j], acc);
+      v[e] = acc;
+      s1 += acc;
+    }
+    const float mu = wave_sum(s1) * inv_c;
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+      const float d = v[e] - mu;
+      s2 = fmaf(d, d, s2);
+    }
+    const float rs = rsqrtf(wave_sum(s2) * inv_c + eps);
+    float o[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) o[e] = gelu_t<T>(fmaf((v[e] - mu) * rs, ga[e], be[e]));
+    T* dst = y + ((long)b * a.T0 + (long)chunk * TCH + t) * a.C0 + lane * CPL;
+    if constexpr (sizeof(T) == 2 && CPL == 8) {
+      st16(dst, pack16<T>(o));
+    } else {
+#pragma unroll
+      for (int e = 0; e < CPL; e += 4) st4(dst + e, o + e);
+    }
+  }
+}
+
 int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, float2* part, int B, int S, int C0, int K, int stride, float eps,
                         hipStream_t st) {
@@ -382,6 +441,31 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
   FH_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv0_bwd_combine_kernel, dim3(B, (C0 + CBW - 1) / CBW), dim3(256), 0, st, (const float*)part, (const float*)wpart, w, gamma, mean,
                      rstd, dw, dgamma, dbeta, a.nchunk, nblk, C0, K, K == 10 ? 10 : MAXK, a.T0, grad_scale);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_conv0_ln_gelu_launch(int dtype, const float* wave, const float* w, const float* bias, const float* gamma, const float* beta, void* y,
+                            int B, int S, int C0, int K, int stride, float eps, hipStream_t st) {
+  if (K > MAXK || (C0 != 512 && C0 != 256)) return -203;   // 64 lanes x 8 (4) consecutive channels
+  Conv0Args a;
+  a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta;
+  a.B = B; a.S = S; a.C0 = C0; a.K = K; a.stride = stride;
+  a.T0 = (S - K) / stride + 1;
+  a.nchunk = fh_conv0_nchunk(a.T0);
+  dim3 grid(a.nchunk, B), block(256);
+  const size_t smem = smem_bytes(stride, K, false);
+#define FH_C0_LN(T, KT, CPL) hipLaunchKernelGGL((conv0_ln_gelu_kernel<T, KT, CPL>), grid, block, smem, st, a, bias, eps, (T*)y)
+#define FH_C0_LN_T(T)                                                    \
+  do {                                                                   \
+    if (C0 == 512) { if (K == 10) FH_C0_LN(T, 10, 8); else FH_C0_LN(T, MAXK, 8); } \
+    else { if (K == 10) FH_C0_LN(T, 10, 4); else FH_C0_LN(T, MAXK, 4); } \
+  } while (0)
+  if (dtype == 0) FH_C0_LN_T(float);
+  else if (dtype == 2) FH_C0_LN_T(f16);
+  else FH_C0_LN_T(bf16);
+#undef FH_C0_LN_T
+#undef FH_C0_LN
   FH_CHECK_LAUNCH();
   return 0;
 }

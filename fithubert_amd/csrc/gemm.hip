@@ -169,7 +169,8 @@ int launch_16(const GemmParams& p, int dtype, hipStream_t stream) {
 
 // ------------------------------------------------------------------ optional per-launch HIP-event timing (bench.py roofline)
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int variant; int M, N, K, groups, splitk; };
+struct ProfRec { hipEvent_t a, b; double flops; int variant; int M, N, K, groups, splitk, tag, atomic, loop, xl, yl; };
+int g_prof_tag = 0;
 std::vector<ProfRec> g_prof;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 bool g_prof_on = false;
@@ -211,6 +212,30 @@ extern "C" int fh_gemm_tune_export(unsigned long long* keys, int* paths, int* sp
 extern "C" int fh_gemm_tune_import(const unsigned long long* keys, const int* paths, const int* splitks, int n) {
   for (int i = 0; i < n; ++i) g_tune[keys[i]] = TuneChoice{paths[i], splitks[i]};
   return (int)g_tune.size();
+}
+// caller-chosen tag attached to the launches recorded from now on (bench.py: 1 while the frozen teacher's forward is queued)
+extern "C" int fh_prof_tag(int tag) {
+  const int old = g_prof_tag;
+  g_prof_tag = tag;
+  return old;
+}
+// per-launch form of fh_prof_collect: rows of {M, N, K (whole reduction), groups, X layout, Y layout, loop, atomic, tag} and the
+// launch's duration / algorithmic FLOPs; returns the number of launches recorded (rows beyond cap are dropped) and clears the log
+extern "C" int fh_prof_collect_launches(double* ms, double* flops, int* rows /*[cap][9]*/, int cap) {
+  int n = 0;
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && n < cap) {
+      ms[n] = t;
+      flops[n] = r.flops;
+      int* q = rows + 9 * n;
+      q[0] = r.M; q[1] = r.N; q[2] = r.K; q[3] = r.groups; q[4] = r.xl; q[5] = r.yl; q[6] = r.loop; q[7] = r.atomic; q[8] = r.tag;
+      ++n;
+    }
+    g_pool.emplace_back(r.a, r.b);
+  }
+  g_prof.clear();
+  return n;
 }
 extern "C" int fh_prof_enable(int on) {
   g_prof_on = on != 0;
@@ -273,12 +298,14 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   r.flops = 2.0 * p.M * ncols * (double)p.Kseg * p.groups;
   r.variant = (dtype ? 4 : 0) + p.X.layout * 2 + p.Y.layout;
   r.M = p.M; r.N = p.N; r.K = p.Kseg * p.X.nseg; r.groups = p.groups; r.splitk = p.splitk;
+  r.tag = g_prof_tag; r.atomic = p.ep.atomic; r.xl = p.X.layout; r.yl = p.Y.layout; r.loop = 0;
   hipEventRecord(r.a, stream);
   const int rc = dtype == 0 ? launch_t<float>(p, stream) : launch_16(p, dtype, stream);
   if (dtype != 0) {
     // slot = loop * 8 + 4 + layouts; the persistent 8-phase loop (8) takes the otherwise unused slots 8 + layouts
     r.variant = fh_g_last_loop == 8 ? 8 + p.X.layout * 2 + p.Y.layout : r.variant + 8 * (fh_g_last_loop & 7);
     r.splitk = fh_g_last_splitk;
+    r.loop = fh_g_last_loop;
   }
   hipEventRecord(r.b, stream);
   g_prof.push_back(r);

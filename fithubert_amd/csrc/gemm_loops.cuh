@@ -1248,6 +1248,10 @@ __global__ void __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) gemm_ring_k
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int cb = 0; cb < TN / 64; ++cb) {
+    // outputs without per-row operands: the 16-bit staged form (half the LDS traffic, bias / GELU / dropout in the accumulator layout) --
+    // what loops 7 / 8 use; with it the 4-wave 256 x 128 build (two workgroups per CU: one stores while the other multiplies) is a
+    // candidate for the forward launches too
+    if (epilogue_bf16<H, MT>(p, acc, cb * 4, my, i0, j0, xi0, yj0 + 64 * cb, lane, g)) continue;
     float bv[8];
     epilogue_bias(p, j0, yj0 + 64 * cb, lane, g, bv);
 #pragma unroll

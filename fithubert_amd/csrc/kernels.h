@@ -15,6 +15,9 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
                         float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
                         hipStream_t st, int stats_ready = 0);
 
+int fh_conv0_ln_gelu_launch(int dtype, const float* wave, const float* w, const float* bias, const float* gamma, const float* beta, void* y,
+                            int B, int S, int C0, int K, int stride, float eps, hipStream_t st);
+
 // ---- norm.hip
 int fh_layernorm_fwd_launch(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                             float* rstd, int M, int C, float eps, fh_drop drop, hipStream_t st);

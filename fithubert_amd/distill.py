@@ -306,6 +306,15 @@ class W2V2Distil:
 
     @torch.no_grad()
     def teacher_hiddens(self, batch) -> torch.Tensor:
+        lib = L.lib() if self.device.type == "cuda" else None
+        prev = lib.fh_prof_tag(1) if lib is not None else 0     # per-launch GEMM profile: these launches are the teacher's
+        try:
+            return self._teacher_hiddens(batch)
+        finally:
+            if lib is not None:
+                lib.fh_prof_tag(prev)
+
+    def _teacher_hiddens(self, batch) -> torch.Tensor:
         self.teacher_model.eval()  # train.py:131
         pm = batch.get("padding_mask")
         lengths = batch.get("_lengths")

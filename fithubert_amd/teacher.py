@@ -227,14 +227,25 @@ class _NativeFrontend:
     def _st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
-    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, b32: torch.Tensor, gelu: bool = False) -> torch.Tensor:
-        """y = x w^T + b over the last dim: hipBLASLt (F.linear) or the library's own GEMM (fh_conv1d_forward with k = 1)."""
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, b32: torch.Tensor, gelu: bool = False,
+               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, preact: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """y = x w^T + b (+ residual) over the last dim: the library's own GEMM (fh_linear_forward; the residual add rides in its
+        epilogue, ``preact`` receives the sum without it) or, for A/B, hipBLASLt (F.linear)."""
         if not self.linear_native:
-            return F.linear(x, w, b)
+            y = F.linear(x, w, b)
+            if preact is not None:
+                preact.copy_(y)
+            if residual is not None:
+                y = torch.add(residual, y, out=out)
+            elif out is not None:
+                out.copy_(y)
+                y = out
+            return y
         B, T, K = x.shape
-        y = torch.empty(B, T, w.shape[0], device=self.dev, dtype=self.tdt)
-        self.L.check(self.lib.fh_conv1d_forward(self.dt, x.data_ptr(), w.data_ptr(), b32.data_ptr(), y.data_ptr(), B, T, K, w.shape[0],
-                                                1, 1, 1 if gelu else 0, self._st()), "fh_conv1d_forward")
+        y = out if out is not None else torch.empty(B, T, w.shape[0], device=self.dev, dtype=self.tdt)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        self.L.check(self.lib.fh_linear_forward(self.dt, x.contiguous().data_ptr(), w.data_ptr(), b32.data_ptr(), ptr(residual), ptr(preact),
+                                                y.data_ptr(), B * T, K, w.shape[0], 1 if gelu else 0, self._st()), "fh_linear_forward")
         return y
 
     def fc1_gelu(self, x: torch.Tensor, w: dict) -> torch.Tensor:
@@ -280,7 +291,7 @@ class _NativeFrontend:
                                                        None, M, C, 1e-5, self.L.Drop(0.0, 0, 0), self._st()), "fh_layernorm_forward")
         return out
 
-    def layer_pre_ln(self, i: int, x: torch.Tensor, key_len, out: torch.Tensor):
+    def layer_pre_ln(self, i: int, x: torch.Tensor, key_len, out: torch.Tensor, want_fc2: bool = False):
         """One pre-LN layer (layer_norm_first=True, HuBERT Large): x += attn(LN(x)); x += ffn(LN(x)); the layer output (what the
         reference's forward hook captures, utils/utils.py:74-78) is the residual stream."""
         L, lib, w = self.L, self.lib, self.tl[i]
@@ -291,15 +302,15 @@ class _NativeFrontend:
         L.check(lib.fh_attention_forward(self.dt, qkv.data_ptr(), attn.data_ptr(), None, key_len.data_ptr() if key_len is not None else None,
                                          B, T, self.heads, self.dh, float(self.dh) ** -0.5, L.Drop(0.0, 0, 0), self._st()),
                 "fh_attention_forward")
-        x1 = x + self.linear(attn, w["wo"], w["bo"], w["bo32"])
+        x1 = self.linear(attn, w["wo"], w["bo"], w["bo32"], residual=x)             # x + out_proj(attn): the add rides in the epilogue
         h2 = self.ln(x1, w["g2"], w["b2"])
-        lr = self.linear(self.fc1_gelu(h2, w), w["w2"], w["c2"], w["c232"])
-        torch.add(x1, lr, out=out)
+        lr = torch.empty_like(x1) if want_fc2 else None                               # the hook's fc2 output, only when asked for
+        self.linear(self.fc1_gelu(h2, w), w["w2"], w["c2"], w["c232"], residual=x1, out=out, preact=lr)
         return out, lr
 
-    def layer(self, i: int, x: torch.Tensor, key_len, out: torch.Tensor):
+    def layer(self, i: int, x: torch.Tensor, key_len, out: torch.Tensor, want_fc2: bool = False):
         if self.pre_ln:
-            return self.layer_pre_ln(i, x, key_len, out)
+            return self.layer_pre_ln(i, x, key_len, out, want_fc2)
         """One post-LN transformer layer (fairseq TransformerSentenceEncoderLayer, layer_norm_first=False) -> (out, fc2 out).
         q|k|v / out_proj / fc2 are plain library GEMMs (hipBLASLt via F.linear); attention, both residual-add + LayerNorm
         pairs and fc1 + bias + GELU are HIP kernels.  ``key_len``: int32 [B] valid frames (right-padded batch) or None."""
@@ -332,9 +343,16 @@ class _NativeFrontend:
                                          y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(), B, S, dim0, k0, s0,
                                          1e-5, self._st()), "fh_conv0_forward")
         else:  # layer_norm mode: conv (Cin = 1) -> LayerNorm over channels -> GELU (HuBERT-Large)
-            y = F.linear(wav.to(self.tdt).unfold(1, k0, s0), self.w0.to(self.tdt), None if self.b0 is None else self.b0.to(self.tdt))
             ln = getattr(model.feature_extractor.conv_layers[0], "2")[1]
-            y = self.ln(y, self._f32(ln.weight), self._f32(ln.bias), gelu=True)
+            if dim0 in (256, 512) and k0 <= 16:   # conv + bias + LayerNorm + GELU in one pass (the conv output is never written)
+                y = torch.empty(B, T, dim0, device=self.dev, dtype=self.tdt)
+                L.check(lib.fh_conv0_layernorm_gelu_forward(self.dt, wav.data_ptr(), self.w0.data_ptr(),
+                                                            self.b0.data_ptr() if self.b0 is not None else None,
+                                                            self._f32(ln.weight).data_ptr(), self._f32(ln.bias).data_ptr(), y.data_ptr(),
+                                                            B, S, dim0, k0, s0, 1e-5, self._st()), "fh_conv0_layernorm_gelu_forward")
+            else:
+                y = F.linear(wav.to(self.tdt).unfold(1, k0, s0), self.w0.to(self.tdt), None if self.b0 is None else self.b0.to(self.tdt))
+                y = self.ln(y, self._f32(ln.weight), self._f32(ln.bias), gelu=True)
         for i, (dim, k, s) in enumerate(self.spec[1:], start=1):
             wf, b = self.layers[i - 1]
             Tn = (T - k) // s + 1
@@ -483,7 +501,7 @@ class TeacherModel(nn.Module):
             for i in range(L):
                 if self.return_attn and i == L - 1:
                     stash_qkv(self.encoder.layers[i], x)
-                x, lr = native.layer(i, x, key_len, hidden[i])
+                x, lr = native.layer(i, x, key_len, hidden[i], want_fc2)
                 if want_fc2:
                     fc2.append(lr)
             return hidden, post, fc2

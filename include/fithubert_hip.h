@@ -121,6 +121,11 @@ int fh_gemm_tune_export(unsigned long long* keys, int* paths, int* splitks, int 
 int fh_gemm_tune_import(const unsigned long long* keys, const int* paths, const int* splitks, int n);
 int fh_prof_enable(int on);
 int fh_prof_collect(double* ms /*[64]*/, double* flops /*[64]*/, long* launches /*[64]*/);
+/* The same log launch by launch (bench.py's per-class table): rows[i] = {M, N, K, groups, X layout, Y layout, loop, atomic, tag},
+ * ms[i], flops[i]; returns the number of rows written (<= cap) and clears the log.  fh_prof_tag sets the tag of the launches recorded
+ * from then on (returns the previous one). */
+int fh_prof_collect_launches(double* ms, double* flops, int* rows, int cap);
+int fh_prof_tag(int tag);
 
 /* ------------------------------------------------------------------------------------------
  * Waveform frontend layer 0: Conv1d(1, C0, K, stride, bias=False) + GroupNorm(C0, C0) + GELU.
@@ -364,7 +369,7 @@ int fh_relation_kd(int dtype, int teacher_dtype, const void* s_qkv, const void* 
 
 /* ------------------------------------------------------------------------------------------
  * Frozen-teacher conv frontend on the student's kernels.  The teacher (fairseq HubertModel /
- * Wav2Vec2Model, loaded at utils/utils.py:102-149) is third party; its transformer stays on PyTorch-ROCm.
+ * Wav2Vec2Model, loaded at utils/utils.py:102-149) is third party; since round 3 its transformer layers run on these kernels too.
  *   fh_conv1d_forward : channels-last Conv1d(Cin, Cout, k, stride) [+ bias] [+ GELU] as ONE MFMA GEMM over
  *                       overlapping windows.  x [B][T][Cin], wf [Cout][k][Cin] (dtype), y [B][Tout][Cout].
  *   fh_posconv_wide_* : weight-normed grouped positional conv with up to 64 channels per group (768 / 16 = 48):
@@ -372,6 +377,15 @@ int fh_relation_kd(int dtype, int teacher_dtype, const void* s_qkv, const void* 
  * ------------------------------------------------------------------------------------------ */
 int fh_conv1d_forward(int dtype, const void* x, const void* wf, const float* bias, void* y, int B, int T, int Cin, int Cout,
                       int k, int stride, int gelu, fh_stream_t stream);
+/* y = [gelu](x W^T + bias) [+ residual]; `preact` (optional) receives x W^T + bias.  x [M][K], W [N][K] (dtype), bias fp32 [N],
+ * residual / preact / y [M][N] (dtype): every nn.Linear of the frozen teacher's transformer layers (fairseq
+ * TransformerSentenceEncoderLayer as loaded at utils/utils.py:102-149), the pre-LN form's residual adds folded into the epilogue. */
+int fh_linear_forward(int dtype, const void* x, const void* w, const float* bias, const void* residual, void* preact, void* y, int M,
+                      int K, int N, int gelu, fh_stream_t stream);
+/* First block of a layer_norm-mode conv frontend (modules/module.py:54-64 form; the HuBERT-Large teacher): Conv1d(1, C0, K, stride)
+ * + bias -> LayerNorm over the C0 channels -> GELU in one pass, y [B][T0][C0] (dtype); C0 in {256, 512}. */
+int fh_conv0_layernorm_gelu_forward(int dtype, const float* wave, const float* w, const float* bias, const float* gamma,
+                                    const float* beta, void* y, int B, int S, int C0, int K, int stride, float eps, fh_stream_t stream);
 int fh_posconv_wide_prepare(int dtype, const float* g, const float* v, void* w_fwd, float* norm2, int D, int groups, int K,
                             fh_stream_t stream);
 int fh_posconv_wide_forward(int dtype, const void* x, const void* w_fwd, const float* bias, void* y, int B, int T, int D,

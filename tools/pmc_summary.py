@@ -17,11 +17,31 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fetch_dir, write_dir, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
 sq_dir = sys.argv[4] if len(sys.argv) > 4 else None
 trace = sys.argv[5] if len(sys.argv) > 5 else None
-NAME = re.compile(r"(gemm\w*_kernel<[^>]*>)")
+sys.path.insert(0, root)
 LAYOUTS = {(0, 0): "0, 0", (0, 1): "0, 1", (1, 0): "1, 0", (1, 1): "1, 1"}
-LOOPS = {0: "gemm_kernel<bf16, {l}>", 1: "gemm_small_kernel<0>", 2: "gemm32_kernel<{l}>", 3: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 64, 2>",
-         4: "gemm_ring_kernel<{l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{l}>",
-         7: "gemm_8ph_kernel<{l}>", 8: "gemm_8ph_stream_kernel<{l}>"}
+ELEM = os.environ.get("FH_PMC_ELEM", "bf16")   # element tag of the profiled run's 16-bit launches (bf16 | f16)
+LOOPS = {0: "gemm_kernel<{t}, {l}>", 1: "gemm_small_kernel<{t}>", 2: "gemm32_kernel<{t}, {l}>", 3: "gemm_ring_kernel<{t}, {l}, 256, 256, 2, 4, 64, 2>",
+         4: "gemm_ring_kernel<{t}, {l}, 256, 128, 2, 2, 32, 3>", 5: "gemm_ring_kernel<{t}, {l}, 256, 256, 2, 4, 32, 4>", 6: "gemm_pp_kernel<{t}, {l}>",
+         7: "gemm_8ph_kernel<{t}, {l}>", 8: "gemm_8ph_stream_kernel<{t}, {l}>"}
+_DEM = re.compile(r"(gemm\w*_kernel)<([^>]*)>")
+_MAN = re.compile(r"_ZN\d+_GLOBAL__N_1\d+(gemm\w*_kernel)I(DF16b|DF16_|f)((?:L[ij]\d+E)*)E")
+_TAGS = {"DF16b": "bf16", "DF16_": "f16", "f": "float", "__bf16": "bf16", "bool _Accum": "bf16", "_Float16": "f16", "float": "float"}
+
+
+def canon_kernel_name(raw):
+    """rocprofv3 kernel name -> 'template<element tag, integer arguments>' (bench.py kernel_name); None for other kernels.  The
+    profiler prints these kernels demangled ('gemm_8ph_kernel<__bf16, 0, 0>', older builds spell __bf16 'bool _Accum') or mangled."""
+    m = _MAN.search(raw)
+    if m:
+        ints = re.findall(r"L[ij](\d+)E", m.group(3))
+        return "%s<%s>" % (m.group(1), ", ".join([_TAGS[m.group(2)]] + ints))
+    m = _DEM.search(raw)
+    if not m:
+        return None
+    args = [a.strip() for a in m.group(2).split(",")]
+    if args and not args[0].isdigit():
+        args[0] = _TAGS.get(args[0], args[0])
+    return "%s<%s>" % (m.group(1), ", ".join(args))
 
 
 def load(d, counters):
@@ -32,10 +52,9 @@ def load(d, counters):
         c = r["Counter_Name"]
         if c not in agg:
             continue
-        m = NAME.search(r["Kernel_Name"])
-        if not m:
+        key = canon_kernel_name(r["Kernel_Name"])   # as bench.py's kernel_name(): e.g. gemm_ring_kernel<bf16, 0, 1, 256, 256, 2, 4, 32, 4>
+        if not key:
             continue
-        key = m.group(1)   # as bench.py's kernel_name(): e.g. gemm_ring_kernel<0, 1, 256, 256, 2, 4, 32, 4>
         agg[c][key] += float(r["Counter_Value"])
         n[c][key] += 1
     return agg, n
@@ -69,7 +88,7 @@ if trace and os.path.exists(trace):
         if len(p) < 9:
             continue
         M, N, K, G, xl, yl, loop, sk = (int(v) for v in p[:8])
-        name = LOOPS.get(loop, "gemm_kernel<float, {l}>").format(l=LAYOUTS[(xl, yl)])
+        name = LOOPS.get(loop, "gemm_kernel<float, {l}>").format(t=ELEM, l=LAYOUTS[(xl, yl)])
         a = alg[name]
         a[0] += 1
         a[1] += 2.0 * M * N * K * G
