@@ -967,6 +967,250 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward: fused, any length
+// The fused form above keeps every Q / dO tile of a (batch, head) resident and owns at most 256 keys (8 waves x 32), so utterances
+// past T2 = 256 -- train-clean-100's MEDIAN utterance has T2 = 349, its longest 613 -- fell back to the two-pass form, which computes
+// P, the dropout mask and dS twice.  This kernel covers them: the keys are cut into nkb = ceil(Tn / 256) blocks of kpb keys (equal
+// shares, a multiple of 32), one workgroup per (key block, head, batch).  A workgroup keeps ITS keys' K / V fragments in registers
+// and its K block in LDS (for the dQ contraction) and STREAMS the 64-query (Q | dO | lse | delta) tiles through two buffers -- every
+// thread fetches its 16-byte pieces of tile i + 1 into registers right behind the barrier of tile i, as the forward streams K / V --
+// so LDS holds 2 tiles + K block + 2 dS^T scratch blocks = 111,616 B at any length.  dK / dV of a key block are complete; dQ of a
+// query block is the sum over the key blocks: with more than one block each workgroup writes its fp32 partial to dq_part[kb] and
+// dq_combine_kernel adds them in a fixed order (deterministic, no atomics) and rounds once.  delta = rowsum(out * dout) comes from
+// attn_delta_kernel (a workgroup no longer sees a query's whole row of work before it needs delta).
+template <typename T>
+__global__ void __launch_bounds__(256) attn_delta_kernel(const T* __restrict__ out, const T* __restrict__ dout, float* __restrict__ delta,
+                                                         int B, int Tn, int H, int dh) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, t, h), h fastest: neighbouring threads read neighbouring heads
+  if (i >= (long)B * Tn * H) return;
+  const int h = (int)(i % H);
+  const long bt = i / H;
+  const int t = (int)(bt % Tn), b = (int)(bt / Tn);
+  const T* o = out + bt * H * dh + h * dh;
+  const T* g = dout + bt * H * dh + h * dh;
+  float part = 0.f;
+  for (int c = 0; c < dh / 8; ++c) {
+    float a[8], d[8];
+    unpack16<T>(ld16(o + c * 8), a);
+    unpack16<T>(ld16(g + c * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part = fmaf(a[e], d[e], part);
+  }
+  delta[((long)b * H + h) * Tn + t] = part;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) dq_combine_kernel(const float* __restrict__ part, int nkb, T* __restrict__ dqkv, long rows, int D) {
+  const int cpr = D / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cpr) return;
+  const long row = i / cpr;
+  const int c = (int)(i - row * cpr) * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const float* p = part + ((long)kb * rows + row) * D + c;
+    float v[8];
+    ld4(p, v);
+    ld4(p + 4, v + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+  }
+  st16(dqkv + row * 3 * D + c, pack16<T>(acc));
+}
+
+template <typename T, int NDT, bool DROP>
+__global__ void __launch_bounds__(512) attn_bwd_fused_stream_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                    T* __restrict__ dqkv, float* __restrict__ dq_part,
+                                                                    const int* __restrict__ key_len, int B, int Tn, int H, int dh,
+                                                                    int kpb, float scale, float scale_log2e, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RS = AT<T>::RS;
+  constexpr int PAIR = 2 * 64 * RS + 512;  // Q tile | dO tile | 64 x LSE | 64 x delta
+  constexpr int NK = AT<T>::NK;
+  typedef typename AT<T>::frag frag;
+  unsigned char* Kt = lds + 2 * PAIR;
+  unsigned char* Sc = Kt + 256 * RS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nkb = gridDim.x;
+  const int kbase = kb * kpb;
+  const int D = H * dh;
+  const long ld = 3L * D;
+  const T* base = qkv + (long)b * Tn * ld + h * dh;
+  const T* dobase = dout + (long)b * Tn * D + h * dh;
+  const int klen = key_len ? min(key_len[b], Tn) : Tn;
+  const int kend = min(Tn, kbase + kpb);       // keys [kbase, kend) are this workgroup's
+  const int kvis = min(klen, kend);            // ... of which [kbase, kvis) are not padding
+  const int k0 = kbase + wave * 32;            // this wave's 32 keys (a wave with k0 >= kvis only takes part in the barriers and the dQ contraction)
+  const bool active = k0 < kvis;
+  const int ntile = (Tn + 63) / 64;
+
+  zero_lds<T>(lds, 2 * PAIR + 256 * RS + 2 * 256 * FUSED_SRS);   // (the dS^T rows of keys nobody owns stay zero for the whole launch)
+  __syncthreads();
+  stage_tiles<T>(4, kend, dh, [&](int t, const T*& src, long& sld, unsigned char*& dst, int& row0) {
+    src = base + D;
+    sld = ld;
+    dst = Kt + t * 64 * RS;
+    row0 = kbase + t * 64;
+  });
+  frag kf[2][NK], vf[2][NK];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = k0 + 16 * kt + r;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      kf[kt][ks] = gfrag<T>(base + D + (long)key * ld, key < kend, ks, lane, dh);
+      vf[kt][ks] = gfrag<T>(base + 2 * D + (long)key * ld, key < kend, ks, lane, dh);
+    }
+  }
+  f32x4 dk[2][NDT], dv[2][NDT];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  KeyScore ks_;
+  ks_.init(drop, b, h, H, Tn, kvis, k0, lane, scale, scale_log2e);
+
+  // this thread's pieces of one (Q tile | dO tile) pair: piece i = row (i / cpr) % 64 of Q (i < 64 cpr) or dO
+  constexpr int NPC = 2;   // 2 x 64 rows x (64 / 8) pieces at the widest head = 1024 = 2 x 512 threads
+  const int cpr = dh / 8, npiece = 2 * 64 * cpr;
+  V16 pre[NPC];
+  int prow[NPC], pdst[NPC];
+  const T* psrc[NPC];
+  long pstep[NPC];   // elements per query row of the source
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int i = (int)threadIdx.x + j * 512;
+    const int isdo = i >= 64 * cpr, rem = i - isdo * 64 * cpr, row = rem / cpr, c = rem - row * cpr;
+    prow[j] = i < npiece ? row : -1;
+    pdst[j] = isdo * 64 * RS + row * RS + c * 16;
+    pstep[j] = isdo ? (long)D : ld;
+    psrc[j] = (isdo ? dobase : base) + (long)row * pstep[j] + c * 8;
+  }
+  float pl = INFINITY, pd = 0.f;
+  auto fetch = [&](int qt0) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      pre[j] = v16_zero();
+      if (prow[j] >= 0 && qt0 + prow[j] < Tn) pre[j] = ld16(psrc[j] + (long)qt0 * pstep[j]);
+    }
+    if (threadIdx.x < 64) {
+      const int query = qt0 + threadIdx.x;
+      pl = query < Tn ? lse[((long)b * H + h) * Tn + query] : INFINITY;
+      pd = query < Tn ? delta[((long)b * H + h) * Tn + query] : 0.f;
+    }
+  };
+  auto deposit = [&](unsigned char* sb) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)
+      if (prow[j] >= 0) st16(sb + pdst[j], pre[j]);
+    if (threadIdx.x < 64) {
+      float* L2w = reinterpret_cast<float*>(sb + 2 * 64 * RS);
+      L2w[threadIdx.x] = pl;
+      L2w[64 + threadIdx.x] = pd;
+    }
+  };
+  fetch(0);
+  const int qq = r >> 2, pp = r & 3;
+  for (int tile = 0; tile < ntile; ++tile) {
+    unsigned char* sb = lds + (tile & 1) * PAIR;
+    // the buffer's readers (the score steps of tile - 2) finished before the barriers this wave has passed since
+    deposit(sb);
+    __syncthreads();   // (also orders the K block staged above in front of the first contraction)
+    if (tile + 1 < ntile) fetch((tile + 1) * 64);
+    const unsigned char* Qs = sb;
+    const unsigned char* Os = Qs + 64 * RS;
+    const float* L2s = reinterpret_cast<const float*>(Qs + 2 * 64 * RS);
+    const float* Dls = L2s + 64;
+#pragma unroll 1
+    for (int m2 = 0; m2 < 2; ++m2) {
+      const int st = 2 * tile + m2;
+      if (st * 32 >= Tn) break;   // (uniform: the last tile of an odd number of 32-query steps)
+      unsigned char* Sb = Sc + (st & 1) * 256 * FUSED_SRS;
+      if (active) {
+        uint2 pdp[2][2], dsp[2][2];  // packed P.drop and dS, [half][kt]
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int qb = 2 * m2 + half;
+          f32x4 s[2], dp[2];
+          s[0] = s[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) {
+            const frag aq = lfrag<T>(Qs, 16 * qb + r, ks, lane);
+            const frag ao = lfrag<T>(Os, 16 * qb + r, ks, lane);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              s[kt] = mma<T>(aq, kf[kt][ks], s[kt]);
+              dp[kt] = mma<T>(ao, vf[kt][ks], dp[kt]);
+            }
+          }
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(L2s + 16 * qb + 4 * q);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(Dls + 16 * qb + 4 * q);
+          ks_.template block<T, DROP>(st * 32 + 16 * half, s, dp, l4, dl, pdp[half], dsp[half]);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+            *reinterpret_cast<uint2*>(Sb + (wave * 32 + 16 * kt + r) * FUSED_SRS + (16 * half + 4 * q) * 2) = dsp[half][kt];
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          mma_transposed_packed<T, NDT>(Os, m2, pdp[0][kt], pdp[1][kt], dv[kt], lane);
+          mma_transposed_packed<T, NDT>(Qs, m2, dsp[0][kt], dsp[1][kt], dk[kt], lane);
+        }
+      }
+      __syncthreads();
+      if (wave < 2 * NDT) {  // dQ^T tile (16 d x 16 queries) of this step over this block's keys: K^T [d][keys] . dS^T [keys][queries]
+        const int qb2 = wave / NDT, dt = wave - qb2 * NDT;
+        const unsigned char* a0 = Kt + (4 * q + qq) * RS + (16 * dt + 4 * pp) * 2;
+        const unsigned char* b0 = Sb + (4 * q + qq) * FUSED_SRS + (16 * qb2 + 4 * pp) * 2;
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } ua[8], ub[8];
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          ua[kc].s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 32 * kc * RS));
+          ua[kc].s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (32 * kc + 16) * RS));
+          ub[kc].s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + 32 * kc * FUSED_SRS));
+          ub[kc].s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + (32 * kc + 16) * FUSED_SRS));
+        }
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 8; kc += 2) {
+          acc0 = mfma16<T>(ua[kc].v, ub[kc].v, acc0);
+          acc1 = mfma16<T>(ua[kc + 1].v, ub[kc + 1].v, acc1);
+        }
+        const int query = st * 32 + 16 * qb2 + r, d = 16 * dt + 4 * q;
+        if (query < Tn && d < dh) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc0[e] + acc1[e];
+          if (nkb == 1) st4(dqkv + ((long)b * Tn + query) * ld + h * dh + d, v);
+          else st4(dq_part + (((long)kb * B + b) * Tn + query) * D + h * dh + d, v);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = k0 + 16 * kt + r;
+    if (key >= kend) continue;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int d = 16 * dt + 4 * q;
+      if (d < dh) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dk[kt][dt][e];
+        st4(dqkv + ((long)b * Tn + key) * ld + D + h * dh + d, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dv[kt][dt][e];
+        st4(dqkv + ((long)b * Tn + key) * ld + 2 * D + h * dh + d, v);
+      }
+    }
+  }
+}
+
 int check_dims(int dtype, int H, int dh, int dh_max = 64) {
   const int vec = dtype == 0 ? 4 : 8;
   if (dh % vec || dh % 4 || dh > dh_max || H <= 0) return -601;  // NDT = 3 builds cover dh <= 48 (student dh = 40), NDT = 4 dh <= 64
@@ -1036,6 +1280,34 @@ int bwd_fused_launch(const T* qkv, const T* out, const T* dout, const float* lse
   FH_CHECK_LAUNCH();
   return 0;
 }
+// scratch of the any-length fused backward: nkb x B x Tn x D floats (0 when one key block suffices)
+int fused_stream_blocks(int Tn) { return (Tn + 255) / 256; }
+template <typename T, int NDT>
+int bwd_fused_stream_launch(const T* qkv, const T* out, const T* dout, const float* lse, float* delta, T* dqkv, float* dq_part,
+                            const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
+  const int nkb = fused_stream_blocks(Tn);
+  const int kpb = (((Tn + nkb - 1) / nkb) + 31) / 32 * 32;
+  const size_t smem = 2 * (2 * 64 * AT<T>::RS + 512) + 256 * AT<T>::RS + 2 * 256 * FUSED_SRS;
+  const long nd = (long)B * Tn * H;
+  hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, out, dout, delta, B, Tn, H, dh);
+  FH_CHECK_LAUNCH();
+  if (drop.p > 0.f) {
+    set_lds(attn_bwd_fused_stream_kernel<T, NDT, true>, smem);
+    hipLaunchKernelGGL((attn_bwd_fused_stream_kernel<T, NDT, true>), dim3(nkb, H, B), dim3(512), smem, st, qkv, dout, lse, delta, dqkv, dq_part,
+                       key_len, B, Tn, H, dh, kpb, scale, sl2, drop);
+  } else {
+    set_lds(attn_bwd_fused_stream_kernel<T, NDT, false>, smem);
+    hipLaunchKernelGGL((attn_bwd_fused_stream_kernel<T, NDT, false>), dim3(nkb, H, B), dim3(512), smem, st, qkv, dout, lse, delta, dqkv, dq_part,
+                       key_len, B, Tn, H, dh, kpb, scale, sl2, drop);
+  }
+  FH_CHECK_LAUNCH();
+  if (nkb > 1) {
+    const long rows = (long)B * Tn, n = rows * (H * dh / 8);
+    hipLaunchKernelGGL(dq_combine_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dq_part, nkb, dqkv, rows, H * dh);
+    FH_CHECK_LAUNCH();
+  }
+  return 0;
+}
 bool fused_bwd_enabled() {  // FH_ATTN_FUSED=0 selects the two-pass backward (A/B comparisons)
   static int mode = -1;
   if (mode < 0) {
@@ -1081,13 +1353,17 @@ int fwd16(const void* qkv, void* out, float* lse, const int* key_len, int B, int
 }
 template <typename T>
 int bwd16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, const int* key_len, int B, int Tn,
-          int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
+          int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st, float* dq_scratch) {
   const int res = resident_tiles<T>(Tn);
   const int nw = wide_waves(res, Tn, 8);  // the 16-wave backward builds spill under the 128-VGPR cap
   const T *q = (const T*)qkv, *o = (const T*)out, *d = (const T*)dout;
   if (res && Tn <= 256 && Tn > 64 && fused_bwd_enabled()) {
     if (dh > 48) return bwd_fused_launch<T, 4>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
     return bwd_fused_launch<T, 3>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+  }
+  if (Tn > 256 && dq_scratch && (H * dh) % 8 == 0 && fused_bwd_enabled()) {   // longer utterances: the streamed fused form
+    if (dh > 48) return bwd_fused_stream_launch<T, 4>(q, o, d, lse, delta, (T*)dqkv, dq_scratch, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+    return bwd_fused_stream_launch<T, 3>(q, o, d, lse, delta, (T*)dqkv, dq_scratch, key_len, B, Tn, H, dh, scale, sl2, drop, st);
   }
   if (dh > 48) {
     if (nw == 8) return bwd_launch_t<T, 4, 8>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
@@ -1111,9 +1387,13 @@ int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, c
                     : fwd16<bf16>(qkv, out, lse, key_len, B, Tn, H, dh, sl2, drop, st);
 }
 
+long fh_attention_bwd_scratch_floats(int dtype, int B, int Tn, int H, int dh) {
+  if (dtype == 0 || Tn <= 256) return 0;
+  return (long)fused_stream_blocks(Tn) * B * Tn * H * dh;
+}
 int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                             float* delta, void* dqkv, const int* key_len, int B, int Tn, int H, int dh, float scale,
-                            fh_drop drop, hipStream_t st) {
+                            fh_drop drop, hipStream_t st, float* dq_scratch) {
   if (int rc = check_dims(dtype, H, dh, 64)) return rc;
   const float sl2 = scale * 1.4426950408889634f;
   if (dtype == 0) {
@@ -1122,6 +1402,6 @@ int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const v
       return bwd_launch_t<float, 4, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
     return bwd_launch_t<float, 3, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
   }
-  return dtype == 2 ? bwd16<f16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st)
-                    : bwd16<bf16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+  return dtype == 2 ? bwd16<f16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dq_scratch)
+                    : bwd16<bf16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dq_scratch);
 }

@@ -88,6 +88,12 @@ int fh_attention_backward(int dtype, const void* qkv, const void* out, const voi
   return fh_attention_bwd_launch(dtype, qkv, out, dout, lse, delta, dqkv, key_len, B, T, H, dh, scale, drop,
                                  ST(stream));
 }
+long fh_attention_backward_scratch_floats(int dtype, int B, int T, int H, int dh) { return fh_attention_bwd_scratch_floats(dtype, B, T, H, dh); }
+int fh_attention_backward_ws(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                             void* dqkv, const int* key_len, int B, int T, int H, int dh, float scale, fh_drop drop, float* scratch,
+                             fh_stream_t stream) {
+  return fh_attention_bwd_launch(dtype, qkv, out, dout, lse, delta, dqkv, key_len, B, T, H, dh, scale, drop, ST(stream), scratch);
+}
 
 int fh_kd_loss(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
                const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,

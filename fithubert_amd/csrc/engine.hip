@@ -352,7 +352,7 @@ struct Plan {
   long u = -1, pred, hz = -1, hh = -1, dhz = -1, gfeat = -1, cnn_pred = -1, dgf = -1, dwm = -1, dwm16 = -1, dbl = -1;
   // backward
   long du, ghead, dxin, ds2, df2, dz1, dx1b, ds1, dao, da, dqkv, delta;
-  long dx1tr, dpsum, dzc, dx0, dfeat, dln0, dylast, pos_dws;
+  long dx1tr, dpsum, dzc, dx0, dfeat, dln0, dylast, pos_dws, attn_scr = -1;
 
   Plan(const fh_student_config& cfg, const fh_student_call& call) : c(cfg), k(call), pl(cfg), wl(cfg, pl) {
     es = c.dtype == 0 ? 4 : 2;
@@ -429,6 +429,10 @@ struct Plan {
       da = ws.add("da", {M2, D}, es);
       dqkv = ws.add("dqkv", {L, M2, 3 * D}, es);
       delta = ws.add("delta", {B * H, sh.T2}, 4);
+      {  // fp32 dQ partials of the any-length fused attention backward (16-bit modes, T2 > 256)
+        const long n = fh_attention_bwd_scratch_floats(c.dtype, (int)B, sh.T2, (int)H, (int)(D / H));
+        if (n > 0) attn_scr = ws.add("attn_scr", {n}, 4);
+      }
       dx1tr = ws.add("dx1tr", {B, sh.Tp, D}, es);
       dpsum = ws.add("dpsum", {B, sh.Tp, D}, es);
       dzc = ws.add("dzc", {B, sh.Tp, D}, es);
@@ -1139,7 +1143,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     RC(fh_attention_bwd_launch(dt, x.at(p.qkv, (long)l * M2 * 3 * D), x.at(p.attn, (long)l * M2 * D), x.W(p.da),
                                x.W<float>(p.lse) + (long)l * B * H * s.T2, x.W<float>(p.delta),
                                x.at(p.dqkv, (long)l * M2 * 3 * D), len_2, B, s.T2, H, D / H, scale,
-                               x.drop(c.attention_dropout, site + 0), x.st));
+                               x.drop(c.attention_dropout, site + 0), x.st, p.attn_scr >= 0 ? x.W<float>(p.attn_scr) : nullptr));
     if (l == L - 1 && d_qkv_last)  // attention-logit / value-relation transfer gradients enter at the last layer's q|k|v
       RC(fh_unary_launch(dt, d_qkv_last, x.at(p.dqkv, (long)l * M2 * 3 * D), M2 * 3 * D, 1, x.st));
     {  // dxin = dqkv . Wqkv + ds1

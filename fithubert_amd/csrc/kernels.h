@@ -46,9 +46,12 @@ int fh_posconv_wn_bwd_launch(const float* g, const float* v, const float* norm, 
 // ---- attention.hip : multi-head self-attention on a packed [B][T][3*D] q|k|v tensor
 int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, const int* key_len, int B, int Tn, int H,
                             int dh, float scale, fh_drop drop, hipStream_t st);
+// dq_scratch: fh_attention_bwd_scratch_floats(...) floats for the any-length fused backward (16-bit modes, Tn > 256: fp32 dQ partials
+// of the key blocks), or null -> the two-pass form
+long fh_attention_bwd_scratch_floats(int dtype, int B, int Tn, int H, int dh);
 int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                             float* delta, void* dqkv, const int* key_len, int B, int Tn, int H, int dh, float scale,
-                            fh_drop drop, hipStream_t st);
+                            fh_drop drop, hipStream_t st, float* dq_scratch = nullptr);
 
 // ---- loss.hip : layer-wise KD loss (MSE / L1) fused with its gradient
 int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,

@@ -198,6 +198,14 @@ int fh_attention_forward(int dtype, const void* qkv, void* out, float* lse, cons
 int fh_attention_backward(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                           void* dqkv, const int* key_len, int B, int T, int H, int dh, float scale, fh_drop drop,
                           fh_stream_t stream);
+/* The same with caller-provided scratch (fh_attention_backward_scratch_floats floats; 0 for fp32 or T <= 256): 16-bit launches
+ * longer than 256 frames then run the ONE-pass fused backward too -- key blocks of <= 256 keys per workgroup, Q / dO tiles streamed,
+ * fp32 dQ partials of the key blocks in the scratch, summed in a fixed order -- instead of the two-pass form (which computes P, the
+ * dropout mask and dS twice). */
+long fh_attention_backward_scratch_floats(int dtype, int B, int T, int H, int dh);
+int fh_attention_backward_ws(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                             void* dqkv, const int* key_len, int B, int T, int H, int dh, float scale, fh_drop drop, float* scratch,
+                             fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layer-wise KD loss + gradient (train.py:250-293,372-378):  out[l] = mean_{b,t,d} f(pred_l - teacher_{tl[l]}),

@@ -20,11 +20,25 @@ def _st():
 
 
 def _tdt(dt):
-    return torch.float32 if dt == L.DT_F32 else torch.bfloat16
+    return {L.DT_F32: torch.float32, L.DT_BF16: torch.bfloat16, L.DT_F16: torch.float16}[dt]
 
 
 def _tol(dt):
-    return 2e-5 if dt == L.DT_F32 else 1.2e-2
+    return {L.DT_F32: 2e-5, L.DT_BF16: 1.2e-2, L.DT_F16: 2e-3}[dt]
+
+
+def _attn_backward(lib, dt, qkv, out, dout, lse, delta, dqkv, key_len, B, T, H, dh, drop, ws: bool):
+    """fh_attention_backward, or (ws) fh_attention_backward_ws with the scratch it asks for -- 16-bit launches past 256 frames then
+    take the one-pass fused backward with streamed Q / dO tiles instead of the two-pass form."""
+    if not ws:
+        L.check(lib.fh_attention_backward(dt, _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(key_len), B, T, H, dh,
+                                          dh ** -0.5, drop, _st()), "attn bwd")
+        return 0
+    n = lib.fh_attention_backward_scratch_floats(dt, B, T, H, dh)
+    scratch = torch.full((max(n, 1),), float("nan"), device=DEV) if n > 0 else None
+    L.check(lib.fh_attention_backward_ws(dt, _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(key_len), B, T, H, dh,
+                                         dh ** -0.5, drop, _p(scratch), _st()), "attn bwd (ws)")
+    return n
 
 
 def _rel(a, b):
@@ -236,13 +250,15 @@ def _attn_ref(qkv, H, dh, key_len):
     return (p @ v).transpose(1, 2).reshape(B, T, D), s
 
 
-@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("dt,ws", [(L.DT_F32, False), (L.DT_BF16, False), (L.DT_BF16, True), (L.DT_F16, True)])
 @pytest.mark.parametrize("dh", [40, 64])
-@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (2, 249, True), (1, 130, False), (3, 70, True), (2, 300, True), (1, 499, False),
+@pytest.mark.parametrize("B,T,masked", [(2, 49, False), (2, 249, True), (1, 130, False), (3, 70, True), (2, 300, True), (3, 349, True), (1, 499, False),
                                         # LibriSpeech train-clean-100 lengths (max 392,400 samples): T2 = 613 for the student, T' = 1226 for
                                         # the teacher -- past the resident-K/V limit (512 bf16 / 320 fp32), i.e. the tiled kernels
                                         (2, 613, True), (2, 880, True), (2, 1226, True), (1, 1225, False)])
-def test_attention_fwd_bwd(dt, B, T, masked, dh):
+def test_attention_fwd_bwd(dt, ws, B, T, masked, dh):
+    """(ws: the backward gets the scratch it asks for, so 16-bit launches past 256 frames -- T2 = 349 is train-clean-100's median
+    utterance, 613 its longest -- run the fused backward with key blocks and streamed Q / dO tiles instead of the two passes.)"""
     torch.manual_seed(B * 7 + T)
     H = 12
     D = H * dh
@@ -258,14 +274,14 @@ def test_attention_fwd_bwd(dt, B, T, masked, dh):
     ref, s = _attn_ref(qr, H, dh, key_len)
     assert _rel(out, ref) < _tol(dt)
     lse_ref = torch.logsumexp(s, dim=-1) / math.log(2.0)
-    assert (lse.double() - lse_ref).abs().max().item() < (1e-4 if dt == L.DT_F32 else 5e-2)
+    assert (lse.double() - lse_ref).abs().max().item() < {L.DT_F32: 1e-4, L.DT_BF16: 5e-2, L.DT_F16: 1e-2}[dt]
     dout = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
     ref.backward(dout.double())
     dqkv = torch.full_like(qkv, float("nan"))
     delta = torch.empty(B, H, T, device=DEV)
     out_in = ref.detach().to(_tdt(dt)).contiguous()
-    L.check(lib.fh_attention_backward(dt, _p(qkv), _p(out_in), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(key_len), B, T, H,
-                                      dh, dh ** -0.5, L.drop(), _st()), "attn bwd")
+    n_scr = _attn_backward(lib, dt, qkv, out_in, dout, lse, delta, dqkv, key_len, B, T, H, dh, L.drop(), ws)
+    assert (n_scr > 0) == (ws and T > 256)
     assert not torch.isnan(dqkv.float()).any()
     tol = _tol(dt) * (1.5 if dt == L.DT_F32 else 2.5)
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
@@ -326,9 +342,9 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(dt):
     assert _rel(dqkv[0, :dh, 2 * D:2 * D + dh], dv_ref) < (1e-4 if dt == L.DT_F32 else 3e-2)
 
 
-@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
-@pytest.mark.parametrize("T,masked", [(200, False), (249, True), (300, False), (613, True)])  # <= 256 bf16: the fused backward; 300: the two-pass one; 613: tiled
-def test_attention_dropout_backward_matches_autograd_with_the_forward_mask(dt, T, masked):
+@pytest.mark.parametrize("dt,ws", [(L.DT_F32, False), (L.DT_BF16, False), (L.DT_BF16, True), (L.DT_F16, True)])
+@pytest.mark.parametrize("T,masked", [(200, False), (249, True), (300, False), (349, True), (613, True)])  # <= 256 16-bit: the resident fused backward; longer: two passes, or (ws) the streamed fused one with 2 / 2 / 3 key blocks
+def test_attention_dropout_backward_matches_autograd_with_the_forward_mask(dt, ws, T, masked):
     """Reads the forward's complete dropout mask of one head through one-hot V probes, then checks dq / dk / dv of that head
     against autograd with that mask held fixed (the backward kernels regenerate the mask from (seed, site, index))."""
     torch.manual_seed(11)
@@ -366,10 +382,9 @@ def test_attention_dropout_backward_matches_autograd_with_the_forward_mask(dt, T
     o.backward(dout[bb, :, hh * dh:(hh + 1) * dh].double())
     dqkv = torch.full_like(qkv, float("nan"))
     delta = torch.empty(B, H, T, device=DEV)
-    L.check(lib.fh_attention_backward(dt, _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(key_len), B, T, H, dh,
-                                      dh ** -0.5, drop, _st()), "attn bwd")
+    _attn_backward(lib, dt, qkv, out, dout, lse, delta, dqkv, key_len, B, T, H, dh, drop, ws)
     assert not torch.isnan(dqkv.float()).any()
-    tol = 2e-4 if dt == L.DT_F32 else 4e-2
+    tol = {L.DT_F32: 2e-4, L.DT_BF16: 4e-2, L.DT_F16: 6e-3}[dt]
     assert _rel(dqkv[bb, :, hh * dh:(hh + 1) * dh], q.grad) < tol, "dq"
     assert _rel(dqkv[bb, :, D + hh * dh:D + (hh + 1) * dh], k.grad) < tol, "dk"
     assert _rel(dqkv[bb, :, vcol:vcol + dh], v.grad) < tol, "dv"
