@@ -606,6 +606,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
 // staged as bf16 -- half the LDS bytes and half the LDS instructions of the fp32 staging -- and the read-back is a plain copy
 // (16-byte LDS read -> 16-byte store, 8 rows x 128 contiguous bytes per wave instruction).  A pre-activation output is staged and
 // copied the same way before the activation.  `acc` is this wave's [4 n-tiles][NM m-tiles] block, column block yj0 .. yj0 + 63.
+// Per-row OPERANDS (round 3): a residual and / or a GELU' operand (the saved factor, or a pre-activation to differentiate) are applied in
+// the read-back -- one coalesced 16-byte load per 16-byte store, issued for the whole pass before its first store -- on the staged
+// 16-bit value, i.e. the result is rounded twice (as the reference's own AMP arithmetic rounds a Linear's output before the residual
+// add); the fp32 parity mode never comes here.  That took the K = 480 layer launches with a residual from 32.9 to ~24 us stand-alone.
 // Returns false (nothing written) when the tile does not qualify; the caller then runs the fp32-staged form.
 constexpr int EPB_ROW = 144;  // 64 bf16 columns + 16 B pad: conflict-free 8-byte writes (16 rows) and 16-byte reads (8 lanes / row)
 template <typename H, int NM, typename AccT>
@@ -613,9 +617,10 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
                                               int xi0, int yj0, int lane, int g) {
   const GemmEpilogue& ep = p.ep;
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
-  const bool ok = !ep.atomic && !ep.gelu_aux && !ep.residual && !ep.row_len && !ep.out_f32 && !ep.tail_cols && (p.c_rpb <= 0 || wrap0 == 0) &&
+  const bool ok = !ep.atomic && !ep.row_len && !ep.out_f32 && !ep.tail_cols && (p.c_rpb <= 0 || wrap0 == 0) &&
                   i0 + xi0 + 16 * NM - 1 < p.M;
   if (!__builtin_amdgcn_readfirstlane(ok)) return false;
+  const bool has_ops = __builtin_amdgcn_readfirstlane(ep.gelu_aux != nullptr || ep.residual != nullptr);
   const int r = lane & 15, q = lane >> 4;
   float b4[4][4];
   bool cv[4];
@@ -685,9 +690,35 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
         pk.y = pack2<H>(v[mm][n][2], v[mm][n][3]);
         *reinterpret_cast<uint2*>(wp + mm * 16 * EPB_ROW + n * 32) = pk;
       }
-    if (jrv) {
+    if (jrv && !has_ops) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) st16(reinterpret_cast<bf16*>(p.C) + base + it * rstep, ld16(lp + it * 8 * EPB_ROW));
+    } else if (jrv) {
+      V16 ax[4], rs[4];
+      if (ep.gelu_aux) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) ax[it] = ld16(reinterpret_cast<const bf16*>(ep.gelu_aux) + base + it * rstep);
+      }
+      if (ep.residual) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) rs[it] = ld16(reinterpret_cast<const bf16*>(ep.residual) + base + it * rstep);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float a[8], o[8];
+        unpack16<H>(ld16(lp + it * 8 * EPB_ROW), a);
+        if (ep.gelu_aux) {
+          unpack16<H>(ax[it], o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] *= ep.aux_factor ? o[e] : gelu_grad_t<H>(o[e]);
+        }
+        if (ep.residual) {
+          unpack16<H>(rs[it], o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += o[e];
+        }
+        st16(reinterpret_cast<bf16*>(p.C) + base + it * rstep, pack16<H>(a));
+      }
     }
   }
   return true;

