@@ -223,9 +223,12 @@ extern "C" int fh_prof_tag(int tag) {
 // launch's duration / algorithmic FLOPs; returns the number of launches recorded (rows beyond cap are dropped) and clears the log
 extern "C" int fh_prof_collect_launches(double* ms, double* flops, int* rows /*[cap][9]*/, int cap) {
   int n = 0;
+  const char* trace = getenv("FH_GEMM_TRACE");   // the same per-launch lines fh_prof_collect writes
+  FILE* tf = trace && *trace ? fopen(trace, "a") : nullptr;
   for (auto& r : g_prof) {
     float t = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && n < cap) {
+      if (tf) fprintf(tf, "%d %d %d %d %d %d %d %d %.4f\n", r.M, r.N, r.K, r.groups, r.xl, r.yl, r.loop, r.splitk, t);
       ms[n] = t;
       flops[n] = r.flops;
       int* q = rows + 9 * n;
@@ -234,6 +237,7 @@ extern "C" int fh_prof_collect_launches(double* ms, double* flops, int* rows /*[
     }
     g_pool.emplace_back(r.a, r.b);
   }
+  if (tf) fclose(tf);
   g_prof.clear();
   return n;
 }

@@ -467,7 +467,11 @@ class TeacherModel(nn.Module):
             x = self.layer_norm(x)
         B, T, _ = x.shape
         fm = self._frame_mask(padding_mask, T, lengths)
-        post = self.post_extract_proj(x)
+        if native is not None and native.linear_native:   # the feature projection on the own GEMM too: no library GEMM in the forward
+            pw = self.post_extract_proj
+            post = native.linear(x.contiguous(), pw.weight.detach(), pw.bias.detach(), native._f32(pw.bias))
+        else:
+            post = self.post_extract_proj(x)
         x = post
         if fm is not None:
             x = x.masked_fill(fm.unsqueeze(-1), 0.0)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries tools/final_measure.sh left in gpurun_out/ into profiles/ (tracked), round-tagged.
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 tail -1 gpurun_out/bench_default.json > profiles/${R}_bench_default.json
 tail -1 gpurun_out/bench128_under_rocprof.json > profiles/${R}_bench_B128_under_rocprof.json
@@ -9,5 +9,5 @@ tail -1 gpurun_out/bench128_under_rocprof.json > profiles/${R}_bench_B128_under_
   cat gpurun_out/bench128_kernel_stats.csv; } > profiles/${R}_bench_B128_kernel_stats.csv
 cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
 [ -f gpurun_out/student_kernel_stats.csv ] && { echo "# rocprofv3 --kernel-trace --stats -- python tools/student_step.py --batch 128 --steps 8 --warmup 2 (student only: forward + KD loss + backward; GEMM table reused; tools/prof_student.sh)"; cat gpurun_out/student_kernel_stats.csv; } > profiles/${R}_student_step_B128_kernel_stats.csv
-[ -f gpurun_out/teacher_kernel_stats.csv ] && { echo "# rocprofv3 --kernel-trace --stats -- python tools/teacher_step.py --native 1 --batch 128 --steps 8 --warmup 2 (teacher forward only; includes the 42 one-off GEMM tuning launches of the first forward)"; cat gpurun_out/teacher_kernel_stats.csv; } > profiles/${R}_teacher_fwd_B128_kernel_stats.csv
+[ -f gpurun_out/teacher_kernel_stats.csv ] && { echo "# rocprofv3 --kernel-trace --stats -- python tools/teacher_step.py --native 1 --batch 128 --steps 8 --warmup 2 (teacher forward only, every kernel native; GEMM table reused from an un-profiled run: no tuning launches in the trace; tools/prof_teacher.sh)"; cat gpurun_out/teacher_kernel_stats.csv; } > profiles/${R}_teacher_fwd_B128_kernel_stats.csv
 ls -la profiles/

@@ -35,6 +35,9 @@ def canon_kernel_name(raw):
     if m:
         ints = re.findall(r"L[ij](\d+)E", m.group(3))
         return "%s<%s>" % (m.group(1), ", ".join([_TAGS[m.group(2)]] + ints))
+    # rocprofv3's demangler does not know DF16b (std::bfloat16_t): names whose first integer argument is 0 stay mangled (handled above),
+    # those with a leading 1 come out as '<bool _Accum, int, E, ...>' -- the 'int, E' IS that 1
+    raw = raw.replace("<bool _Accum, int, E,", "<__bf16, 1,").replace("<bool _Accum, int, E>", "<__bf16, 1>")
     m = _DEM.search(raw)
     if not m:
         return None
