@@ -433,7 +433,7 @@ def main():
         ach = fl[v] / (ms[v] * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype != "float32" else 157.3   # the f16 MFMA forms run at the bf16 rate (MI355X_MICROARCH.md)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "mfma_busy": None,
                 "kernel": kernel_name(v, args.dtype), "launches": int(ln[v]), "avg_launch_us": round(ms[v] / ln[v] * 1e3, 2),
                 "avg_gflop_per_launch": round(fl[v] / ln[v] / 1e9, 3),
                 "all_gemm": {"achieved": round(sum(fl) / (tot_ms * 1e-3) / 1e12, 2), "launches": int(sum(ln)),
