@@ -112,7 +112,6 @@ _ENGINE_SIGS = {
     "fh_student_forward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P]),
     "fh_student_backward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fh_student_backward_cnn": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "fh_student_fused_layers": (_I, [_I]),
     "fh_student_backward_ex": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, C.POINTER(StudentGradsC), _P]),
     "fh_student_backward_notify": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, C.POINTER(StudentGradsC),
                                         C.POINTER(GradNotifyC), _P]),

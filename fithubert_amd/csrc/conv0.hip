@@ -221,25 +221,37 @@ __global__ void __launch_bounds__(256) conv0_bwd_onepass_kernel(Conv0Args a, con
     __syncthreads();
     const int nt = stage_wave(a, b, chunk, sw);
     const T* dyp = dy + ((long)b * a.T0 + (long)chunk * TCH) * a.C0 + m.c0;
-#pragma unroll 2
-    for (int t = m.tl; t < nt; t += m.nlan) {
-      float v[CV], d[CV];
-      ld4(dyp + (long)t * a.C0, d);
-      conv4_at<KT>(sw, w, t, a.stride, v);
-      const float* x = sw + t * a.stride;
+    // dy of PF frames is requested before the first of them is used: the pass reads 2 bytes per ~40 VALU instructions, and with
+    // two loads in flight per wave (the compiler's own unroll) three waves per SIMD kept ~12 KB per CU on the wire -- 0.8 TB/s
+    constexpr int PF = 4;
+    for (int t0 = m.tl; t0 < nt; t0 += PF * m.nlan) {
+      float dq[PF][CV];
 #pragma unroll
-      for (int e = 0; e < CV; ++e) {
-        const float xh = (v[e] - mu[e]) * rs[e];
-        const float g = d[e] * gelu_grad_t<T>(fmaf(xh, ga[e], be[e]));
-        v[e] = g;
-        acc[e][KT] += g;
-        acc[e][KT + 1] = fmaf(g, xh, acc[e][KT + 1]);
+      for (int u = 0; u < PF; ++u) {
+        const int t = t0 + u * m.nlan;
+        if (t < nt) ld4(dyp + (long)t * a.C0, dq[u]);
       }
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        const float xj = x[j];
+      for (int u = 0; u < PF; ++u) {
+        const int t = t0 + u * m.nlan;
+        if (t >= nt) break;
+        float v[CV];
+        conv4_at<KT>(sw, w, t, a.stride, v);
+        const float* x = sw + t * a.stride;
 #pragma unroll
-        for (int e = 0; e < CV; ++e) acc[e][j] = fmaf(v[e], xj, acc[e][j]);
+        for (int e = 0; e < CV; ++e) {
+          const float xh = (v[e] - mu[e]) * rs[e];
+          const float g = dq[u][e] * gelu_grad_t<T>(fmaf(xh, ga[e], be[e]));
+          v[e] = g;
+          acc[e][KT] += g;
+          acc[e][KT + 1] = fmaf(g, xh, acc[e][KT + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const float xj = x[j];
+#pragma unroll
+          for (int e = 0; e < CV; ++e) acc[e][j] = fmaf(v[e], xj, acc[e][j]);
+        }
       }
     }
   }

@@ -494,7 +494,6 @@ struct Ctx {
 };
 
 enum { SITE_INPUT = 1, SITE_ENC = 2, SITE_LAYER0 = 16 };
-int g_fused_layer = -1;  // -1: FH_FUSED_LAYER (default off), 0 / 1: fh_student_fused_layers()
 
 inline int splitk_for(long tiles, long red) {
   long sk = (512 + tiles - 1) / tiles;
@@ -748,11 +747,6 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
   // ---- transformer layers (post-LN)   module.py:557-582
   const long M2 = s.M2;
   const float scale = 1.0f / sqrtf((float)(D / H));
-  // full-row fused kernels (layer_fused.hip): out-proj + residual + LayerNorm, and fc1 + GELU + fc2 + residual + LayerNorm
-  // OFF by default: measured slower than the five-launch form at every batch size (B = 4 / 16 / 32 / 128: 6.26 / 8.15 / 11.2 / 32.5 ms
-  // per student step against 5.57 / 7.49 / 10.5 / 31.2) -- see layer_fused.hip and DESIGN.md section 7
-  if (g_fused_layer < 0) g_fused_layer = (getenv("FH_FUSED_LAYER") && getenv("FH_FUSED_LAYER")[0] == '1') ? 1 : 0;
-  const bool fused = g_fused_layer == 1 && fh_layer_fused_ok(dt, D, Fd);
   for (int l = 0; l < L; ++l) {
     const float* lp = prm + p.pl.layer0 + (long)l * p.pl.layer_stride;
     const long lpo = p.pl.layer0 + (long)l * p.pl.layer_stride;
@@ -771,19 +765,6 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
     RC(fh_attention_fwd_launch(dt, x.at(p.qkv, (long)l * M2 * 3 * D), x.at(p.attn, (long)l * M2 * D),
                                x.W<float>(p.lse) + (long)l * B * H * s.T2, len_2, B, s.T2, H, D / H, scale,
                                x.drop(c.attention_dropout, site + 0), x.st));
-    if (fused) {
-      RC(fh_rows_linear_ln_launch(x.at(p.attn, (long)l * M2 * D), x.nat(lpo + p.pl.l_o_w), lp + p.pl.l_o_b, xin, lp + p.pl.l_ln1_w,
-                                  lp + p.pl.l_ln1_b, nullptr, x.at(p.s1, (long)l * M2 * D), x.at(p.xa, (long)l * M2 * D),
-                                  x.W<float>(p.st1_mean) + l * M2, x.W<float>(p.st1_rstd) + l * M2, (int)M2, D, D, 1e-5f,
-                                  x.drop(c.dropout, site + 1), x.st));
-      RC(fh_rows_ffn_ln_launch(x.at(p.xa, (long)l * M2 * D), x.nat(lpo + p.pl.l_fc1_w), lp + p.pl.l_fc1_b, x.nat(lpo + p.pl.l_fc2_w),
-                               lp + p.pl.l_fc2_b, x.at(p.xa, (long)l * M2 * D), lp + p.pl.l_ln2_w, lp + p.pl.l_ln2_b,
-                               x.at(p.z1, (long)l * M2 * Fd), x.at(p.hbuf, (long)l * M2 * Fd),
-                               x.at(p.f2, (long)l * M2 * D), x.at(p.s2, (long)l * M2 * D), xout, x.W<float>(p.st2_mean) + l * M2,
-                               x.W<float>(p.st2_rstd) + l * M2, (int)M2, D, Fd, 1e-5f, x.drop(c.activation_dropout, site + 2),
-                               x.drop(c.dropout, site + 3), x.st));
-      continue;
-    }
     {  // out_proj + dropout1 + residual
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.at(p.attn, (long)l * M2 * D), FH_R_CONTIG, D);
@@ -1408,11 +1389,6 @@ int fh_student_ws_info(const fh_student_config* c, const fh_student_call* k, con
   return 1;
 }
 
-int fh_student_fused_layers(int on) {
-  const int prev = g_fused_layer;
-  g_fused_layer = on < 0 ? -1 : (on ? 1 : 0);
-  return prev;
-}
 
 int fh_student_frames(const fh_student_config* c, int S, int* T_conv, int* T_enc) {
   if (!c || validate(*c)) return -1;

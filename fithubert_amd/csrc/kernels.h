@@ -75,11 +75,3 @@ int fh_mul_gelu_grad_launch(int dtype, const void* src, const void* aux, void* d
                             int factor = 0);
 int fh_mask_drop_launch(int dtype, const void* src, void* dst, long rows, int C, int rpb, const int* row_len, fh_drop drop,
                         hipStream_t st);
-
-// ---- layer_fused.hip : full-row fused kernels of the post-LN transformer layer (bf16; module.py:557-582)
-bool fh_layer_fused_ok(int dtype, int D, int Fd);
-int fh_rows_linear_ln_launch(const void* A, const void* W, const float* b, const void* res, const float* gamma, const float* beta, void* pre,
-                             void* s, void* y, float* mean, float* rstd, int M, int K, int N, float eps, fh_drop drop, hipStream_t st);
-int fh_rows_ffn_ln_launch(const void* A, const void* W1, const float* b1, const void* W2, const float* b2, const void* res, const float* gamma,
-                          const float* beta, void* z1, void* h, void* f2, void* s, void* y, float* mean, float* rstd, int M, int D, int F,
-                          float eps, fh_drop drop_act, fh_drop drop_out, hipStream_t st);

@@ -326,11 +326,6 @@ typedef struct {
   const void* d_cnn;
   const void* d_qkv_last;
 } fh_student_grads;
-/* Transformer layers through the full-row fused kernels (out-proj + residual + LayerNorm; fc1 + GELU + fc2 + residual + LayerNorm:
- * modules/module.py:557-582 in two launches per layer instead of five) where the shape allows it (bf16, widths <= 512): on = 1 / 0,
- * -1 = environment default (FH_FUSED_LAYER, off: on MI355X the fused form measured 4-12 % slower per student step than the five
- * launches at every batch size).  Returns the previous setting.  Results agree to bf16 rounding. */
-int fh_student_fused_layers(int on);
 int fh_student_backward_ex(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
                            void* ws, float* grads, const float* wave, const int* lens, const fh_student_grads* g,
                            fh_stream_t stream);
