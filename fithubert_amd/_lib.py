@@ -35,6 +35,9 @@ class GemmEpilogue(C.Structure):
         ("residual", C.c_void_p), ("row_len", C.c_void_p), ("out_f32", C.c_int), ("atomic", C.c_int),
         ("idiv", C.c_int), ("si1", C.c_long), ("si0", C.c_long), ("jdiv", C.c_int), ("sj1", C.c_long),
         ("sj0", C.c_long), ("tail_cols", C.c_int), ("aux_factor", C.c_int),
+        ("kd_teacher", C.c_void_p), ("kd_tdtype", C.c_int), ("kd_lstride", C.c_long), ("kd_layer", C.c_void_p), ("kd_w", C.c_void_p),
+        ("kd_Tt", C.c_int), ("kd_P", C.c_int), ("kd_type", C.c_int), ("kd_grad_scale", C.c_float), ("kd_count", C.c_float),
+        ("kd_partials", C.c_void_p),
     ]
 
 
@@ -96,6 +99,12 @@ class GradNotifyC(C.Structure):
     _fields_ = [("comm_stream", C.c_void_p), ("ready", GRAD_READY_FN), ("user", C.c_void_p)]
 
 
+class StudentKdC(C.Structure):
+    _fields_ = [("teacher", C.c_void_p), ("teacher_dtype", C.c_int), ("teacher_lstride", C.c_long), ("teacher_layer", C.c_void_p),
+                ("layer_w", C.c_void_p), ("Tt", C.c_int), ("loss_type", C.c_int), ("grad_scale", C.c_float), ("partials", C.c_void_p),
+                ("out_losses", C.c_void_p)]
+
+
 class StudentCallC(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("training", C.c_int), ("heads_on", C.c_int), ("seed", C.c_uint32)]
 
@@ -110,6 +119,8 @@ _ENGINE_SIGS = {
     "fh_student_frames": (_I, [C.POINTER(StudentConfigC), _I, C.POINTER(_I), C.POINTER(_I)]),
     "fh_student_prepare": (_I, [C.POINTER(StudentConfigC), _P, _P, _P]),
     "fh_student_forward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P]),
+    "fh_student_kd_partials": (_L, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC)]),
+    "fh_student_forward_kd": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, C.POINTER(StudentKdC), _P]),
     "fh_student_backward": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fh_student_backward_cnn": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fh_student_backward_ex": (_I, [C.POINTER(StudentConfigC), C.POINTER(StudentCallC), _P, _P, _P, _P, _P, _P, C.POINTER(StudentGradsC), _P]),
@@ -217,6 +228,7 @@ def operand(t_ptr, layout, ld, rpb=0, bstride=0, gstride=0, nseg=1, tshift=(0, 0
 def epilogue(**kw):
     e = GemmEpilogue()
     e.alpha = 1.0
+    e.kd_grad_scale = e.kd_count = 1.0
     for k, v in kw.items():
         if k == "drop":
             e.drop.p, e.drop.seed, e.drop.site = v

@@ -664,7 +664,7 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
   return 0;
 }
 
-int forward(const Ctx& x, const float* wave, const int* lens) {
+int forward(const Ctx& x, const float* wave, const int* lens, const fh_student_kd* kd = nullptr) {
   const Plan& p = x.p;
   const fh_student_config& c = p.c;
   const Shapes& s = p.sh;
@@ -859,7 +859,30 @@ int forward(const Ctx& x, const float* wave, const int* lens) {
       g.ep.bias = (const float*)x.rel(p.wl.head_bm) + (long)l0 * P;
       g.ep.bias_gstride = P;
       g.ep.bias_mod = P;
+      if (kd && kd->teacher) {
+        // KD loss in this GEMM's epilogue (train.py:250-293): the workspace tensor "pred" receives d loss / d pred, `pred` itself is
+        // never written; row m = (utterance, reduced frame), column = (sub-frame j, feature)
+        if (!tr || !p.k.heads_on) return -823;
+        g.c_rpb = s.T2;
+        g.c_bstride = (long)s.T2 * s.f * P;
+        g.ep.kd_teacher = kd->teacher;
+        g.ep.kd_tdtype = kd->teacher_dtype;
+        g.ep.kd_lstride = kd->teacher_lstride;
+        g.ep.kd_layer = kd->teacher_layer;
+        g.ep.kd_w = kd->layer_w;
+        g.ep.kd_Tt = kd->Tt;
+        g.ep.kd_P = P;
+        g.ep.kd_type = kd->loss_type;
+        g.ep.kd_grad_scale = kd->grad_scale;
+        g.ep.kd_count = (float)((long)B * s.T2 * s.f * P);
+        g.ep.kd_partials = kd->partials;
+        if (kd->Tt < s.T2 * s.f) return -824;
+      }
       RC(fh_gemm_launch(g, dt, x.st));
+      if (kd && kd->teacher) {
+        const int nblk = (int)(((M2 + 63) / 64) * ((s.f * P + 63) / 64));
+        RC(fh_kd_loss_final_launch(kd->partials, kd->layer_w, kd->out_losses, Lh, nblk, (double)B * s.T2 * s.f * P, x.st));
+      }
       return 0;
     }
     GemmParams g = fh_gemm_params();
@@ -1411,12 +1434,25 @@ int fh_student_prepare(const fh_student_config* c, const float* params, void* wc
 
 int fh_student_forward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
                        const float* wave, const int* lens, fh_stream_t stream) {
+  return fh_student_forward_kd(c, k, params, wc, ws, wave, lens, nullptr, stream);
+}
+long fh_student_kd_partials(const fh_student_config* c, const fh_student_call* k) {
+  if (!c || !k || validate(*c) != 0) return -1;
+  Plan p(*c, *k);
+  if (p.ok != 0) return p.ok;
+  if (c->n_tasks > 0 || c->tr_factor <= 0) return 0;   // the fused form exists for the merged layer-wise heads
+  const long Lh = k->heads_on ? c->layers : 1;
+  return Lh * ((p.sh.M2 + 63) / 64) * (((long)p.sh.f * c->pred_dim + 63) / 64);
+}
+int fh_student_forward_kd(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
+                          const float* wave, const int* lens, const fh_student_kd* kd, fh_stream_t stream) {
   if (!c || !k) return -1;
   RC(validate(*c));
   Plan p(*c, *k);
   if (p.ok != 0) return p.ok;
+  if (kd && kd->teacher && (c->n_tasks > 0 || c->tr_factor <= 0 || !k->training || !k->heads_on)) return -823;
   Ctx x{p, params, (const unsigned char*)wc, (unsigned char*)ws, (hipStream_t)stream, c->dtype};
-  return forward(x, wave, lens);
+  return forward(x, wave, lens, kd);
 }
 
 int fh_student_backward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,

@@ -32,6 +32,8 @@ static inline GemmEpilogue fh_epilogue() {
   e.alpha = 1.0f; e.bias = nullptr; e.bias_gstride = 0; e.bias_mod = 0; e.preact = nullptr; e.act = FH_ACT_NONE;
   e.drop.p = 0.f; e.drop.seed = 0; e.drop.site = 0; e.gelu_aux = nullptr; e.residual = nullptr; e.row_len = nullptr;
   e.out_f32 = 0; e.atomic = 0; e.idiv = 0; e.si1 = 0; e.si0 = 0; e.jdiv = 0; e.sj1 = 0; e.sj0 = 0; e.tail_cols = 0; e.aux_factor = 0;
+  e.kd_teacher = nullptr; e.kd_tdtype = 1; e.kd_lstride = 0; e.kd_layer = nullptr; e.kd_w = nullptr; e.kd_Tt = 0; e.kd_P = 0; e.kd_type = 0;
+  e.kd_grad_scale = 1.f; e.kd_count = 1.f; e.kd_partials = nullptr;
   return e;
 }
 static inline GemmParams fh_gemm_params() {

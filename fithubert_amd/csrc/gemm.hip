@@ -153,6 +153,14 @@ TuneChoice tune_measure(const GemmParams& p, int dtype, hipStream_t stream) {
 
 int launch_16(const GemmParams& p, int dtype, hipStream_t stream) {
   resolve_path();
+  if (p.ep.kd_teacher) {   // the KD-loss epilogue is compiled into loops 7 and 4 (FH_KD_LOOP picks; default 4: two workgroups per CU, so one
+    static int kd_loop = -1;   // workgroup's operand-bound epilogue runs under the other's K loop)
+    if (kd_loop < 0) {
+      const char* e = getenv("FH_KD_LOOP");
+      kd_loop = (e && e[0] == '7') ? 7 : 4;
+    }
+    return launch_path(p, kd_loop, dtype, stream);
+  }
   if (g_gemm_path != 9) return launch_path(p, g_gemm_path, dtype, stream);
   const unsigned long long key = tune_key(p, dtype, stream_mask(stream));
   auto it = g_tune.find(key);
@@ -287,6 +295,13 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.ep.row_len && p.c_rpb <= 0) return -109;
   if ((p.X.segoff[0] | p.X.segoff[1] | p.Y.segoff[0] | p.Y.segoff[1] | p.X.gstride | p.Y.gstride) % vec) return -110;
   if (p.X.seg1_limit % 8 || p.Y.seg1_limit % 8 || p.ep.tail_cols % 8 || (p.ep.tail_cols > 0 && (p.c_rpb <= 0 || p.ep.atomic))) return -111;
+  if (p.ep.kd_teacher) {   // KD-loss epilogue: the forms that implement it
+    const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
+    if (p.c_rpb <= 0 || wrap0 != 0 || p.ep.kd_P <= 0 || p.ep.kd_P % 8 || p.N % p.ep.kd_P || p.ep.atomic || p.ep.residual || p.ep.gelu_aux ||
+        p.ep.row_len || p.ep.out_f32 || p.ep.preact || p.ep.tail_cols || (p.splitk & 0xffff) > 1 || !p.ep.kd_layer || !p.ep.kd_w ||
+        !p.ep.kd_partials || p.ep.kd_tdtype < 0 || p.ep.kd_tdtype > 2 || p.ep.act != FH_ACT_NONE || p.ep.drop.p > 0.f)
+      return -112;
+  }
   if (!g_prof_on) return dtype == 0 ? launch_t<float>(p, stream) : launch_16(p, dtype, stream);
   ProfRec r;
   if (!g_pool.empty()) {

@@ -236,6 +236,65 @@ template <int XL, int YL> struct TileMath<float, XL, YL> {
   }
 };
 
+// ------------------------------------------------------------------ KD-loss epilogue (fh_gemm_epilogue.kd_*)
+__device__ __forceinline__ void kd_load8(const GemmEpilogue& ep, long off, float* t) {
+  if (ep.kd_tdtype == 0) {
+    const float* q = reinterpret_cast<const float*>(ep.kd_teacher) + off;
+    ld4(q, t);
+    ld4(q + 4, t + 4);
+  } else if (ep.kd_tdtype == 2) {
+    unpack16<f16>(ld16(reinterpret_cast<const f16*>(ep.kd_teacher) + off), t);
+  } else {
+    unpack16<bf16>(ld16(reinterpret_cast<const bf16*>(ep.kd_teacher) + off), t);
+  }
+}
+// teacher element offset of output (group g, row i, column c); c a multiple of 8, so its 8 columns share one sub-frame
+__device__ __forceinline__ long kd_offset(const GemmParams& p, int g, int i, int c) {
+  const GemmEpilogue& ep = p.ep;
+  const int b = i / p.c_rpb, t = i - b * p.c_rpb, j = c / ep.kd_P, f = p.N / ep.kd_P;
+  return (long)ep.kd_layer[g] * ep.kd_lstride + ((long)b * ep.kd_Tt + (long)f * t + j) * ep.kd_P + (c - j * ep.kd_P);
+}
+struct KdCoef {
+  float g;     // d loss / d v per unit of (v - t) (mse) or of sign(v - t) (l1); the arithmetic of kd_loss_kernel, term by term
+  bool live;   // the group's weight is not 0
+};
+__device__ __forceinline__ KdCoef kd_coef(const GemmEpilogue& ep, int g) {
+  const float w = ep.kd_w[g];
+  KdCoef c;
+  c.g = ep.kd_grad_scale * w / ep.kd_count * (ep.kd_type == 0 ? 2.0f : 1.0f);
+  c.live = w != 0.f;
+  return c;
+}
+// a[8]: the prediction (already rounded to the output type) -> the gradient; returns this lane's share of the loss sum
+__device__ __forceinline__ float kd_apply(const GemmEpilogue& ep, const KdCoef& kc, const float* t, float* a) {
+  float acc = 0.f;
+  if (kc.live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = a[e] - t[e];
+      if (ep.kd_type == 0) {
+        acc = fmaf(d, d, acc);
+        a[e] = kc.g * d;
+      } else {
+        acc += fabsf(d);
+        a[e] = d > 0.f ? kc.g : (d < 0.f ? -kc.g : 0.f);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+  }
+  return acc;
+}
+// the loss sum of one 64-row x 64-column block (row0, col0 multiples of 64), summed over the wave that owns it
+__device__ __forceinline__ void kd_write_slot(const GemmParams& p, int g, int row0, int col0, int lane, float v) {
+  v = wave_sum(v);
+  if (lane == 0 && row0 < p.M && col0 < p.N) {
+    const int nrb = (p.M + 63) >> 6, ncb = (p.N + 63) >> 6;
+    p.ep.kd_partials[((long)g * nrb + (row0 >> 6)) * ncb + (col0 >> 6)] = v;
+  }
+}
+
 // ------------------------------------------------------------------ epilogue (shared by both main loops)
 template <typename T, int NN = 4, int NM = 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[NN][NM], int i0, int j0, int xi0, int yj0,
@@ -345,9 +404,9 @@ template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float* f) {
 template <> __device__ __forceinline__ void st8<f16>(f16* p, const float* f) { st16(p, pack16<f16>(f)); }
 
 // read-back phase of the staged epilogue: `my` holds 32 rows x 64 fp32 columns of this wave (pass h)
-template <typename T>
+template <typename T, bool KD = false>
 __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const unsigned char* my, int h, int i0, int j0, int xi0,
-                                                  int yj0, int lane, int g, const float (&bv)[8]) {
+                                                  int yj0, int lane, int g, const float (&bv)[8], float* kd_acc = nullptr) {
   const GemmEpilogue& ep = p.ep;
   if (ep.atomic) {
     // weight gradients: one output row x 64 contiguous columns per wave instruction (256 B, the shape fp32 atomics like)
@@ -382,7 +441,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
   // rather than LDS-bound.
   const long wrap0 = p.c_rpb > 0 ? p.c_bstride - (long)p.c_rpb * p.ldc : 0;
   // (batch entries of fewer than 8 rows -- more than one wrap per row step -- stay with the general form)
-  const bool simple = !ep.out_f32 && (p.c_rpb <= 0 || p.c_rpb >= 8);
+  const bool simple = !ep.out_f32 && (p.c_rpb <= 0 || p.c_rpb >= 8) && !KD;   // (KD: the general form below carries the loss arithmetic)
   if (simple && __builtin_amdgcn_readfirstlane(i0 + xi0 + 32 * h + 31 < p.M)) {
     // offsets of the lane's four rows: constant stride, plus the batch-entry correction when a row step crosses into the next
     // entry (the conv data gradients write every other frame of a longer sequence: batch stride != rows x ldc)
@@ -562,6 +621,14 @@ __device__ __forceinline__ void epilogue_readback(const GemmParams& p, const uns
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
+    if constexpr (KD) {   // v is the prediction: round it as the stored `pred` would be, compare with the teacher, write the gradient
+      float tv[8];
+      kd_load8(ep, kd_offset(p, g, i_first + it * 8, j), tv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = to_f(from_f<T>(v[e]));
+      const float part = kd_apply(ep, kd_coef(ep, g), tv, v);
+      if (kd_acc) *kd_acc += part;
+    }
     if (ep.out_f32)
       st8<float>(reinterpret_cast<float*>(p.C) + co[it], v);
     else
@@ -581,12 +648,13 @@ __device__ __forceinline__ void epilogue_bias(const GemmParams& p, int j0, int y
   }
 }
 
-template <typename T>
+template <typename T, bool KD = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const f32x4 (&acc)[4][4], unsigned char* lds, int i0,
                                                      int j0, int xi0, int yj0, int lane, int wave, int g) {
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
   float bv[8];
+  float kd_acc = 0.f;
   epilogue_bias(p, j0, yj0, lane, g, bv);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -597,8 +665,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
       for (int n = 0; n < 4; ++n)
         *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
     __syncthreads();
-    epilogue_readback<T>(p, my, h, i0, j0, xi0, yj0, lane, g, bv);
+    epilogue_readback<T, KD>(p, my, h, i0, j0, xi0, yj0, lane, g, bv, &kd_acc);
   }
+  if constexpr (KD) kd_write_slot(p, g, i0 + xi0, j0 + yj0, lane, kd_acc);   // this wave's 64 x 64 block
 }
 
 // bf16-staged epilogue for outputs without per-row operands (no GELU' operand, residual or row mask; bf16 output): bias, GELU and
@@ -612,7 +681,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
 // add); the fp32 parity mode never comes here.  That took the K = 480 layer launches with a residual from 32.9 to ~24 us stand-alone.
 // Returns false (nothing written) when the tile does not qualify; the caller then runs the fp32-staged form.
 constexpr int EPB_ROW = 144;  // 64 bf16 columns + 16 B pad: conflict-free 8-byte writes (16 rows) and 16-byte reads (8 lanes / row)
-template <typename H, int NM, typename AccT>
+template <typename H, int NM, bool KD = false, typename AccT = void>
 __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& acc, int n_base, unsigned char* my, int i0, int j0,
                                               int xi0, int yj0, int lane, int g) {
   const GemmEpilogue& ep = p.ep;
@@ -620,7 +689,12 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
   const bool ok = !ep.atomic && !ep.row_len && !ep.out_f32 && !ep.tail_cols && (p.c_rpb <= 0 || wrap0 == 0) &&
                   i0 + xi0 + 16 * NM - 1 < p.M;
   if (!__builtin_amdgcn_readfirstlane(ok)) return false;
-  const bool has_ops = __builtin_amdgcn_readfirstlane(ep.gelu_aux != nullptr || ep.residual != nullptr);
+  const bool has_ops = KD || __builtin_amdgcn_readfirstlane(ep.gelu_aux != nullptr || ep.residual != nullptr);
+  float kd_acc[NM / 4 > 0 ? NM / 4 : 1];   // loss sums of this wave's 64-row blocks (KD-loss epilogue)
+#pragma unroll
+  for (int sblk = 0; sblk < (NM / 4 > 0 ? NM / 4 : 1); ++sblk) kd_acc[sblk] = 0.f;
+  KdCoef kc{0.f, false};
+  if constexpr (KD) kc = kd_coef(ep, g);
   const int r = lane & 15, q = lane >> 4;
   float b4[4][4];
   bool cv[4];
@@ -695,6 +769,11 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
       for (int it = 0; it < 4; ++it) st16(reinterpret_cast<bf16*>(p.C) + base + it * rstep, ld16(lp + it * 8 * EPB_ROW));
     } else if (jrv) {
       V16 ax[4], rs[4];
+      float tv[KD ? 4 : 1][8];
+      if constexpr (KD) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) kd_load8(ep, kd_offset(p, g, i0 + xi0 + 32 * h + (lane >> 3) + 8 * it, jr), tv[it]);
+      }
       if (ep.gelu_aux) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) ax[it] = ld16(reinterpret_cast<const bf16*>(ep.gelu_aux) + base + it * rstep);
@@ -717,9 +796,14 @@ __device__ __forceinline__ bool epilogue_bf16(const GemmParams& p, const AccT& a
 #pragma unroll
           for (int e = 0; e < 8; ++e) a[e] += o[e];
         }
+        if constexpr (KD) kd_acc[h >> 1] += kd_apply(ep, kc, tv[it], a);   // a = the staged (rounded) prediction -> its gradient
         st16(reinterpret_cast<bf16*>(p.C) + base + it * rstep, pack16<H>(a));
       }
     }
+  }
+  if constexpr (KD) {
+#pragma unroll
+    for (int sblk = 0; sblk < NM / 4; ++sblk) kd_write_slot(p, g, i0 + xi0 + 64 * sblk, j0 + yj0, lane, kd_acc[sblk]);
   }
   return true;
 }
@@ -879,7 +963,7 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------ the kernel
-template <typename T, int XL, int YL>
+template <typename T, int XL, int YL, bool KD = false>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int BK = 8 * VEC;
@@ -933,7 +1017,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
     __syncthreads();
   }
 
-  gemm_epilogue_staged<T>(p, acc, lds, i0, j0, xi0, yj0, lane, wave, g);
+  gemm_epilogue_staged<T, KD>(p, acc, lds, i0, j0, xi0, yj0, lane, wave, g);
 }
 
 // ------------------------------------------------------------------ direct-to-LDS loads (LDS-DMA): shared pieces
@@ -1166,7 +1250,7 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <typename H, int XL, int YL, int BM_, int BN_, int WM, int WN, int BK_, int NST>
+template <typename H, int XL, int YL, int BM_, int BN_, int WM, int WN, int BK_, int NST, bool KD = false>
 // (the 4-wave build is meant to run TWO workgroups per CU: without the second launch-bound argument the compiler took 364 registers
 // per wave -- 236 + 128 accumulators -- and one workgroup was all a CU could hold)
 __global__ void __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) gemm_ring_kernel(const GemmParams p) {
@@ -1282,8 +1366,9 @@ __global__ void __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) gemm_ring_k
     // outputs without per-row operands: the 16-bit staged form (half the LDS traffic, bias / GELU / dropout in the accumulator layout) --
     // what loops 7 / 8 use; with it the 4-wave 256 x 128 build (two workgroups per CU: one stores while the other multiplies) is a
     // candidate for the forward launches too
-    if (epilogue_bf16<H, MT>(p, acc, cb * 4, my, i0, j0, xi0, yj0 + 64 * cb, lane, g)) continue;
+    if (epilogue_bf16<H, MT, KD>(p, acc, cb * 4, my, i0, j0, xi0, yj0 + 64 * cb, lane, g)) continue;
     float bv[8];
+    float kd_acc[TM / 64] = {};
     epilogue_bias(p, j0, yj0 + 64 * cb, lane, g, bv);
 #pragma unroll
     for (int h = 0; h < TM / 32; ++h) {
@@ -1292,7 +1377,11 @@ __global__ void __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) gemm_ring_k
 #pragma unroll
         for (int n = 0; n < 4; ++n)
           *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[cb * 4 + n][2 * h + mm];
-      epilogue_readback<H>(p, my, h, i0, j0, xi0, yj0 + 64 * cb, lane, g, bv);
+      epilogue_readback<H, KD>(p, my, h, i0, j0, xi0, yj0 + 64 * cb, lane, g, bv, &kd_acc[h >> 1]);
+    }
+    if constexpr (KD) {
+#pragma unroll
+      for (int sblk = 0; sblk < TM / 64; ++sblk) kd_write_slot(p, g, i0 + xi0 + 64 * sblk, j0 + yj0 + 64 * cb, lane, kd_acc[sblk]);
     }
   }
 }
@@ -1363,6 +1452,12 @@ template <typename T> int launch_t(const GemmParams& p, hipStream_t stream) {
   const int tiles_i = (p.M + BM - 1) / BM, tiles_j = (p.N + BN - 1) / BN;
   dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(256);
   const int xl = p.X.layout, yl = p.Y.layout;
+  if (p.ep.kd_teacher) {
+    if (xl != FH_R_CONTIG || yl != FH_R_CONTIG) return -113;
+    hipLaunchKernelGGL((gemm_kernel<T, FH_R_CONTIG, FH_R_CONTIG, true>), grid, block, 0, stream, p);
+    FH_CHECK_LAUNCH();
+    return 0;
+  }
   if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
     hipLaunchKernelGGL((gemm_kernel<T, FH_R_CONTIG, FH_R_CONTIG>), grid, block, 0, stream, p);
   else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
@@ -1756,7 +1851,7 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
 
 
 // one 256 x 256 output tile (logical tile lb, reduction split lblk.split of nsplit) of the 8-phase loop
-template <typename H, int XL, int YL>
+template <typename H, int XL, int YL, bool KD = false>
 __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char* lds, const LogicalBlock lblk, int nsplit, int g) {
   constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
   constexpr int RA = XL == FH_R_STRIDED ? 16 : 8, RB = YL == FH_R_STRIDED ? 8 : 4;  // LDS reads of an A / B fragment phase
@@ -1876,8 +1971,9 @@ __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
-  if (epilogue_bf16<H, 8>(p, acc, 0, my, i0, j0, xi0, yj0, lane, g)) return;
+  if (epilogue_bf16<H, 8, KD>(p, acc, 0, my, i0, j0, xi0, yj0, lane, g)) return;
   float bv[8];
+  float kd_acc[2] = {0.f, 0.f};
   epilogue_bias(p, j0, yj0, lane, g, bv);
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
@@ -1886,14 +1982,18 @@ __device__ __forceinline__ void gemm_8ph_tile(const GemmParams& p, unsigned char
 #pragma unroll
       for (int n = 0; n < 4; ++n)
         *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[n][2 * h + mm];
-    epilogue_readback<H>(p, my, h, i0, j0, xi0, yj0, lane, g, bv);
+    epilogue_readback<H, KD>(p, my, h, i0, j0, xi0, yj0, lane, g, bv, &kd_acc[h >> 1]);
+  }
+  if constexpr (KD) {   // (a row tile cut by M: the 64-row blocks that exist)
+    kd_write_slot(p, g, i0 + xi0, j0 + yj0, lane, kd_acc[0]);
+    kd_write_slot(p, g, i0 + xi0 + 64, j0 + yj0, lane, kd_acc[1]);
   }
 }
 
-template <typename H, int XL, int YL>
+template <typename H, int XL, int YL, bool KD = false>
 __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  gemm_8ph_tile<H, XL, YL>(p, lds, logical_block(p.splitk), (int)gridDim.y, (int)blockIdx.z);
+  gemm_8ph_tile<H, XL, YL, KD>(p, lds, logical_block(p.splitk), (int)gridDim.y, (int)blockIdx.z);
 }
 // ------------------------------------------------------------------ loop 8: the 8-phase loop as a STREAMING persistent launch
 // One workgroup per CU walks the tiles f, f + G, f + 2 G, ... (G = grid size, a multiple of 8, so a workgroup's tiles keep their XCD
@@ -2230,6 +2330,17 @@ template <typename H> int launch_8ph(const GemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   const int xl = p.X.layout, yl = p.Y.layout;
+  if (p.ep.kd_teacher) {   // the KD-loss epilogue is compiled into its own instance (32 more live registers in the read-back)
+    if (xl != FH_R_CONTIG || yl != FH_R_CONTIG) return -113;
+    static bool kd_attr = false;
+    if (!kd_attr) {
+      hipFuncSetAttribute((const void*)gemm_8ph_kernel<H, FH_R_CONTIG, FH_R_CONTIG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      kd_attr = true;
+    }
+    hipLaunchKernelGGL((gemm_8ph_kernel<H, FH_R_CONTIG, FH_R_CONTIG, true>), grid, block, smem, stream, p);
+    FH_CHECK_LAUNCH();
+    return 0;
+  }
   if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
     hipLaunchKernelGGL((gemm_8ph_kernel<H, FH_R_CONTIG, FH_R_CONTIG>), grid, block, smem, stream, p);
   else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)
@@ -2245,7 +2356,7 @@ template <typename H> int launch_8ph(const GemmParams& p, hipStream_t stream) {
 // launches loop 8 can take: the bf16-staged epilogue without per-row operands, one reduction split
 bool stream_ok(const GemmParams& p) {
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
-  return !p.ep.atomic && !p.ep.gelu_aux && !p.ep.residual && !p.ep.row_len && !p.ep.out_f32 && !p.ep.tail_cols &&
+  return !p.ep.atomic && !p.ep.gelu_aux && !p.ep.residual && !p.ep.row_len && !p.ep.out_f32 && !p.ep.tail_cols && !p.ep.kd_teacher &&
          (p.c_rpb <= 0 || wrap0 == 0) && (p.splitk & 0xffff) <= 1;
 }
 template <typename H> int launch_8ph_stream(const GemmParams& p, hipStream_t stream) {
@@ -2292,6 +2403,17 @@ template <typename H, int BM_, int BN_, int WM, int WN, int BK_, int NST> int la
     attr_set = true;
   }
   const int xl = p.X.layout, yl = p.Y.layout;
+  if (p.ep.kd_teacher) {   // KD-loss epilogue: its own instance
+    if (xl != FH_R_CONTIG || yl != FH_R_CONTIG) return -113;
+    static bool kd_attr = false;
+    if (!kd_attr) {
+      hipFuncSetAttribute((const void*)gemm_ring_kernel<H, FH_R_CONTIG, FH_R_CONTIG, BM_, BN_, WM, WN, BK_, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      kd_attr = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<H, FH_R_CONTIG, FH_R_CONTIG, BM_, BN_, WM, WN, BK_, NST, true>), grid, block, smem, stream, p);
+    FH_CHECK_LAUNCH();
+    return 0;
+  }
   if (xl == FH_R_CONTIG && yl == FH_R_CONTIG)
     hipLaunchKernelGGL((gemm_ring_kernel<H, FH_R_CONTIG, FH_R_CONTIG, BM_, BN_, WM, WN, BK_, NST>), grid, block, smem, stream, p);
   else if (xl == FH_R_CONTIG && yl == FH_R_STRIDED)

@@ -57,6 +57,8 @@ int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const v
 int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
                       const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L, int B,
                       int Tp, int Tt, int P, long teacher_lstride, int loss_type, float grad_scale, hipStream_t st);
+// out[l] = sum(partials[l][0 .. nblk)) / count, out[L] = sum_l w[l] out[l]  (the tail of fh_kd_loss_launch; also behind the KD-loss GEMM epilogue)
+int fh_kd_loss_final_launch(const float* partials, const float* layer_w, double* out_losses, int L, int nblk, double count, hipStream_t st);
 int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,
                            const float* layer_w, const int* teacher_layer, float* partials, double* out_losses, int L,
                            int B, int Tp, int Tt, int P, long teacher_lstride, int loss_type, float rec_weight,

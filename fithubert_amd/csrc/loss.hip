@@ -303,3 +303,9 @@ int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const
   FH_CHECK_LAUNCH();
   return 0;
 }
+
+int fh_kd_loss_final_launch(const float* partials, const float* layer_w, double* out_losses, int L, int nblk, double count, hipStream_t st) {
+  hipLaunchKernelGGL(kd_loss_final_kernel, dim3(1), dim3(256), 0, st, partials, layer_w, out_losses, L, nblk, 1.0 / count);
+  FH_CHECK_LAUNCH();
+  return 0;
+}

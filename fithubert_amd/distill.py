@@ -142,6 +142,10 @@ class W2V2Distil:
         self.num_gpus = len(t["gpus"]) if isinstance(t["gpus"], list) else t["gpus"]
         self.accumulate = int(t.get("accumulate_grad_batches", 1))
         self._rows_loss = self.sim_loss_weight > 0   # row-wise kernel (rec + cosine); its out[-1] is the fully weighted total
+        # KD loss inside the projection heads' GEMM epilogue (fh_student_forward_kd): built and bit-identical, but it takes that GEMM off
+        # the streaming loop 8 and its operand-bound epilogue runs serially with the K loop -- 0.4 - 1.1 % SLOWER per step than the
+        # separate loss kernel (which streams at 5.4 TB/s) on three boxes, so it is opt-in: FH_KD_FUSED=1
+        self._kd_fused = os.environ.get("FH_KD_FUSED", "0") == "1"
         self._one = torch.ones(1, device=self.device)
         self._zero_i = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._set_loss_tables()
@@ -371,10 +375,24 @@ class W2V2Distil:
         # as the reference's per-process RNG streams do
         step_seed = seed if seed is not None else \
             ((self.opt_step * 7919 + self._micro * 104729 + batch_idx + 1 + self.rank * 0x9E3779B1) & 0xFFFFFFFF)
-        ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed)
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
-        if self._rows_loss:
+        # FH_KD_FUSED=1: the layer-wise loss rides in the projection heads' GEMM epilogue (`pred` is never written, the loss vector and
+        # d loss / d pred come out of the forward); default: the separate fused loss kernel, which is faster
+        fused_kd = (not self._rows_loss) and self._kd_fused and getattr(self.engine, "kd_fusable", lambda h=True: False)(self.student_model._heads_on)
+        if fused_kd:
+            if ev is not None:      # the teacher's hidden states are an operand of the forward now (one batch ahead: ready long before)
+                torch.cuda.current_stream(self.device).wait_event(ev)
+            ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed,
+                                     kd=dict(teacher=hid, layer_w=self.layer_w, teacher_layer=self.teacher_layer,
+                                             loss_type=0 if self.rec_loss_type == "mse" else 1,
+                                             grad_scale=float(self.rec_loss_weight) * self.loss_scale))
+            out, d_pred = ws.kd_out, ws.view("pred")
+        else:
+            ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed)
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+        if fused_kd:
+            pass
+        elif self._rows_loss:
             out, d_pred = self.engine.kd_loss_rows(ws, hid, self.layer_w, self.teacher_layer,
                                                    loss_type=0 if self.rec_loss_type == "mse" else 1,
                                                    rec_weight=float(self.rec_loss_weight), sim_weight=float(self.sim_loss_weight),

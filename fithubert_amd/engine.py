@@ -208,8 +208,16 @@ class StudentEngine:
         return tp, [t // f for t in tp]
 
     # ------------------------------------------------------------------ compute
+    def kd_fusable(self, heads_on: bool = True) -> bool:
+        """The KD loss can ride in the merged heads' GEMM epilogue (fh_student_forward_kd): layer-wise heads with time reduction."""
+        return self.c.n_tasks == 0 and self.c.tr_factor > 0 and bool(heads_on)
+
     def forward(self, wave: torch.Tensor, sample_lengths=None, training: bool = False, heads_on: bool = True,
-                seed: int = 0) -> Workspace:
+                seed: int = 0, kd: Optional[dict] = None) -> Workspace:
+        """``kd`` (training only): dict(teacher=[Lt][B][Tt][P] tensor, layer_w, teacher_layer, loss_type=0, grad_scale=1.0) -- the
+        layer-wise KD loss is then computed inside the projection heads' GEMM epilogue: ``ws.kd_out`` holds the fp64 loss vector
+        [per-layer means..., weighted total] and ``ws.view("pred")`` d loss / d pred (pass it to ``backward(d_pred=...)``); the
+        predictions themselves are never written."""
         assert wave.is_cuda and wave.dtype == torch.float32 and wave.dim() == 2 and wave.is_contiguous()
         B, S = wave.shape
         if training and self.auto_tune and (self._shape_class(B, S) + (bool(heads_on),)) not in self._tuned:
@@ -228,9 +236,26 @@ class StudentEngine:
             ws.lens = torch.tensor([tp, t2], dtype=torch.int32).to(self.device, non_blocking=True)
         ws.wave = wave
         self.prepare()
+        ws.kd_out = None
+        lens_p = ws.lens.data_ptr() if ws.lens is not None else None
+        if kd is not None:
+            if not (training and self.kd_fusable(heads_on)):
+                raise ValueError("the fused KD loss needs a training forward of the layer-wise heads with time reduction")
+            teacher = kd["teacher"]
+            assert teacher.is_cuda and teacher.is_contiguous() and teacher.dim() == 4 and teacher.shape[1] == B
+            n = self.lib.fh_student_kd_partials(C.byref(self.c), C.byref(call))
+            Lh = self.c.layers
+            ws.kd_partials = torch.empty(max(n, 1), device=self.device, dtype=torch.float32)
+            ws.kd_out = torch.empty(Lh + 1, device=self.device, dtype=torch.float64)
+            a = L.StudentKdC(teacher.data_ptr(), tensor_dtype_code(teacher), B * teacher.shape[2] * teacher.shape[3],
+                             kd["teacher_layer"].data_ptr(), kd["layer_w"].data_ptr(), int(teacher.shape[2]), int(kd.get("loss_type", 0)),
+                             float(kd.get("grad_scale", 1.0)), ws.kd_partials.data_ptr(), ws.kd_out.data_ptr())
+            ws.kd_keep = (teacher, kd["teacher_layer"], kd["layer_w"])
+            L.check(self.lib.fh_student_forward_kd(C.byref(self.c), C.byref(call), self.params.data_ptr(), self.wc.data_ptr(), buf.data_ptr(),
+                                                   wave.data_ptr(), lens_p, C.byref(a), self.stream()), "fh_student_forward_kd")
+            return ws
         L.check(self.lib.fh_student_forward(C.byref(self.c), C.byref(call), self.params.data_ptr(), self.wc.data_ptr(),
-                                            buf.data_ptr(), wave.data_ptr(), ws.lens.data_ptr() if ws.lens is not None else None,
-                                            self.stream()), "fh_student_forward")
+                                            buf.data_ptr(), wave.data_ptr(), lens_p, self.stream()), "fh_student_forward")
         return ws
 
     @staticmethod

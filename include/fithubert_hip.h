@@ -73,6 +73,21 @@ typedef struct {
                               preact set): `preact` receives GELU'(alpha X.Y + bias) -- the sigmoid of the activation is at hand there,
                               the derivative costs 5 more VALU issues; backward (gelu_aux set): C = (X.Y) * gelu_aux, no GELU'
                               evaluation (it cost ~17 issues per element in the conv data-gradient epilogues) */
+  /* KD-loss epilogue (train.py:250-293 inside the merged projection heads' GEMM, round 3): with kd_teacher set, v = alpha X.Y + bias is
+   * rounded to the output type -- exactly the `pred` element the unfused path stores -- and compared with the teacher frame it
+   * predicts: row i = (utterance b = i / c_rpb, frame t = i % c_rpb), column c = (sub-frame j = c / kd_P, feature c % kd_P) against
+   * teacher[kd_layer[g]][b][(N / kd_P) t + j][c % kd_P].  C receives d loss / d v = kd_grad_scale * kd_w[g] / kd_count * (2 (v - t) | sign(v - t));
+   * the sum of (v - t)^2 | |v - t| of every 64-row x 64-column block goes to kd_partials[(g * ceil(M / 64) + i / 64) * ceil(N / 64) + c / 64]
+   * (one wave each, fixed order: bit-reproducible; fh_kd_loss_finish turns them into the per-layer means).  `pred` itself is never
+   * written.  Requires c_rpb > 0, rows of one utterance contiguous, no other per-row operand; runs on loop 7 (16-bit) / the fp32 kernel. */
+  const void* kd_teacher;
+  int kd_tdtype;           /* element type of the teacher tensor (dtype code) */
+  long kd_lstride;         /* elements between teacher layers */
+  const int* kd_layer;     /* [groups] teacher layer of each group */
+  const float* kd_w;       /* [groups] loss weight of each group (0: the group's gradient is 0 and its loss is not accumulated) */
+  int kd_Tt, kd_P, kd_type; /* teacher frames per utterance, feature width, 0 = mse / 1 = l1 */
+  float kd_grad_scale, kd_count; /* see above; kd_count = elements of one group's loss mean (B * Tp * P) */
+  float* kd_partials;
 } fh_gemm_epilogue;
 
 typedef struct {
@@ -307,6 +322,26 @@ int fh_student_prepare(const fh_student_config* c, const float* params, void* wc
 /* lens: device int [2][B] = valid frames after the frontend, valid frames after time reduction; NULL = no padding */
 int fh_student_forward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,
                        void* ws, const float* wave, const int* lens, fh_stream_t stream);
+/* The training forward with the layer-wise KD loss (train.py:250-293, mse / l1 with per-layer weights) computed INSIDE the merged
+ * projection heads' GEMM epilogue: the workspace tensor "pred" receives d loss / d pred (what fh_kd_loss would have written to dpred),
+ * out_losses the L per-layer means and the weighted total, and `pred` itself is never written or read back (1.17 GB each way at
+ * B = 128).  Exists for the layer-wise heads with time reduction (fithubert.yaml); teacher [Lt][B][Tt][P] as fh_kd_loss takes it, ready on
+ * `stream` when the call is made.  partials: fh_student_kd_partials(c, k) floats.  kd == NULL: fh_student_forward. */
+typedef struct {
+  const void* teacher;
+  int teacher_dtype;
+  long teacher_lstride;      /* elements between teacher layers (B * Tt * P) */
+  const int* teacher_layer;  /* [L] teacher layer of each student layer */
+  const float* layer_w;      /* [L] */
+  int Tt;                    /* teacher frames per utterance (>= frames of "pred") */
+  int loss_type;             /* 0 = mse, 1 = l1 */
+  float grad_scale;          /* rec_loss_weight (x the loss scale of the fp16 mode) */
+  float* partials;
+  double* out_losses;        /* [L + 1] */
+} fh_student_kd;
+long fh_student_kd_partials(const fh_student_config* c, const fh_student_call* k);
+int fh_student_forward_kd(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc, void* ws,
+                          const float* wave, const int* lens, const fh_student_kd* kd, fh_stream_t stream);
 /* grads += d loss / d params.  d_pred: gradient w.r.t. the workspace tensor "pred" (same shape/dtype) or NULL;
  * d_hidden: gradient w.r.t. "xo" slots 1..L (layer outputs, [L][B*T_enc][D], dtype) or NULL. */
 int fh_student_backward(const fh_student_config* c, const fh_student_call* k, const float* params, const void* wc,

@@ -23,6 +23,7 @@ from oracle import loss_ref as LR  # noqa: E402
 from oracle import student_ref as S  # noqa: E402
 
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # fp16 KD-loss deviation from the reference's fp32 loss, ABSOLUTE (eval forward, identical weights / inputs).  The reference's own AMP
 # arithmetic (the unmodified reference under torch.autocast(float16), tools/ref_amp_delta.py -> profiles/r03_reference_amp_delta.txt)
 # deviates by -1.78e-4 on the 2 s fixture: no fp16 computation can promise less than the reference's own.  Measured values of this
@@ -642,3 +643,44 @@ def test_backward_notify_segments_tile_the_gradient_buffer(variant):
         assert segs[0][1] == head_first, segs                            # the heads' range is reported first
     for (_, first, count), snap in zip(segs, snaps):
         assert torch.equal(snap, got[first:first + count]), (first, count)   # final at the time it was reported
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bf16", "float16"])
+@pytest.mark.parametrize("padded,loss_type", [(False, 0), (True, 0), (True, 1)])
+def test_kd_loss_in_the_heads_gemm_epilogue_equals_the_separate_loss_kernel(dtype, padded, loss_type):
+    """fh_student_forward_kd (train.py:250-293 inside the merged projection heads' GEMM): the loss vector equals fh_kd_loss's on the
+    materialised predictions to summation order (per-tile partials instead of per-block ones), d loss / d pred is BIT-identical (the
+    epilogue rounds the prediction to the storage type before it compares, exactly what the separate kernel reads back), and so is
+    everything the backward derives from it up to the atomics' order.  Odd frame counts (T2 = 49 -> 98 predicted frames against 99 of
+    the teacher), a ragged last row tile, a zero-weight layer, mse and l1, padded batch."""
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=4)
+    eng, _ = _engine(cfg, 9, dtype)
+    B, S = 3, 32000
+    g = torch.Generator().manual_seed(5)
+    wav = (0.3 * torch.randn(B, S, generator=g)).to(DEV)
+    lens = [32000, 25000, 31000] if padded else None
+    if padded:
+        for b, n in enumerate(lens):
+            wav[b, n:] = 0
+    Tt = 99
+    teacher = torch.randn(4, B, Tt, 768, generator=g).to(DEV).to(eng.elem if dtype != "float32" else torch.float32).contiguous()
+    w = torch.tensor([0.1, 0.0, 0.1, 1.0], device=DEV)
+    tl = torch.tensor([2, 0, 1, 3], dtype=torch.int32, device=DEV)
+    gs = 4096.0 if dtype == "float16" else 1.0
+    ws_a = eng.forward(wav, lens, training=True, seed=3)
+    out_a, d_a = eng.kd_loss(ws_a, teacher, w, tl, loss_type=loss_type, grad_scale=gs)
+    eng.grads.zero_()
+    eng.backward(ws_a, d_pred=d_a)
+    g_a = eng.grads.clone()
+    ws_b = eng.forward(wav, lens, training=True, seed=3, kd=dict(teacher=teacher, layer_w=w, teacher_layer=tl, loss_type=loss_type, grad_scale=gs))
+    out_b, d_b = ws_b.kd_out, ws_b.view("pred")
+    torch.cuda.synchronize()
+    assert torch.equal(d_a, d_b)
+    assert out_a[1].item() == 0 and out_b[1].item() == 0                       # the zero-weight layer reports no loss, as fh_kd_loss
+    assert torch.allclose(out_a, out_b, rtol=1e-6, atol=0), (out_a, out_b)
+    eng.grads.zero_()
+    eng.backward(ws_b, d_pred=d_b)
+    torch.cuda.synchronize()
+    assert _rel_l2(eng.grads, g_a) < 1e-4                                       # same inputs; fp32 atomics in another order (1.1e-5 seen in fp16)
+    assert torch.equal(ws_a.view("xo"), ws_b.view("xo"))
