@@ -38,6 +38,8 @@ class GemmEpilogue(C.Structure):
         ("kd_teacher", C.c_void_p), ("kd_tdtype", C.c_int), ("kd_lstride", C.c_long), ("kd_layer", C.c_void_p), ("kd_w", C.c_void_p),
         ("kd_Tt", C.c_int), ("kd_P", C.c_int), ("kd_type", C.c_int), ("kd_grad_scale", C.c_float), ("kd_count", C.c_float),
         ("kd_partials", C.c_void_p),
+        ("c0_wave", C.c_void_p), ("c0_w", C.c_void_p), ("c0_gamma", C.c_void_p), ("c0_beta", C.c_void_p), ("c0_mean", C.c_void_p),
+        ("c0_rstd", C.c_void_p), ("c0_wpart", C.c_void_p), ("c0_S", C.c_int), ("c0_K", C.c_int), ("c0_stride", C.c_int),
     ]
 
 

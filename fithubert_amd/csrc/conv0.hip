@@ -77,13 +77,14 @@ __global__ void __launch_bounds__(128) conv0_stats_kernel(Conv0Args a, float* pa
 
 // combine chunk partials (fp64), then mean_c = w_c . m, var_c = w_c^T Cov w_c  ->  mean, rstd per (b, c)
 __global__ void conv0_stats_final_kernel(const float* part, const float* w, float* mean, float* rstd, int B, int nchunk, int C0,
-                                         int K, int T0, float eps) {
+                                         int K, int T0, float eps, double* wsum /*[B][K + K*K] raw sums, kept for the backward, or null*/) {
   __shared__ double sm[MAXK + MAXK * MAXK];
   const int b = blockIdx.x;
   const int ns = K + K * K;
   for (int s = threadIdx.x; s < ns; s += blockDim.x) {
     double acc = 0.0;
     for (int k = 0; k < nchunk; ++k) acc += (double)part[((long)b * nchunk + k) * ns + s];
+    if (wsum) wsum[(long)b * ns + s] = acc;
     sm[s] = acc / (double)T0;
   }
   __syncthreads();
@@ -276,26 +277,57 @@ __global__ void __launch_bounds__(256) conv0_bwd_onepass_kernel(Conv0Args a, con
 // per (utterance b, block of 64 channels): waveform sums from the statistics partials and the per-channel sums of the pass
 // partials (fp64, every thread walking a CONTIGUOUS run of the partial arrays -- the first form had one thread per channel walk
 // all blocks with a 48-byte stride: 95-180 us for a few KB of arithmetic), then for every channel the formula above
+// waveform sums of one utterance from the statistics partials: Sx_j (K values) and Rx (K x K), fp64, [B][K + K*K].  One workgroup per
+// utterance, every (sum, half of the chunks) pair a thread with four loads in flight -- the combine kernel used to walk all chunks of
+// every sum serially in each of its blocks (125 dependent loads at 10 s: 0.6 ms under the concurrent weight-gradient stream)
+__global__ void __launch_bounds__(512) conv0_wave_sums_kernel(const float* __restrict__ spart, double* __restrict__ sums, int nchunk, int ns) {
+  __shared__ double part[2][MAXK + MAXK * MAXK];
+  const int b = blockIdx.x, s = threadIdx.x & 255, half = threadIdx.x >> 8;
+  if (s < ns) {
+    const int k_lo = half ? nchunk / 2 : 0, k_hi = half ? nchunk : nchunk / 2;
+    const float* pp = spart + (long)b * nchunk * ns + s;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = k_lo;
+    for (; k + 4 <= k_hi; k += 4) {
+      const float v0 = pp[(long)k * ns], v1 = pp[(long)(k + 1) * ns], v2 = pp[(long)(k + 2) * ns], v3 = pp[(long)(k + 3) * ns];
+      a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+    }
+    for (; k < k_hi; ++k) a0 += (double)pp[(long)k * ns];
+    part[half][s] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (threadIdx.x < ns) sums[(long)b * ns + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x];
+}
+
 constexpr int CBW = 64;
-__global__ void __launch_bounds__(256) conv0_bwd_combine_kernel(const float* spart, const float* wpart, const float* w,
+__global__ void __launch_bounds__(256) conv0_bwd_combine_kernel(const double* wsum, const float* wpart, const float* w,
                                                                 const float* gamma, const float* mean, const float* rstd, float* dw,
                                                                 float* dgamma, float* dbeta, int nchunk, int nblk, int C0, int K,
                                                                 int KT, int T0, float scale) {
   __shared__ double sx[MAXK], rx[MAXK * MAXK];
   __shared__ double acc[CBW * (MAXK + 2)];
+  // blockIdx.z: a share of the partial blocks (the formula below is linear in A_j, S1, S2, so every share adds its own contribution:
+  // with one partial block per 256-frame tile -- the GEMM-epilogue form, 125 per 10 s utterance -- a single walk was 0.68 ms of
+  // dependent loads)
   const int b = blockIdx.x, cb = blockIdx.y * CBW;
+  const int k_lo = (int)((long)nblk * blockIdx.z / gridDim.z), k_hi = (int)((long)nblk * (blockIdx.z + 1) / gridDim.z);
   const int ns = K + K * K;
   for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-    double a = 0.0;
-    for (int k = 0; k < nchunk; ++k) a += (double)spart[((long)b * nchunk + k) * ns + s];
+    const double a = wsum[(long)b * ns + s];
     if (s < K) sx[s] = a; else rx[s - K] = a;
   }
   const int per = KT + 2, items = CBW * per;   // (channel, slot) pairs of this block: contiguous in every partial block
   for (int it = threadIdx.x; it < items; it += blockDim.x) {
-    double a = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const float* pp = wpart + ((long)b * nblk * C0 + cb) * per + it;
-    for (int k = 0; k < nblk; ++k) a += (double)pp[(long)k * C0 * per];
-    acc[it] = a;
+    const long st = (long)C0 * per;
+    int k = k_lo;
+    for (; k + 4 <= k_hi; k += 4) {   // four independent loads in flight
+      const float v0 = pp[k * st], v1 = pp[(k + 1) * st], v2 = pp[(k + 2) * st], v3 = pp[(k + 3) * st];
+      a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+    }
+    for (; k < k_hi; ++k) a0 += (double)pp[k * st];
+    acc[it] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   const int c = cb + threadIdx.x;
@@ -329,9 +361,17 @@ int fh_conv0_bwd_blocks(int B, int nchunk) {
 }
 // scratch (floats) shared by forward and backward: float2 partials [B][nchunk][C0] | float2 [B][C0] | backward partial sums
 // [B][blocks][C0][MAXK + 2]
+// scratch when the backward's partial sums come from the GEMM epilogue: one block per 256-frame tile of every utterance
+// width (in float2) of the per-utterance block between the statistics partials and the backward's partial sums: MAXK + MAXK^2 fp64
+// waveform sums (or, historically, C0 (a, b) pairs)
+int fh_conv0_ab_width(int C0) { return C0 > MAXK + MAXK * MAXK ? C0 : MAXK + MAXK * MAXK; }
+long fh_conv0_fused_scratch_n(int B, int T0, int C0) {
+  const long nchunk = fh_conv0_nchunk(T0);
+  return 2L * B * nchunk * C0 + 2L * B * fh_conv0_ab_width(C0) + (long)B * nchunk * C0 * (MAXK + 2);
+}
 long fh_conv0_scratch_n(int B, int T0, int C0) {
   const long nchunk = fh_conv0_nchunk(T0);
-  return 2L * B * nchunk * C0 + 2L * B * C0 + (long)B * fh_conv0_bwd_blocks(B, (int)nchunk) * C0 * (MAXK + 2);
+  return 2L * B * nchunk * C0 + 2L * B * fh_conv0_ab_width(C0) + (long)B * fh_conv0_bwd_blocks(B, (int)nchunk) * C0 * (MAXK + 2);
 }
 
 // ---------------------------------------------------------------- layer_norm-mode frontend (HuBERT Large): conv + bias + LayerNorm + GELU
@@ -406,8 +446,10 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
   if (K + K * K > 2 * C0) return -202;  // the statistics partials reuse the [B][nchunk][C0] float2 scratch
   hipLaunchKernelGGL(conv0_stats_kernel, grid, dim3(128), smem_bytes(stride, K, false), st, a, (float*)part);
   FH_CHECK_LAUNCH();
+  // the utterance's raw waveform sums stay in the scratch (the [B][ab width] block behind the partials) for the backward's combine
+  double* wsum = reinterpret_cast<double*>(part + (long)B * a.nchunk * C0);
   hipLaunchKernelGGL(conv0_stats_final_kernel, dim3(B), dim3(256), 0, st, (const float*)part, w, mean, rstd, B, a.nchunk, C0, K,
-                     a.T0, eps);
+                     a.T0, eps, wsum);
   FH_CHECK_LAUNCH();
 #define FH_C0_APPLY(T, KT, CW) \
   hipLaunchKernelGGL((conv0_apply_kernel<T, KT, CW>), grid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (T*)y)
@@ -427,7 +469,7 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
 int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const float* gamma, const float* beta,
                         const void* dy, const float* mean, const float* rstd, float2* part, float2* ab, float* dw,
                         float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
-                        hipStream_t st, int stats_ready) {
+                        hipStream_t st, int stats_ready, int ext_nblk) {
   if (K > MAXK || C0 % 64 != 0 || C0 / CV > 256 || 256 % (C0 / CV) != 0) return -201;
   Conv0Args a;
   a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta;
@@ -441,17 +483,30 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
     hipLaunchKernelGGL(conv0_stats_kernel, grid, dim3(128), smem_bytes(stride, K, false), st, a, (float*)part);
     FH_CHECK_LAUNCH();
   }
-  const int nblk = fh_conv0_bwd_blocks(B, a.nchunk);  // ~1024 blocks in total; each writes its partial sums once
+  // ext_nblk > 0: the per-(utterance, block, channel) sums are already in `wpart` -- ext_nblk blocks of [C0][10 + 2] per utterance, left
+  // there by the conv-0 weight-gradient epilogue of layer 1's data-gradient GEMM (gemm_loops.cuh) -- and only the combine runs
+  const int nblk = ext_nblk > 0 ? ext_nblk : fh_conv0_bwd_blocks(B, a.nchunk);  // ~1024 blocks in total; each writes its partial sums once
   dim3 wgrid(nblk, B);
-  float* wpart = (float*)(ab + (long)B * C0);
+  float* wpart = (float*)(ab + (long)B * fh_conv0_ab_width(C0));
+  if (ext_nblk <= 0) {
 #define FH_C0_WG(T, KT) \
   hipLaunchKernelGGL((conv0_bwd_onepass_kernel<T, KT>), wgrid, block, smem_bytes(stride, K, false), st, a, mean, rstd, (const T*)dy, wpart)
-  if (dtype == 0) { if (K == 10) FH_C0_WG(float, 10); else FH_C0_WG(float, MAXK); }
-  else if (dtype == 2) { if (K == 10) FH_C0_WG(f16, 10); else FH_C0_WG(f16, MAXK); }
-  else { if (K == 10) FH_C0_WG(bf16, 10); else FH_C0_WG(bf16, MAXK); }
+    if (dtype == 0) { if (K == 10) FH_C0_WG(float, 10); else FH_C0_WG(float, MAXK); }
+    else if (dtype == 2) { if (K == 10) FH_C0_WG(f16, 10); else FH_C0_WG(f16, MAXK); }
+    else { if (K == 10) FH_C0_WG(bf16, 10); else FH_C0_WG(bf16, MAXK); }
 #undef FH_C0_WG
-  FH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv0_bwd_combine_kernel, dim3(B, (C0 + CBW - 1) / CBW), dim3(256), 0, st, (const float*)part, (const float*)wpart, w, gamma, mean,
+    FH_CHECK_LAUNCH();
+  } else if (K != 10) {
+    return -204;
+  }
+  const int ksplit = nblk >= 32 ? 8 : 1;
+  const int ns = K + K * K;
+  double* wsum = reinterpret_cast<double*>(ab);   // [B][ns] fp64 raw waveform sums: left there by the forward's statistics kernel (stats_ready)
+  if (!stats_ready) {
+    hipLaunchKernelGGL(conv0_wave_sums_kernel, dim3(B), dim3(512), 0, st, (const float*)part, wsum, a.nchunk, ns);
+    FH_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(conv0_bwd_combine_kernel, dim3(B, (C0 + CBW - 1) / CBW, ksplit), dim3(256), 0, st, (const double*)wsum, (const float*)wpart, w, gamma, mean,
                      rstd, dw, dgamma, dbeta, a.nchunk, nblk, C0, K, K == 10 ? 10 : MAXK, a.T0, grad_scale);
   FH_CHECK_LAUNCH();
   return 0;

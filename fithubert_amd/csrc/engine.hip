@@ -335,6 +335,14 @@ struct WsLayout {
   }
 };
 
+// conv 0's backward inside layer 1's data-gradient GEMM (fh_gemm_epilogue.c0_*): k = 1 layer 1 over 128 conv-0 channels, 10 taps, 16-bit;
+// FH_CONV0_FUSED_BWD=0 restores the two kernels (A/B)
+inline bool conv0_bwd_fusable(const fh_student_config& c) {
+  static const int on = [] { const char* e = getenv("FH_CONV0_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on && c.dtype != 0 && c.n_conv >= 2 && c.conv_k[1] == 1 && c.conv_stride[1] == 1 && c.conv_dim[0] == 128 && c.conv_k[0] <= 10 &&
+         256 * c.conv_stride[0] + 16 <= 2048 && c.feature_grad_mult > 0.f;
+}
+
 struct Plan {
   fh_student_config c;
   fh_student_call k;
@@ -368,7 +376,8 @@ struct Plan {
     }
     c0_mean = ws.add("c0_mean", {B, c.conv_dim[0]}, 4);
     c0_rstd = ws.add("c0_rstd", {B, c.conv_dim[0]}, 4);
-    c0_scratch = ws.add("c0_scratch", {fh_conv0_scratch_n((int)B, sh.T[0], c.conv_dim[0])}, 4);
+    c0_scratch = ws.add("c0_scratch", {tr && conv0_bwd_fusable(c) ? fh_conv0_fused_scratch_n((int)B, sh.T[0], c.conv_dim[0])
+                                                                  : fh_conv0_scratch_n((int)B, sh.T[0], c.conv_dim[0])}, 4);
     const long E = c.conv_dim[c.n_conv - 1];
     ln0 = ws.add("ln0", {Mp, E}, es);
     ln0_mean = ws.add("ln0_mean", {Mp}, 4);
@@ -1266,6 +1275,32 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     unsigned char* dst = x.W<unsigned char>(i - 1 >= 1 ? p.dz[i - 1] : p.dz[0]);
     const unsigned char* aux = i - 1 >= 1 ? x.W<unsigned char>(p.z[i - 1]) : nullptr;
     const void* wf = x.rel(p.wl.conv_wf[i]);
+    if (i == 1 && conv0_bwd_fusable(c)) {
+      // layer 1's data gradient IS d loss / d y0: its tiles are consumed in the GEMM's epilogue by conv 0's weight-gradient sums (one
+      // utterance per group, so that a 256-frame tile shares its GroupNorm statistics and waveform window); dz[0] is never written
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.W(p.dz[1]), FH_R_CONTIG, cout);
+      g.X.gstride = (long)Ti * cout;
+      g.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
+      g.C = nullptr;
+      g.M = Ti; g.N = cin; g.Kseg = cout; g.ldc = cin;
+      g.groups = B;
+      const long nchunk = fh_conv0_nchunk(s.T[0]);
+      g.ep.c0_wave = wave;
+      g.ep.c0_w = x.params + p.pl.conv_w[0];
+      g.ep.c0_gamma = x.params + p.pl.gn_w;
+      g.ep.c0_beta = x.params + p.pl.gn_b;
+      g.ep.c0_mean = x.W<float>(p.c0_mean);
+      g.ep.c0_rstd = x.W<float>(p.c0_rstd);
+      g.ep.c0_wpart = reinterpret_cast<float*>(x.W<float2>(p.c0_scratch) + (long)B * nchunk * c.conv_dim[0] + (long)B * fh_conv0_ab_width(c.conv_dim[0]));
+      g.ep.c0_S = s.S; g.ep.c0_K = c.conv_k[0]; g.ep.c0_stride = c.conv_stride[0];
+      RC(fh_gemm_launch(g, dt, x.st));
+      RC(fh_conv0_bwd_launch(dt, wave, x.params + p.pl.conv_w[0], x.params + p.pl.gn_w, x.params + p.pl.gn_b, nullptr,
+                             x.W<float>(p.c0_mean), x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch),
+                             x.W<float2>(p.c0_scratch) + (long)B * nchunk * c.conv_dim[0], grads + p.pl.conv_w[0], grads + p.pl.gn_w,
+                             grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st, 1, (int)nchunk));
+      return 0;
+    }
     if (kk == sd || (kk == 1 && sd == 1)) {
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);

@@ -34,6 +34,7 @@ static inline GemmEpilogue fh_epilogue() {
   e.out_f32 = 0; e.atomic = 0; e.idiv = 0; e.si1 = 0; e.si0 = 0; e.jdiv = 0; e.sj1 = 0; e.sj0 = 0; e.tail_cols = 0; e.aux_factor = 0;
   e.kd_teacher = nullptr; e.kd_tdtype = 1; e.kd_lstride = 0; e.kd_layer = nullptr; e.kd_w = nullptr; e.kd_Tt = 0; e.kd_P = 0; e.kd_type = 0;
   e.kd_grad_scale = 1.f; e.kd_count = 1.f; e.kd_partials = nullptr;
+  e.c0_wave = e.c0_w = e.c0_gamma = e.c0_beta = e.c0_mean = e.c0_rstd = nullptr; e.c0_wpart = nullptr; e.c0_S = e.c0_K = e.c0_stride = 0;
   return e;
 }
 static inline GemmParams fh_gemm_params() {

@@ -153,6 +153,7 @@ TuneChoice tune_measure(const GemmParams& p, int dtype, hipStream_t stream) {
 
 int launch_16(const GemmParams& p, int dtype, hipStream_t stream) {
   resolve_path();
+  if (p.ep.c0_wpart) return launch_path(p, 4, dtype, stream);   // the conv-0 weight-gradient epilogue lives in loop 4
   if (p.ep.kd_teacher) {   // the KD-loss epilogue is compiled into loops 7 and 4 (FH_KD_LOOP picks; default 4: two workgroups per CU, so one
     static int kd_loop = -1;   // workgroup's operand-bound epilogue runs under the other's K loop)
     if (kd_loop < 0) {
@@ -295,6 +296,12 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   if (p.ep.row_len && p.c_rpb <= 0) return -109;
   if ((p.X.segoff[0] | p.X.segoff[1] | p.Y.segoff[0] | p.Y.segoff[1] | p.X.gstride | p.Y.gstride) % vec) return -110;
   if (p.X.seg1_limit % 8 || p.Y.seg1_limit % 8 || p.ep.tail_cols % 8 || (p.ep.tail_cols > 0 && (p.c_rpb <= 0 || p.ep.atomic))) return -111;
+  if (p.ep.c0_wpart) {     // conv-0 weight-gradient epilogue: one utterance per group, 128 channels, 16-bit
+    if (dtype == 0 || p.N != 128 || p.ep.c0_K < 1 || p.ep.c0_K > 10 || p.ep.c0_stride < 1 || 256 * p.ep.c0_stride + 16 > 2048 || p.ep.atomic ||
+        p.ep.residual || p.ep.gelu_aux || p.ep.row_len || p.ep.kd_teacher || (p.splitk & 0xffff) > 1 || p.X.layout != FH_R_CONTIG ||
+        p.Y.layout != FH_R_STRIDED || !p.ep.c0_wave || !p.ep.c0_w || !p.ep.c0_gamma || !p.ep.c0_beta || !p.ep.c0_mean || !p.ep.c0_rstd)
+      return -114;
+  }
   if (p.ep.kd_teacher) {   // KD-loss epilogue: the forms that implement it
     const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
     if (p.c_rpb <= 0 || wrap0 != 0 || p.ep.kd_P <= 0 || p.ep.kd_P % 8 || p.N % p.ep.kd_P || p.ep.atomic || p.ep.residual || p.ep.gelu_aux ||

@@ -1246,11 +1246,100 @@ template <int ROWS, int BK_, int NW> struct RingLoader<FH_R_STRIDED, ROWS, BK_, 
   }
 };
 
+// ------------------------------------------------------------------ conv-0 weight-gradient epilogue (fh_gemm_epilogue.c0_*)
+// The accumulators of a 256-frame x 128-channel tile ARE d loss / d y0 of those frames (y0 = GELU(GroupNorm(conv0(wave))), layer 1 being
+// a k = 1 conv): instead of storing them (1.05 GB at B = 128) for a second kernel to read back, each lane turns its 8 frames x 16
+// channels into g = dy * GELU'(.), with conv0 + GroupNorm recomputed from the waveform window staged in LDS, and accumulates what
+// conv0_bwd_onepass_kernel accumulates: A_j = sum_t g x_j[t], S1 = sum g, S2 = sum g xhat.  Two channels at a time (their taps and 12 sums
+// in registers beside the 128 accumulators), the 16 frame-lanes of a channel reduced with four DPP adds, the two row-waves through LDS.
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a row (every lane receives it)
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1, 0, 3, 2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2, 3, 0, 1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+template <typename H, int NT, int MT>
+__device__ __forceinline__ void conv0_wgrad_epilogue(const GemmParams& p, const f32x4 (&acc)[NT][MT], unsigned char* lds, int i0, int xi0,
+                                                     int yj0, int lane, int wave_row, int b, int ti, int ntile) {
+  constexpr int KT = 10, PER = KT + 2;
+  const GemmEpilogue& ep = p.ep;
+  const int stride = ep.c0_stride, K = ep.c0_K, C0 = p.N;
+  float* sw = reinterpret_cast<float*>(lds);       // the tile's waveform window: 256 * stride + K samples (zero past the utterance)
+  float* red = sw + 2048;                          // [2 row-waves][C0][PER]
+  float* wl = red + 2 * 128 * PER;                 // conv-0 taps [C0][KT] (zero past K)
+  float* stl = wl + 128 * KT;                      // per channel: mean, rstd of this utterance, gamma, beta
+  {
+    const long s0 = (long)i0 * stride;
+    const float* src = ep.c0_wave + (long)b * ep.c0_S;
+    const int n = 256 * stride + 16;
+    for (int i = threadIdx.x; i < n && i < 2048; i += blockDim.x) sw[i] = s0 + i < ep.c0_S ? src[s0 + i] : 0.f;
+    for (int i = threadIdx.x; i < C0 * KT; i += blockDim.x) {
+      const int c = i / KT, j = i - c * KT;
+      wl[i] = j < K ? ep.c0_w[c * K + j] : 0.f;
+    }
+    for (int c = threadIdx.x; c < C0; c += blockDim.x) {
+      stl[4 * c] = ep.c0_mean[b * C0 + c];
+      stl[4 * c + 1] = ep.c0_rstd[b * C0 + c];
+      stl[4 * c + 2] = ep.c0_gamma[c];
+      stl[4 * c + 3] = ep.c0_beta[c];
+    }
+  }
+  __syncthreads();
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int c0 = yj0 + 16 * n + 4 * q + 2 * half;
+      float w[2][KT], mu[2], rs[2], ga[2], be[2], a12[2][PER];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = c0 + e;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) w[e][j] = wl[c * KT + j];
+        mu[e] = stl[4 * c]; rs[e] = stl[4 * c + 1]; ga[e] = stl[4 * c + 2]; be[e] = stl[4 * c + 3];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) a12[e][j] = 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float* x = sw + (xi0 + 16 * m + r) * stride;
+        float xs[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) xs[j] = x[j];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float v = 0.f;
+#pragma unroll
+          for (int j = 0; j < KT; ++j) v = fmaf(w[e][j], xs[j], v);
+          const float xh = (v - mu[e]) * rs[e];
+          const float gq = acc[n][m][2 * half + e] * gelu_grad_t<H>(fmaf(xh, ga[e], be[e]));
+          a12[e][KT] += gq;
+          a12[e][KT + 1] = fmaf(gq, xh, a12[e][KT + 1]);
+#pragma unroll
+          for (int j = 0; j < KT; ++j) a12[e][j] = fmaf(gq, xs[j], a12[e][j]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          const float t = row16_sum(a12[e][j]);
+          if (r == 0) red[(wave_row * C0 + c0 + e) * PER + j] = t;
+        }
+    }
+  }
+  __syncthreads();
+  float* out = ep.c0_wpart + ((long)b * ntile + ti) * C0 * PER;
+  for (int i = threadIdx.x; i < C0 * PER; i += blockDim.x) out[i] = red[i] + red[C0 * PER + i];
+}
+
 template <int N> __device__ __forceinline__ void wait_vm_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <typename H, int XL, int YL, int BM_, int BN_, int WM, int WN, int BK_, int NST, bool KD = false>
+template <typename H, int XL, int YL, int BM_, int BN_, int WM, int WN, int BK_, int NST, bool KD = false, bool C0B = false>
 // (the 4-wave build is meant to run TWO workgroups per CU: without the second launch-bound argument the compiler took 364 registers
 // per wave -- 236 + 128 accumulators -- and one workgroup was all a CU could hold)
 __global__ void __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) gemm_ring_kernel(const GemmParams p) {
@@ -1358,6 +1447,11 @@ __global__ void __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) gemm_ring_k
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero-chunk) tail loads before LDS is reused
   __syncthreads();                                   // every wave is done reading the ring
+  if constexpr (C0B) {   // the tile is consumed, not stored: conv-0 weight-gradient sums of its 256 frames
+    static_assert(!C0B || (BM_ == 256 && BN_ == 128 && WM == 2 && TN == 64), "one column tile of 128 channels, two row-waves");
+    conv0_wgrad_epilogue<H, NT, MT>(p, acc, lds, i0, xi0, yj0, lane, wave % WM, g, ti, (p.M + BM_ - 1) / BM_);
+    return;
+  }
   // staged epilogue, wave-local from here on (each wave owns its staging rows): passes of 32 rows x 64 columns
   unsigned char* my = lds + wave * EPI_WAVE;
   const int r = lane & 15, q = lane >> 4;
@@ -2356,7 +2450,7 @@ template <typename H> int launch_8ph(const GemmParams& p, hipStream_t stream) {
 // launches loop 8 can take: the bf16-staged epilogue without per-row operands, one reduction split
 bool stream_ok(const GemmParams& p) {
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
-  return !p.ep.atomic && !p.ep.gelu_aux && !p.ep.residual && !p.ep.row_len && !p.ep.out_f32 && !p.ep.tail_cols && !p.ep.kd_teacher &&
+  return !p.ep.atomic && !p.ep.gelu_aux && !p.ep.residual && !p.ep.row_len && !p.ep.out_f32 && !p.ep.tail_cols && !p.ep.kd_teacher && !p.ep.c0_wpart &&
          (p.c_rpb <= 0 || wrap0 == 0) && (p.splitk & 0xffff) <= 1;
 }
 template <typename H> int launch_8ph_stream(const GemmParams& p, hipStream_t stream) {
@@ -2403,6 +2497,21 @@ template <typename H, int BM_, int BN_, int WM, int WN, int BK_, int NST> int la
     attr_set = true;
   }
   const int xl = p.X.layout, yl = p.Y.layout;
+  if (p.ep.c0_wpart) {   // conv-0 weight-gradient epilogue: its own instance of the 4-wave 256 x 128 build (X contiguous, Y strided)
+    if constexpr (BM_ == 256 && BN_ == 128 && WM == 2 && WN == 2) {
+      if (xl != FH_R_CONTIG || yl != FH_R_STRIDED) return -113;
+      static bool c0_attr = false;
+      if (!c0_attr) {
+        hipFuncSetAttribute((const void*)gemm_ring_kernel<H, FH_R_CONTIG, FH_R_STRIDED, BM_, BN_, WM, WN, BK_, NST, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        c0_attr = true;
+      }
+      hipLaunchKernelGGL((gemm_ring_kernel<H, FH_R_CONTIG, FH_R_STRIDED, BM_, BN_, WM, WN, BK_, NST, false, true>), grid, block, smem, stream, p);
+      FH_CHECK_LAUNCH();
+      return 0;
+    } else {
+      return -113;
+    }
+  }
   if (p.ep.kd_teacher) {   // KD-loss epilogue: its own instance
     if (xl != FH_R_CONTIG || yl != FH_R_CONTIG) return -113;
     static bool kd_attr = false;
