@@ -50,10 +50,10 @@ int qoct(long v) {
   while ((v >> (lg + 1)) > 0) ++lg;
   return 100000 + lg * 4 + (int)(((v - (1L << lg)) * 4) >> lg);
 }
-unsigned long long tune_key(const GemmParams& p, int dtype, unsigned mask = 0u) {
+unsigned long long tune_key_q(const GemmParams& p, int dtype, unsigned mask, int qm, int qk) {
   unsigned long long h = 1469598103934665603ULL;
   auto mix = [&](long v) { h = (h ^ (unsigned long long)v) * 1099511628211ULL; };
-  mix(qoct(p.M)); mix(qoct(p.N)); mix(qoct(p.Kseg)); mix(p.X.nseg); mix(p.X.layout); mix(p.Y.layout); mix(p.groups);
+  mix(qm); mix(qoct(p.N)); mix(qk); mix(p.X.nseg); mix(p.X.layout); mix(p.Y.layout); mix(p.groups);
   mix(p.ep.atomic); mix(p.ep.atomic ? 0 : p.splitk);
   mix(p.ep.preact != nullptr); mix(p.ep.act); mix(p.ep.gelu_aux != nullptr); mix(p.ep.residual != nullptr);
   if (p.ep.aux_factor) mix(104729);
@@ -61,6 +61,27 @@ unsigned long long tune_key(const GemmParams& p, int dtype, unsigned mask = 0u) 
   if (dtype == 2) mix(15485863);  // f16 launches keep their own measurements
   if (mask) mix(0x5bd1e995L + mask);  // ... and so do launches of a stream with a restricted set of loops
   return h;
+}
+unsigned long long tune_key(const GemmParams& p, int dtype, unsigned mask = 0u) {
+  return tune_key_q(p, dtype, mask, qoct(p.M), qoct(p.Kseg));
+}
+// A launch whose own shape class was never measured takes the choice of the nearest measured class that differs only in the long
+// dimension(s) (rows for the forward / data-gradient launches, the reduction for the weight gradients): StudentEngine.autotune keys
+// its passes on the utterance length's quarter octave, while every conv layer's row count crosses ITS quarter-octave boundaries at
+// other lengths -- a length-bucketed epoch (445 bucket shapes in train-clean-100) would otherwise drop such launches to the
+// 128-tile fallback (B = 64 x 15.4 s: 51 ms instead of 41).  A loop that cannot take the launch falls through to loop 2 in launch_path.
+const TuneChoice* tune_neighbour(const GemmParams& p, int dtype, unsigned mask) {
+  const int qm = qoct(p.M), qk = qoct(p.Kseg);
+  const bool vm = p.M > 4096, vk = p.Kseg > 4096;
+  if (!vm && !vk) return nullptr;
+  for (int d = 1; d <= 12; ++d)   // three octaves either way, nearest first
+    for (int dm = vm ? -d : 0; dm <= (vm ? d : 0); ++dm)
+      for (int dk = vk ? -d : 0; dk <= (vk ? d : 0); ++dk) {
+        if ((dm < 0 ? -dm : dm) != d && (dk < 0 ? -dk : dk) != d) continue;
+        auto it = g_tune.find(tune_key_q(p, dtype, mask, qm + dm, qk + dk));
+        if (it != g_tune.end()) return &it->second;
+      }
+  return nullptr;
 }
 int ring_splitk(const GemmParams& p, int tm, int tn, int target) {
   const long tiles = (long)((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn) * p.groups;
@@ -166,8 +187,19 @@ int launch_16(const GemmParams& p, int dtype, hipStream_t stream) {
   const unsigned long long key = tune_key(p, dtype, stream_mask(stream));
   auto it = g_tune.find(key);
   if (it == g_tune.end()) {
-    if (!g_tune_mode) return launch_path(p, 2, dtype, stream);
-    it = g_tune.emplace(key, tune_measure(p, dtype, stream)).first;
+    if (!g_tune_mode) {
+      const TuneChoice* nb = tune_neighbour(p, dtype, stream_mask(stream));
+      if (!nb) return launch_path(p, 2, dtype, stream);
+      TuneChoice c = *nb;
+      if (p.ep.atomic) {   // a split count measured on a longer reduction: keep every split at least 512 deep, as the candidates are
+        const long red = (long)p.Kseg * p.X.nseg;
+        const int cap = (int)(red / 512 > 0 ? red / 512 : 1), sk = c.splitk & (FH_SPLIT_REMAP - 1);
+        if (sk > cap) c.splitk = cap | (c.splitk & FH_SPLIT_REMAP);
+      }
+      it = g_tune.emplace(key, c).first;   // (remembered: the search runs once per class)
+    } else {
+      it = g_tune.emplace(key, tune_measure(p, dtype, stream)).first;
+    }
   }
   GemmParams q = p;
   if (p.ep.atomic) q.splitk = it->second.splitk;

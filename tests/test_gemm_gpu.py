@@ -611,3 +611,67 @@ def test_saved_gelu_derivative_forward_and_backward(loop):
     assert (sav.double() - gp).abs().max().item() <= 1e-2            # |GELU'| <= 1.13, bf16 storage
     ref = (dY.double() @ W.double().t()) * sav.double()              # exactly the stored factor
     assert (dz.double() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+
+
+def test_untuned_shape_class_takes_the_nearest_measured_one(tmp_path):
+    """A launch whose quarter-octave class (tune_key, gemm.hip) was never measured takes the choice of the nearest measured class that
+    differs only in the long dimension -- not the 128-tile fallback: M = 64 x 731 rows measured, M = 64 x 768 (the next class) launched
+    without tuning; the weight-gradient form (long reduction, atomic) likewise.  Results against fp64."""
+    dev = "cuda"
+    lib = L.lib()
+    saved = str(tmp_path / "table.json")
+    L.save_gemm_table(saved)
+    lib.fh_gemm_tune(-1)
+    torch.manual_seed(0)
+    N, K = 480, 480
+
+    def fwd(M, tune):
+        X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        d = L.GemmDesc()
+        d.X, d.Y, d.C = L.operand(X.data_ptr(), 0, K), L.operand(W.data_ptr(), 0, K), out.data_ptr()
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+        d.ep = L.epilogue()
+        lib.fh_gemm_tune(1 if tune else 0)
+        try:
+            _run(d, L.DT_BF16)
+        finally:
+            lib.fh_gemm_tune(0)
+        _run(d, L.DT_BF16)
+        ref = X.double() @ W.double().t()
+        assert (out.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+        return lib.fh_gemm_last_loop()
+
+    def wgrad(R, tune):
+        A = torch.randn(R, N, device=dev).to(torch.bfloat16)      # dY [R][N]
+        Bm = torch.randn(R, K, device=dev).to(torch.bfloat16)     # X  [R][K]
+        out = torch.zeros(N, K, device=dev, dtype=torch.float32)
+        d = L.GemmDesc()
+        d.X, d.Y, d.C = L.operand(A.data_ptr(), 1, N), L.operand(Bm.data_ptr(), 1, K), out.data_ptr()
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = N, K, R, K, 1, 8
+        d.ep = L.epilogue(atomic=1)
+        lib.fh_gemm_tune(1 if tune else 0)
+        try:
+            _run(d, L.DT_BF16)
+        finally:
+            lib.fh_gemm_tune(0)
+        out.zero_()
+        _run(d, L.DT_BF16)
+        ref = A.double().t() @ Bm.double()
+        assert (out.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+        return lib.fh_gemm_last_loop()
+
+    try:
+        assert fwd(64 * 768, tune=False) == 2                 # empty table: the fallback loop
+        lib.fh_gemm_tune(-1)
+        tuned = fwd(64 * 731, tune=True)
+        assert tuned != 2
+        assert fwd(64 * 768, tune=False) == tuned             # the neighbouring class's measurement
+        tw = wgrad(64 * 731, tune=True)
+        assert tw != 2
+        assert wgrad(64 * 768, tune=False) == tw
+        assert wgrad(64 * 300, tune=False) == tw              # an octave away, split count capped by the shorter reduction
+    finally:
+        lib.fh_gemm_tune(-1)
+        L.load_gemm_table(saved)
