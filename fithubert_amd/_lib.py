@@ -107,6 +107,11 @@ class StudentKdC(C.Structure):
                 ("out_losses", C.c_void_p)]
 
 
+class TeacherLayerC(C.Structure):
+    """fh_teacher_layer (include/fithubert_hip.h): device pointers of one teacher layer's weights"""
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "c1", "w2", "c2", "g2", "b2")]
+
+
 class StudentCallC(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("training", C.c_int), ("heads_on", C.c_int), ("seed", C.c_uint32)]
 
@@ -174,6 +179,8 @@ SIGNATURES = {
     "fh_conv1d_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fh_linear_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fh_conv0_layernorm_gelu_forward": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fh_teacher_encoder_scratch_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "fh_teacher_encoder_forward": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "fh_posconv_wide_prepare": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fh_posconv_wide_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fh_cast": (_I, [_I, _P, _P, _L, _P]),

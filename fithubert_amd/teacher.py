@@ -172,6 +172,8 @@ class _NativeFrontend:
         self.mode = fe.mode
         self._tuned = set()
         self._f32_cache = {}
+        self._stream = None          # stream handle pinned by TeacherModel.run for one forward
+        self._layer_table = None     # fh_teacher_layer[] of the transformer layers (built on first use)
         self.layers = []
         for i, (dim, k, s) in enumerate(self.spec):
             conv = getattr(fe.conv_layers[i], "0")
@@ -225,7 +227,31 @@ class _NativeFrontend:
                     g2=f32(lyr.final_layer_norm.weight), b2=f32(lyr.final_layer_norm.bias)))
 
     def _st(self):
-        return torch.cuda.current_stream(self.dev).cuda_stream
+        # (TeacherModel.run pins the stream handle for the duration of one forward: ~100 launches, and torch.cuda.current_stream
+        # costs 4 us a call -- at the reference's batch of 3 the host is the bottleneck)
+        return self._stream if self._stream is not None else torch.cuda.current_stream(self.dev).cuda_stream
+
+    def encoder(self, x: torch.Tensor, key_len, hidden: torch.Tensor, want_fc2: bool, qkv_last: Optional[torch.Tensor]):
+        """All transformer layers in one library call (fh_teacher_encoder_forward): x [B][T][D] -> hidden [L][B][T][D] (+ every
+        layer's fc2 output, + the last layer's q|k|v projections when asked for)."""
+        B, T, D = x.shape
+        Fd = self.tl[0]["w1"].shape[0]
+        if self._layer_table is None:
+            arr = (self.L.TeacherLayerC * len(self.tl))()
+            for i, w in enumerate(self.tl):
+                for name, key in (("wqkv", "wqkv"), ("bqkv", "bqkv32"), ("wo", "wo"), ("bo", "bo32"), ("g1", "g1"), ("b1", "b1"),
+                                  ("w1", "w1"), ("c1", "c1"), ("w2", "w2"), ("c2", "c232"), ("g2", "g2"), ("b2", "b2")):
+                    t = w[key]
+                    assert t.is_contiguous() and t.dtype == (torch.float32 if key in ("bqkv32", "bo32", "g1", "b1", "c1", "c232", "g2", "b2") else self.tdt)
+                    setattr(arr[i], name, t.data_ptr())
+            self._layer_table = arr
+        fc2 = torch.empty_like(hidden) if want_fc2 else None
+        scratch = torch.empty(self.lib.fh_teacher_encoder_scratch_bytes(self.dt, B, T, D, Fd), device=self.dev, dtype=torch.uint8)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        self.L.check(self.lib.fh_teacher_encoder_forward(self.dt, self._layer_table, len(self.tl), 1 if self.pre_ln else 0, x.data_ptr(),
+                                                         hidden.data_ptr(), ptr(fc2), ptr(qkv_last), ptr(key_len), B, T, D, Fd, self.heads,
+                                                         scratch.data_ptr(), self._st()), "fh_teacher_encoder_forward")
+        return fc2
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, b32: torch.Tensor, gelu: bool = False,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, preact: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -458,6 +484,15 @@ class TeacherModel(nn.Module):
                     return self.run(source, padding_mask, want_fc2, lengths)
                 finally:
                     native.lib.fh_gemm_tune(0)
+            native._stream = torch.cuda.current_stream(source.device).cuda_stream
+            try:
+                return self._forward_impl(native, source, padding_mask, want_fc2, lengths, dt)
+            finally:
+                native._stream = None
+        return self._forward_impl(None, source, padding_mask, want_fc2, lengths, dt)
+
+    def _forward_impl(self, native, source, padding_mask, want_fc2, lengths, dt):
+        if native is not None:
             x = native.features(self, source)
         else:
             x = self.feature_extractor(source.to(dt)).transpose(1, 2)
@@ -502,6 +537,13 @@ class TeacherModel(nn.Module):
             # right-padded batches (what dataset.collate produces): the key mask is a per-utterance valid-frame count
             key_len = None if fm is None else (~fm).sum(-1).to(torch.int32)
             x = x.contiguous()
+            if native.linear_native and native.fc1_native and os.environ.get("FH_TEACHER_ENCODER", "native") == "native":
+                # every layer in one library call (the host does not walk the layers)
+                qkv_last = torch.empty(B, T, 3 * x.shape[-1], device=x.device, dtype=dt) if self.return_attn else None
+                fc2s = native.encoder(x, key_len, hidden, want_fc2, qkv_last)
+                if self.return_attn:
+                    self.last_qkv = qkv_last
+                return hidden, post, (list(fc2s.unbind(0)) if want_fc2 else None)
             for i in range(L):
                 if self.return_attn and i == L - 1:
                     stash_qkv(self.encoder.layers[i], x)

@@ -443,6 +443,28 @@ int fh_posconv_wide_prepare(int dtype, const float* g, const float* v, void* w_f
 int fh_posconv_wide_forward(int dtype, const void* x, const void* w_fwd, const float* bias, void* y, int B, int T, int D,
                             int groups, int K, fh_stream_t stream);
 
+/* The teacher's transformer layers in ONE call (fairseq TransformerSentenceEncoderLayer x n_layers as loaded at
+ * utils/utils.py:102-149; the per-layer outputs are what the reference's forward hooks capture, utils/utils.py:61-99).
+ *   layers   : host array of n_layers weight tables (device pointers; W* in `dtype`, biases / LayerNorm parameters fp32);
+ *              wqkv = rows of q_proj | k_proj | v_proj stacked ([3D][D]), g1 / b1 = self_attn_layer_norm, g2 / b2 = final_layer_norm
+ *   pre_ln   : 0 = post-LN (layer_norm_first False: HuBERT / wav2vec 2.0 Base), 1 = pre-LN (HuBERT Large)
+ *   x        : [B][T][D] input of layer 0 (after the positional conv and, post-LN, the encoder LayerNorm)
+ *   hidden   : [n_layers][B][T][D] <- every layer's output            fc2_out : same shape, every layer's fc2 output (the hook's
+ *              second value), or NULL       qkv_last : [B][T][3D] <- the LAST layer's q|k|v projections (utils/utils.py:244-263), or NULL
+ *   key_len  : int32 [B] valid frames of a right-padded batch, or NULL     scratch : fh_teacher_encoder_scratch_bytes(...) bytes */
+typedef struct fh_teacher_layer {
+  const void* wqkv; const float* bqkv;
+  const void* wo;   const float* bo;
+  const float* g1;  const float* b1;
+  const void* w1;   const float* c1;
+  const void* w2;   const float* c2;
+  const float* g2;  const float* b2;
+} fh_teacher_layer;
+long fh_teacher_encoder_scratch_bytes(int dtype, int B, int T, int D, int F);
+int fh_teacher_encoder_forward(int dtype, const fh_teacher_layer* layers, int n_layers, int pre_ln, const void* x, void* hidden,
+                               void* fc2_out, void* qkv_last, const int* key_len, int B, int T, int D, int F, int heads,
+                               void* scratch, fh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
