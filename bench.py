@@ -83,7 +83,8 @@ CLASS_NOTE = {
 def classify(r) -> str:
     if r["atomic"]:
         return "weight_gradients"
-    big = r["M"] >= 100000
+    # (conv layer 1's data gradient is launched per utterance -- groups = B, M = T0 rows each -- since it carries conv 0's weight-gradient sums)
+    big = r["M"] >= 100000 or (r["groups"] > 1 and r["M"] * r["groups"] >= 1000000)
     if r["tag"] == 1:
         return "teacher_conv" if big else "teacher_linear"
     if big:
