@@ -172,6 +172,9 @@ class W2V2Distil:
             # for the length of a launch) leaves one CU per XCD to them
             from . import _lib as _L
             _L.lib().fh_gemm_reserve_cus(8)
+        if os.environ.get("FH_RESERVE_CUS") and self.device.type == "cuda":   # A/B: CUs the persistent GEMM loop leaves to other kernels
+            from . import _lib as _L
+            _L.lib().fh_gemm_reserve_cus(int(os.environ["FH_RESERVE_CUS"]))
         broadcast_parameters(self.engine.params)
         self.student_model.mark_params_updated()
         self._micro = 0
