@@ -123,7 +123,10 @@ class W2V2Distil:
         if t.get("delete_projections"):
             self.student_model._disable_projection_heads()
         if t.get("specaug"):
-            raise NotImplementedError("specaug applies to the mel branch only, which is out of scope")
+            # train.py:83-86 builds SpecAug(**yaml['specaug']) and hands it to the student, whose forward applies it on the mel-spectrogram
+            # branch only (modules/model.py:436-441); with n_mels <= 0 (every shipped config) it is attached and never used -- same here
+            # (the mel branch itself is out of scope and rejected by the config check)
+            self.student_model.add_specaug(dict(self.yaml_cfg.get("specaug") or {}))
         self.num_encoders = self.model_cfg["encoder_layers"]
         # The reference samples rand_l with the unseeded global RNG of each DDP process (train.py:91,174).  Here the stream is
         # seeded and IDENTICAL on every rank on purpose: the per-layer loss weights must agree across ranks or the all-reduced

@@ -179,7 +179,9 @@ class CustomStudentModel(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def add_specaug(self, specaug):
-        raise NotImplementedError("SpecAugment applies to the mel-spectrogram branch only (model.py:439-441), which is out of scope")
+        """modules/model.py:373-374: stored; the forward applies it on the mel-spectrogram branch only (model.py:436-441), which this
+        build does not have (n_mels > 0 is rejected at construction), so for the waveform frontend it is inert -- as in the reference."""
+        self.specaug = specaug
 
     def _get_feat_extract_output_lengths(self, input_lengths: torch.LongTensor):
         """modules/model.py:376-391."""

@@ -289,6 +289,22 @@ def test_dump_yaml_writes_the_effective_config(tmp_path):
     assert t.yaml_cfg["distiller"] == src["distiller"]                     # the task's own dict is left alone
 
 
+def test_specaug_flag_attaches_the_settings_and_is_inert_without_a_mel_branch():
+    """train.py:83-86: `train.specaug: True` builds SpecAug(**yaml['specaug']) and hands it to the student, whose forward applies it
+    on the mel-spectrogram branch only (modules/model.py:436-441); with n_mels = 0 it is attached and never used."""
+    from fithubert_amd.distill import W2V2Distil
+    y = _cfg(1)
+    y["train"]["specaug"] = True
+    st = StubStudent()
+    got = {}
+    st.add_specaug = lambda sa: got.update(sa=sa)
+    t = W2V2Distil(y, dtype="float32", device="cpu", teacher=StubTeacher(), seed=0, student_model=st)
+    assert got["sa"] == dict(y.get("specaug") or {})
+    t.configure_optimizers(num_training_steps=10)
+    out = t.training_step({"x": torch.randn(2, 64), "padding_mask": torch.zeros(2, 64, dtype=torch.bool), "_lengths": [64, 64]}, batch_idx=0)
+    assert out is not None and t.opt_step == 1          # the step ran to the optimizer with the flag set
+
+
 def test_bench_gpus_n_without_launcher_refuses_cleanly_when_devices_are_missing():
     if torch.cuda.device_count() >= 2:
         pytest.skip("two devices present")
