@@ -2534,165 +2534,6 @@ template <typename H, int BM_, int BN_, int WM, int WN, int BK_, int NST> int la
   FH_CHECK_LAUNCH();
   return 0;
 }
-// ------------------------------------------------------------------ loop 10: 4 waves, 128 x 128 per wave (R_CONTIG x R_CONTIG)
-// One wave per SIMD with the whole 512-register file: 256 accumulator registers (AGPRs -- the MFMAs are issued from inline asm with the
-// accumulator as a tied "+a" operand: through the builtin, LLVM gives the result a different register than the addend under this
-// pressure and moves every accumulator twice per MFMA), two sets of fragment registers (128 VGPRs).  Per 32-deep K-tile the four waves
-// read 4 x 16 KiB of fragments where the 2 x 4 arrangement of loops 3 / 5 / 7 / 8 reads 8 x 12 .. 14 KiB per 32 of depth -- the LDS
-// port, not the matrix pipe, bounds those K loops --, and nothing waits on LDS latency in steady state: while the
-// 64 MFMAs of tile t run on fragment set t & 1, the wave reads tile t + 1's fragments into the other set (that tile has landed in
-// every wave: it was waited for in front of the barrier that opened tile t) and issues the LDS-DMA of tile t + 4 into the stage tile
-// t - 1 left.  Five 32-KiB stages (BK = 32): tile t in registers, t + 1 being read, t + 2 and t + 3 in flight, t + 4 being issued.
-template <typename H> __device__ __forceinline__ void mfma16_tied(f32x4& c, const bf16x8& a, const bf16x8& b) {
-  if constexpr (ElemTraits<H>::DT == 2)
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-template <typename H>
-__global__ void __launch_bounds__(256, 1) gemm_4w_kernel(const GemmParams p) {
-  constexpr int NST = 5, BK_ = 32, MT = 8, NT = 8;
-  typedef RingLoader<FH_R_CONTIG, 256, BK_, 4> LX;
-  typedef RingLoader<FH_R_CONTIG, 256, BK_, 4> LY;
-  constexpr int STAGE = LX::TILE + LY::TILE;   // 32 KiB
-  constexpr int LPT = LX::NI + LY::NI;         // 8 LDS-DMA instructions per lane and K-tile
-  static_assert(NST * STAGE >= 4 * EPI_WAVE, "ring smaller than the epilogue staging area");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.z;
-  const int tiles_j = (p.N + 255) / 256;
-  const LogicalBlock lblk = logical_block(p.splitk);
-  int ti, tj;
-  tile_coords(lblk.lb, (p.M + 255) / 256, tiles_j, p.Kseg * p.X.nseg, ti, tj);
-  const int i0 = ti * 256, j0 = tj * 256;
-  const int tiles_per_seg = (p.Kseg + BK_ - 1) / BK_;
-  const int ntiles = tiles_per_seg * tile_nseg(p, j0);
-  const int per_split = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int t0 = lblk.split * per_split;
-  const int t1 = min(ntiles, t0 + per_split);
-  if (t0 >= t1) return;
-  const int nt = t1 - t0;
-
-  LX lx;
-  LY ly;
-  lx.init(p.X, g, i0, p.M, tid);
-  ly.init(p.Y, g, j0, p.N, tid);
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int xi0 = (wave & 1) * 128, yj0 = (wave >> 1) * 128;
-
-  int is_seg = t0 / tiles_per_seg;
-  int is_k0 = (t0 - is_seg * tiles_per_seg) * BK_;
-  int issued = 0;
-  bool need_slow = true;
-  auto advance = [&]() {   // the loaders' pointers -> K-tile `issued` (zero chunks past the end keep the vmcnt bookkeeping uniform)
-    if (issued == nt) {
-      lx.set_zero();
-      ly.set_zero();
-    } else if (issued < nt) {
-      const bool partial = is_k0 + BK_ > p.Kseg;
-      if (need_slow || partial) {
-        lx.set_tile(p.X, is_seg, is_k0, p.Kseg);
-        ly.set_tile(p.Y, is_seg, is_k0, p.Kseg);
-      }
-      is_k0 += BK_;
-      need_slow = false;
-      if (is_k0 >= p.Kseg) {
-        is_k0 = 0;
-        is_seg = min(is_seg + 1, 1);
-        need_slow = true;
-      }
-    }
-    ++issued;
-  };
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s) {   // tiles 0 .. 3 as a burst
-    advance();
-    lx.issue(lds + s * STAGE);
-    ly.issue(lds + s * STAGE + LX::TILE);
-  }
-  bf16x8 fx[2][MT], fy[2][NT];
-  auto read_frags = [&](int stage, auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    const unsigned char* bx = lds + stage * STAGE;
-    const unsigned char* by = bx + LX::TILE;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) fy[SET][n] = LY::frag(by, yj0 + 16 * n, 0, lane);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) fx[SET][m] = LX::frag(bx, xi0 + 16 * m, 0, lane);
-  };
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPT) : "memory");   // tiles 0 and 1 have landed in every wave
-  read_frags(0, std::integral_constant<int, 0>{});
-  int st_read = 1, st_dma = NST - 1;   // stage of tile it + 1 / of tile it + 4
-  auto step = [&](int it, auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    advance();
-    unsigned char* dst = lds + st_dma * STAGE;
-    const unsigned char* nbx = lds + st_read * STAGE;
-    const unsigned char* nby = nbx + LX::TILE;
-    const bool more = it + 1 < nt;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int n = 0; n < NT; ++n) mfma16_tied<H>(acc[n][m], fy[SET][n], fx[SET][m]);
-      // behind every group of eight MFMAs: one LDS-DMA instruction of tile it + 4 and two fragment reads of tile it + 1 (issued in
-      // FRONT of the MFMAs they would draw an lgkmcnt(0) before the first one: the compiler cannot count across the asm statements)
-      if (m < LX::NI) lx.issue_one(dst, m);
-      else ly.issue_one(dst + LX::TILE, m - LX::NI);
-      if (more) {
-        fy[SET ^ 1][m] = LY::frag(nby, yj0 + 16 * m, 0, lane);
-        fx[SET ^ 1][m] = LX::frag(nbx, xi0 + 16 * m, 0, lane);
-      }
-    }
-    // tile it + 2 has landed in this wave (it + 3 and it + 4 may be in flight) ... and, behind the barrier, in every wave; every wave
-    // is also done with tile it's stage (its fragment reads returned before its MFMAs could issue)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPT) : "memory");
-    st_read = st_read == NST - 1 ? 0 : st_read + 1;
-    st_dma = st_dma == NST - 1 ? 0 : st_dma + 1;
-  };
-  int it = 0;
-  for (; it + 1 < nt; it += 2) {
-    step(it, std::integral_constant<int, 0>{});
-    step(it + 1, std::integral_constant<int, 1>{});
-  }
-  if (it < nt) step(it, std::integral_constant<int, 0>{});
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain the (zero-chunk) tail loads before LDS is reused
-  __syncthreads();
-  // staged epilogue, wave-local from here on: passes of 32 rows x 64 columns (as the ring loops)
-  unsigned char* my = lds + wave * EPI_WAVE;
-  const int r = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    if (epilogue_bf16<H, MT, false>(p, acc, cb * 4, my, i0, j0, xi0, yj0 + 64 * cb, lane, g)) continue;
-    float bv[8];
-    epilogue_bias(p, j0, yj0 + 64 * cb, lane, g, bv);
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-#pragma unroll
-      for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-          *reinterpret_cast<f32x4*>(my + (mm * 16 + r) * EPI_ROW + (n * 16 + 4 * q) * 4) = acc[cb * 4 + n][2 * h + mm];
-      epilogue_readback<H>(p, my, h, i0, j0, xi0, yj0 + 64 * cb, lane, g, bv);
-    }
-  }
-}
-template <typename H> int launch_4w(const GemmParams& p, hipStream_t stream) {
-  const int tiles_i = (p.M + 255) / 256, tiles_j = (p.N + 255) / 256;
-  dim3 grid(tiles_i * tiles_j, p.splitk & 0xffff, p.groups), block(256);
-  const size_t smem = (size_t)5 * 512 * 32 * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_4w_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_4w_kernel<H>), grid, block, smem, stream, p);
-  FH_CHECK_LAUNCH();
-  return 0;
-}
 bool ring_ok(const GemmParams& p, int bk) {
   if (p.X.layout == FH_R_STRIDED && p.X.rpb > 0 && p.X.rpb < bk) return false;
   if (p.Y.layout == FH_R_STRIDED && p.Y.rpb > 0 && p.Y.rpb < bk) return false;
@@ -2714,10 +2555,6 @@ template <typename H> int launch_path_h(const GemmParams& p, int path, hipStream
   if (path == 6 && ring_ok(p, 32)) return launch_pp<H>(p, stream);
   if (path == 7 && ring_ok(p, 64)) return launch_8ph<H>(p, stream);
   if (path == 8 && ring_ok(p, 64) && stream_ok(p)) { fh_g_last_loop = 8; return launch_8ph_stream<H>(p, stream); }
-  if (path == 10 && p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG && !p.ep.kd_teacher && !p.ep.c0_wpart) {
-    fh_g_last_loop = 10;
-    return launch_4w<H>(p, stream);
-  }
   return launch_32<H>(p, stream);
 }
 

@@ -24,15 +24,9 @@ for name, M, N, K in (("q|k|v", 63872, 2304, 768), ("out-proj", 63872, 768, 768)
     d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
     d.ep = L.epilogue(bias=b.data_ptr())
     res = {}
-    for path in (7, 8, 10):
+    for path in (7, 8):
         lib.fh_gemm_set_path(path)
         res[path] = timeit(lambda: L.check(lib.fh_gemm(d, 1, st()), "gemm"))
     lib.fh_gemm_set_path(9)
     fl = 2.0 * M * N * K
-    print(f"{name:12s} {M}x{N}x{K}: hipBLASLt {t_lt:6.1f} us ({fl/t_lt/1e6:5.0f} TF/s)   loop 7 {res[7]:6.1f}   loop 8 {res[8]:6.1f} us ({fl/res[8]/1e6:5.0f} TF/s)   loop 10 {res[10]:6.1f} us ({fl/res[10]/1e6:5.0f} TF/s)   own / lt = {min(res.values())/t_lt:.3f}", flush=True)
-    ref = (X.float() @ W.float().t() + b).to(torch.bfloat16)
-    lib.fh_gemm_set_path(10); Cc.zero_(); L.check(lib.fh_gemm(d, 1, st()), "gemm"); torch.cuda.synchronize()
-    assert lib.fh_gemm_last_loop() == 10
-    err = (Cc.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
-    assert err < 2e-2, err
-    lib.fh_gemm_set_path(9)
+    print(f"{name:12s} {M}x{N}x{K}: hipBLASLt {t_lt:6.1f} us ({fl/t_lt/1e6:5.0f} TF/s)   loop 7 {res[7]:6.1f}   loop 8 {res[8]:6.1f} us ({fl/res[8]/1e6:5.0f} TF/s)   own / lt = {min(res.values())/t_lt:.3f}", flush=True)
