@@ -334,8 +334,8 @@ def main():
                     "indexes the teacher out of range, so use it with --teacher large; SURVEY 0.1)")
     ap.add_argument("--teacher", default="base", choices=["base", "large"], help="variant: HuBERT-Large-shaped teacher (24 x 1024)")
     ap.add_argument("--teacher-frontend", default="native", choices=["native", "torch"],
-                    help="frozen teacher's conv frontend + positional conv: the student's HIP kernels (native) or stock "
-                         "PyTorch-ROCm ops (torch); its transformer layers always run on PyTorch-ROCm")
+                    help="frozen teacher: native = every kernel is the library's own (conv frontend, positional conv, and the transformer "
+                         "layers through fh_teacher_encoder_forward); torch = stock PyTorch-ROCm modules (A/B)")
     ap.add_argument("--gemm-table", default=os.environ.get("FH_GEMM_TABLE", ""),
                     help="JSON file with the per-shape GEMM main-loop table: loaded if present (then nothing is re-measured, so a "
                          "profiler sees only the steps), written after the run otherwise")
