@@ -1,4 +1,6 @@
-"""Frozen teacher on stock PyTorch-ROCm (north star: "the frozen teacher forward runs on PyTorch-ROCm").
+"""Frozen teacher.  The north star allows it on stock PyTorch-ROCm; since round 3 every kernel of its forward is the library's own
+(``native_frontend``: conv frontend, positional conv, and all transformer layers in one call, fh_teacher_encoder_forward); the plain
+torch modules below hold the weights under fairseq's names and remain as the A/B and CPU path.
 
 A plain ``nn.Module`` HuBERT / wav2vec 2.0 encoder with fairseq's parameter names, so a fairseq checkpoint's
 ``state['model']`` loads into it, plus the contract of the reference's ``TeacherWrapper``
@@ -154,10 +156,11 @@ class _FeatureExtractor(nn.Module):
 
 
 class _NativeFrontend:
-    """The frozen teacher's conv frontend and positional conv on the student's HIP kernels:
-    conv0+GroupNorm+GELU fused (fh_conv0_forward), conv layers as channels-last MFMA GEMMs with a GELU epilogue
-    (fh_conv1d_forward), weight-normed grouped positional conv (fh_posconv_wide_forward).  Weights are prepared ONCE
-    (the teacher is frozen).  The transformer layers stay on PyTorch-ROCm."""
+    """The frozen teacher on the library's HIP kernels: conv0+GroupNorm+GELU fused (fh_conv0_forward; the Large
+    model's conv0+LayerNorm+GELU: fh_conv0_layernorm_gelu_forward), conv layers as channels-last MFMA GEMMs with a GELU epilogue
+    (fh_conv1d_forward), weight-normed grouped positional conv (fh_posconv_wide_forward), and the transformer layers -- post-LN or
+    pre-LN -- in one call (fh_teacher_encoder_forward; per-layer entry points kept for A/B).  Weights are prepared ONCE (the teacher
+    is frozen)."""
 
     def __init__(self, model: "TeacherModel"):
         from . import _lib as L
