@@ -1323,9 +1323,19 @@ int wide_waves(int res, int Tn, int max_nw = 16) {  // waves per workgroup: FH_A
     forced = e ? atoi(e) : 0;
   }
   if (forced == 4 || forced == 8 || forced == 16) return forced;
+  if (max_nw == 0) return 0;   // (query of the override alone)
   if (!res) return 4;
   const int nw = Tn > 256 ? 16 : (Tn > 128 ? 8 : 4);
   return nw < max_nw ? nw : max_nw;
+}
+// Forward: the width that wastes the fewest query rows (a workgroup covers 32 rows per wave: T = 349 is 68 % of two 8-wave or one
+// 16-wave workgroup but 91 % of three 4-wave ones -- 180 -> 148 us at B = 128, 40-wide heads; the median LibriSpeech utterance), 8 waves
+// on a tie (K / V are streamed, so 16 waves share nothing more and measured 2 - 7 % slower at T = 499).  FH_ATTN_WAVES overrides.
+int fwd_waves(int Tn) {
+  const int forced = wide_waves(0, 0, 0);
+  if (forced == 4 || forced == 8 || forced == 16) return forced;
+  const int pad8 = (Tn + 255) / 256 * 256, pad4 = (Tn + 127) / 128 * 128;
+  return pad4 < pad8 ? 4 : 8;
 }
 }  // namespace
 
@@ -1336,7 +1346,7 @@ int fwd16(const void* qkv, void* out, float* lse, const int* key_len, int B, int
   const T* q = (const T*)qkv;
   // Workgroup width: 16 waves share one stream of K / V tiles, but at small batches the grid must still cover the chip -- halve
   // the width while the launch has fewer workgroups than CUs (B = 4, T = 499: 48 workgroups of 16 waves -> 192 of 4)
-  int nw = wide_waves(1, Tn);
+  int nw = fwd_waves(Tn);
   while (nw > 4 && (long)B * H * ((Tn + 32 * nw - 1) / (32 * nw)) < 256) nw >>= 1;
   if (dh > 48) {  // 64-wide heads: the teacher (HuBERT Base 768 / 12, Large 1024 / 16), the ex.yaml student
     switch (nw) {
