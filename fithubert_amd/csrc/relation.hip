@@ -17,6 +17,7 @@
 // probability in both distributions and contribute nothing.
 #include "kernels.h"
 #include "common.cuh"
+#include "attn_frag.cuh"
 
 namespace {
 
@@ -271,6 +272,217 @@ __global__ void __launch_bounds__(256) relation_kd_kernel(RelArgs a) {
   if (threadIdx.x == 0 && a.partials) a.partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0];
 }
 
+// ------------------------------------------------------------------------------------------------ 16-bit operands: the same losses on the matrix cores
+// The fp32 kernel above forms its 64 x 64 logit tiles with VALU FMAs: 5 - 6 TFLOP/s, 23 - 28 ms per loss term at B = 128, T = 499 -- half
+// a training step for an optional term.  With 16-bit q|k|v (the bf16 / fp16 modes) the tiles are MFMA products of exactly the same
+// inputs (a product of two 16-bit values is exact in fp32; only the order of the fp32 additions differs), so the logits, the loss and
+// G = dL/dS_s are as accurate as before.  Decomposition, as the attention kernels (attn_frag.cuh):
+//   * a workgroup (4 waves) owns 64 rows of ONE operand (SWAP = false: the row operand -- queries; SWAP = true: the column operand --
+//     keys) and sweeps 64-row tiles of the other through LDS; wave w computes the TRANSPOSED tiles  M^T[swept row][own row]  for its
+//     16 own rows, student and teacher, so a lane owns one own row (column lane & 15);
+//   * the tile of G^T is, in accumulator layout, directly the B operand of  dOwn^T[d][own] += Swept_s^T[d][swept] G^T[swept][own]
+//     (mma_transposed: the swept student tile is read transposed from the same LDS image).  G is carried into that product as a
+//     head + remainder PAIR of 16-bit values (two MFMAs), unscaled (O(1): the 1 / (B H T) normaliser would underflow fp16), and the
+//     fp32 sums are scaled once at the end -- the gradient keeps fp32-grade accuracy (tests: 2e-4 of its norm);
+//   * so the row operand's gradient comes from the SWAP = false launch and the column operand's from the SWAP = true launch, each
+//     complete per workgroup: no atomics, bit-reproducible.  kl-div rows need log-sum-exp of both logit rows: the SWAP = false launch
+//     computes them in a first sweep (its lanes own the queries) and leaves them in the scratch for the SWAP = true launch.
+template <typename T> __device__ __forceinline__ void split16(float v, T& hi, T& lo) {
+  hi = (T)v;
+  lo = (T)(v - (float)hi);
+}
+template <typename TS, typename TT, int NDT, bool SWAP>
+__global__ void __launch_bounds__(256) relation_mfma_kernel(RelArgs a, float* __restrict__ lse /* [2][B H Tp] */, int Tp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int TILE = 64 * AT<TS>::RS;
+  unsigned char* Ws = lds;               // swept student tile [64][RS]
+  unsigned char* Wt = lds + TILE;        // swept teacher tile
+  float* lrow = reinterpret_cast<float*>(lds + 2 * TILE);   // SWAP: lse_s | lse_t of the swept (query) rows of the tile
+  __shared__ float red[256];
+  const int ob = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int T = a.T, dhs = a.Ds / a.H, dht = a.Dt / a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const long lds_ = 3L * a.Ds, ldt_ = 3L * a.Dt;
+  const TS* sq = reinterpret_cast<const TS*>(a.s_qkv) + (long)b * T * lds_ + h * dhs;
+  const TT* tq = reinterpret_cast<const TT*>(a.t_qkv) + (long)b * T * ldt_ + h * dht;
+  const int own_off_s = SWAP ? a.b_off_s : a.a_off_s, swp_off_s = SWAP ? a.a_off_s : a.b_off_s;
+  const int own_off_t = SWAP ? a.b_off_t : a.a_off_t, swp_off_t = SWAP ? a.a_off_t : a.b_off_t;
+  int klen = T;
+  if (a.masked) {
+    if (a.s_len) klen = min(klen, a.s_len[b]);
+    if (a.t_len) klen = min(klen, a.t_len[b]);
+  }
+  // mse normaliser: all entries minus those of masked key columns (train.py:336-341), over the whole batch
+  float den = 1.f;
+  if (a.mode == 0) {
+    double dd = (double)a.B * a.H * T * (double)T;
+    if (a.masked)
+      for (int bb = 0; bb < a.B; ++bb) {
+        int kl = T;
+        if (a.s_len) kl = min(kl, a.s_len[bb]);
+        if (a.t_len) kl = min(kl, a.t_len[bb]);
+        dd -= (double)a.H * (T - kl) * (double)T;
+      }
+    den = (float)dd;
+  }
+  const float gsc = a.mode == 0 ? a.weight * 2.0f / den : a.weight * a.gscale;
+  const int own = ob * 64 + wave * 16 + r;          // this lane's own row (query, or key when SWAP)
+  const bool own_in = own < T;
+  // own-row fragments (global -> registers, once)
+  typename AT<TS>::frag os[AT<TS>::NK];
+  typename AT<TT>::frag ot[AT<TT>::NK];
+#pragma unroll
+  for (int ks = 0; ks < AT<TS>::NK; ++ks) os[ks] = gfrag<TS>(sq + own_off_s + (long)own * lds_, own_in, ks, lane, dhs);
+#pragma unroll
+  for (int ks = 0; ks < AT<TT>::NK; ++ks) ot[ks] = gfrag<TT>(tq + own_off_t + (long)own * ldt_, own_in, ks, lane, dht);
+  zero_lds<TS>(lds, 2 * TILE);   // (columns dh .. 63 of the padded rows are never written again)
+  __syncthreads();
+  const int nt = (T + 63) / 64;
+  const float L2E = 1.4426950408889634f;
+  const long lbase = ((long)b * a.H + h) * Tp;
+  float* lse_s = lse ? lse + lbase : nullptr;
+  float* lse_t = lse ? lse + (long)a.B * a.H * Tp + lbase : nullptr;
+
+  auto tiles = [&](int t0, f32x4 (&ss)[4], f32x4 (&st)[4]) {   // M^T tiles of the 64 swept rows from t0 (raw dot products x scale)
+    __syncthreads();                                            // the previous tile's readers are done
+    stage_tile<TS>(Ws, sq + swp_off_s, lds_, t0, T, dhs);
+    stage_tile<TT>(Wt, tq + swp_off_t, ldt_, t0, T, dht);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      ss[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < AT<TS>::NK; ++ks) ss[kb] = mma<TS>(lfrag<TS>(Ws, 16 * kb + r, ks, lane), os[ks], ss[kb]);
+#pragma unroll
+      for (int ks = 0; ks < AT<TT>::NK; ++ks) st[kb] = mma<TT>(lfrag<TT>(Wt, 16 * kb + r, ks, lane), ot[ks], st[kb]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ss[kb][e] *= a.scale_s;
+        st[kb][e] *= a.scale_t;
+      }
+    }
+  };
+  // entry (kb, e) of a tile at t0: swept row t0 + 16 kb + 4 q + e
+  float m_s = 0.f, m_t = 0.f;   // kl-div, SWAP = false: log-sum-exp of this lane's query row
+  if (a.mode == 1 && !SWAP) {
+    float ms = -INFINITY, mt = -INFINITY, ls = 0.f, lt = 0.f;
+    for (int kt = 0; kt < nt; ++kt) {
+      f32x4 ss[4], st[4];
+      tiles(kt * 64, ss, st);
+      float xs = -INFINITY, xt = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool v = kt * 64 + 16 * kb + 4 * q + e < klen;
+          if (!v) { ss[kb][e] = -INFINITY; st[kb][e] = -INFINITY; }
+          xs = fmaxf(xs, ss[kb][e]);
+          xt = fmaxf(xt, st[kb][e]);
+        }
+      xs = fmaxf(xor_max(xs), ms);
+      xt = fmaxf(xor_max(xt), mt);
+      float es = 0.f, et = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          es += ss[kb][e] == -INFINITY ? 0.f : fast_exp2((ss[kb][e] - xs) * L2E);
+          et += st[kb][e] == -INFINITY ? 0.f : fast_exp2((st[kb][e] - xt) * L2E);
+        }
+      es = xor_sum(es);
+      et = xor_sum(et);
+      ls = ls * (ms == -INFINITY ? 0.f : fast_exp2((ms - xs) * L2E)) + es;
+      lt = lt * (mt == -INFINITY ? 0.f : fast_exp2((mt - xt) * L2E)) + et;
+      ms = xs;
+      mt = xt;
+    }
+    m_s = ms + __logf(ls);
+    m_t = mt + __logf(lt);
+    if (lse && q == 0 && own_in) {
+      lse_s[own] = m_s;
+      lse_t[own] = m_t;
+    }
+  }
+  // ---- loss and gradient sweep
+  float loss = 0.f;
+  f32x4 dO[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) dO[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_grad = a.d_qkv != nullptr;
+  for (int kt = 0; kt < nt; ++kt) {
+    f32x4 ss[4], st[4];
+    tiles(kt * 64, ss, st);
+    if (SWAP && a.mode == 1) {   // log-sum-exp of the swept (query) rows of this tile
+      if (threadIdx.x < 128) {
+        const int row = kt * 64 + (threadIdx.x & 63);
+        const float* src = threadIdx.x < 64 ? lse_s : lse_t;
+        lrow[threadIdx.x] = row < T ? src[row] : 0.f;
+      }
+      __syncthreads();
+    }
+    f32x4 gh[4], gl[4];   // G^T tile as head / remainder (values representable in TS), unscaled
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int sw = kt * 64 + 16 * kb + 4 * q + e;       // swept row
+        const int qi = SWAP ? sw : own, ki = SWAP ? own : sw;
+        const bool v = qi < T && ki < klen;
+        float g = 0.f;
+        if (v) {
+          if (a.mode == 0) {
+            const float d = ss[kb][e] - st[kb][e];
+            if (!SWAP) loss = fmaf(d, d, loss);
+            g = d;
+          } else {
+            const float rs = SWAP ? lrow[16 * kb + 4 * q + e] : m_s, rt = SWAP ? lrow[64 + 16 * kb + 4 * q + e] : m_t;
+            const float lps = ss[kb][e] - rs, lpt = st[kb][e] - rt;
+            const float ps = fast_exp2(lps * L2E), pt = fast_exp2(lpt * L2E);
+            if (!SWAP) loss = fmaf(pt, lpt - lps, loss);
+            g = ps - pt;
+          }
+        }
+        TS hi, lo;
+        split16<TS>(g, hi, lo);
+        gh[kb][e] = (float)hi;
+        gl[kb][e] = (float)lo;
+      }
+    if (want_grad) {
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        mma_transposed<TS, NDT>(Ws, m2, gh[2 * m2], gh[2 * m2 + 1], dO, lane);
+        mma_transposed<TS, NDT>(Ws, m2, gl[2 * m2], gl[2 * m2 + 1], dO, lane);
+      }
+    }
+  }
+  if (want_grad && own_in) {   // dOwn^T in accumulator layout: row d = 16 dt + 4 q + e, column = own row
+    float* dst = a.d_qkv + ((long)b * T + own) * lds_ + own_off_s + h * dhs;
+    const float sc = gsc * a.scale_s;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int d = 16 * dt + 4 * q;
+      if (d < dhs) {   // (head widths are multiples of 8: a group of four is inside or outside)
+        float4 cur = *reinterpret_cast<float4*>(dst + d);
+        cur.x = fmaf(dO[dt][0], sc, cur.x);
+        cur.y = fmaf(dO[dt][1], sc, cur.y);
+        cur.z = fmaf(dO[dt][2], sc, cur.z);
+        cur.w = fmaf(dO[dt][3], sc, cur.w);
+        *reinterpret_cast<float4*>(dst + d) = cur;
+      }
+    }
+  }
+  if (!SWAP) {
+    red[threadIdx.x] = loss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && a.partials) a.partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0];
+  }
+}
+
 // out[0] = sum(partials) / normaliser  (fp64)
 __global__ void relation_final_kernel(const float* partials, int n, double* out, RelArgs a) {
   __shared__ double sh[256];
@@ -300,7 +512,11 @@ __global__ void relation_final_kernel(const float* partials, int n, double* out,
 
 }  // namespace
 
-extern "C" int fh_relation_kd_nblk(int B, int T, int H) { return B * H * ((T + RT - 1) / RT); }
+// scratch floats of fh_relation_kd: one loss partial per (utterance, head, 64-row block), then -- for the 16-bit kernels' kl-div form --
+// the log-sum-exp of every student and teacher logit row ([2][B H Tp], Tp = T rounded up to 64)
+static int rel_nparts(int B, int T, int H) { return B * H * ((T + RT - 1) / RT); }
+static int rel_tp(int T) { return (T + RT - 1) / RT * RT; }
+extern "C" int fh_relation_kd_nblk(int B, int T, int H) { return rel_nparts(B, T, H) + 2 * B * H * rel_tp(T); }
 
 static int relation_launch(int dtype, int teacher_dtype, const RelArgs& a, hipStream_t st);
 
@@ -345,13 +561,37 @@ extern "C" int fh_relation_kd(int dtype, int teacher_dtype, const void* s_qkv, c
   hipStream_t st = (hipStream_t)stream;
   const int rc = relation_launch(dtype, teacher_dtype, a, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(relation_final_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, fh_relation_kd_nblk(B, T, H), loss_out, a);
+  hipLaunchKernelGGL(relation_final_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, rel_nparts(B, T, H), loss_out, a);
   FH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename TS, typename TT, int NDT>
+static int relation_mfma_launch(const RelArgs& a, hipStream_t st) {
+  const dim3 grid((a.T + RT - 1) / RT, a.H, a.B), block(256);
+  const size_t smem = (size_t)2 * 64 * AT<TS>::RS + 128 * sizeof(float);
+  const int Tp = rel_tp(a.T);
+  float* lse = a.mode == 1 ? a.partials + rel_nparts(a.B, a.T, a.H) : nullptr;
+  hipLaunchKernelGGL((relation_mfma_kernel<TS, TT, NDT, false>), grid, block, smem, st, a, lse, Tp);   // loss, row operand's gradient, (log-sum-exp rows)
+  FH_CHECK_LAUNCH();
+  if (a.d_qkv) {
+    hipLaunchKernelGGL((relation_mfma_kernel<TS, TT, NDT, true>), grid, block, smem, st, a, lse, Tp);  // column operand's gradient
+    FH_CHECK_LAUNCH();
+  }
   return 0;
 }
 
 static int relation_launch(int dtype, int teacher_dtype, const RelArgs& a, hipStream_t st) {
   const dim3 grid((a.T + RT - 1) / RT, a.H, a.B), block(256);
+  // 16-bit student and teacher projections, loss modes: the MFMA kernels (the fp32 parity mode and the relation-tensor modes of the
+  // module API stay on the fp32 kernel)
+  if (dtype != 0 && teacher_dtype != 0 && a.mode <= 1 && a.t_qkv && a.partials && (a.Ds / a.H) % 8 == 0 && (a.Dt / a.H) % 8 == 0) {
+    const bool wide = a.Ds / a.H > 48;
+#define FH_RM(TS, TT) return wide ? relation_mfma_launch<TS, TT, 4>(a, st) : relation_mfma_launch<TS, TT, 3>(a, st)
+    if (dtype == 2) { if (teacher_dtype == 2) FH_RM(f16, f16); else FH_RM(f16, bf16); }
+    else { if (teacher_dtype == 2) FH_RM(bf16, f16); else FH_RM(bf16, bf16); }
+#undef FH_RM
+  }
   const size_t smem = (size_t)5 * RT * RSTR * sizeof(float);
 #define FH_REL(TS, TT)                                                                                                       \
   do {                                                                                                                       \

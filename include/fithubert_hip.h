@@ -407,7 +407,10 @@ int fh_student_backward_notify(const fh_student_config* c, const fh_student_call
  *           over keys, mean over rows.  (Padded batch + kl-div: the reference's arithmetic gives nan; masked keys contribute 0 here.)
  *   s_len / t_len : int32 [B] valid keys of student / teacher (a key is masked when either masks it), or NULL
  *   d_qkv : fp32 [B][T][3*Ds], ACCUMULATES weight * dLoss/d s_qkv (zero it first; several calls may add into it), or NULL
- *   partials : fp32 scratch, fh_relation_kd_nblk(B, T, H) floats;  loss_out : double[1] <- the (unweighted) loss
+ *   partials : fp32 scratch, fh_relation_kd_nblk(B, T, H) floats (loss partials, then the kl-div form's row log-sum-exps);
+ *   loss_out : double[1] <- the (unweighted) loss.  16-bit student AND teacher projections: the logit tiles, and the gradient
+ *   products with G as a 16-bit head + remainder pair, run on the matrix cores (two launches: row operand, column operand; no
+ *   atomics); an fp32 side selects the fp32 VALU kernel
  * ------------------------------------------------------------------------------------------ */
 /* The relation tensor itself, for the module API (the reference's patched layer RETURNS attn / v_rel, utils/utils.py:263-265,278):
  * out != NULL: out[(b h)][q][k] = (A_q . B_k) d^-1/2 fp32, masked keys (k >= key_len[b], which = 0 only) = -inf;

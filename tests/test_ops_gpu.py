@@ -517,18 +517,21 @@ def _relation_loss_ref(s, t, mode):
     return term.sum(-1).mean()
 
 
-@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("dt,tdt", [(L.DT_F32, L.DT_BF16), (L.DT_BF16, L.DT_BF16), (L.DT_F16, L.DT_F16), (L.DT_BF16, L.DT_F16), (L.DT_F16, L.DT_BF16),
+                                    (L.DT_BF16, L.DT_F32)])
 @pytest.mark.parametrize("which,mode", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("B,T,masked", [(2, 49, False), (3, 130, True), (2, 200, True), (2, 499, True)])   # 499 = the 10 s utterance without a TR layer
-def test_relation_transfer_loss_and_gradient(dt, which, mode, B, T, masked):
+def test_relation_transfer_loss_and_gradient(dt, tdt, which, mode, B, T, masked):
     """fh_relation_kd: attention-logit mse / kl-div and value-relation kl-div against the materialised fp64 form and its
     autograd gradient; student 40-wide heads, teacher 64-wide heads (fithubert.yaml vs HuBERT Base), the teacher masking one
-    more key than the student on one utterance (the two padding rules differ)."""
+    more key than the student on one utterance (the two padding rules differ).  16-bit student AND teacher
+    projections run the MFMA kernels (every pairing of bf16 / fp16), anything with an fp32 side the fp32 kernel -- same tolerances:
+    the logit tiles are exact products either way and G enters the gradient products as a head + remainder pair."""
     torch.manual_seed(T + which * 3 + mode)
     H, dhs, dht = 12, 40, 64
     lib = L.lib()
     sq = (torch.randn(B, T, 3 * H * dhs, device=DEV) * 0.8).to(_tdt(dt))
-    tq = (torch.randn(B, T, 3 * H * dht, device=DEV) * 0.8).to(torch.bfloat16)
+    tq = (torch.randn(B, T, 3 * H * dht, device=DEV) * 0.8).to(_tdt(tdt))
     s_len = t_len = None
     if masked:
         s_len = torch.tensor([T, T * 3 // 4, T // 2][:B], device=DEV, dtype=torch.int32)
@@ -538,7 +541,7 @@ def test_relation_transfer_loss_and_gradient(dt, which, mode, B, T, masked):
     partials = torch.empty(lib.fh_relation_kd_nblk(B, T, H), device=DEV)
     out = torch.empty(1, device=DEV, dtype=torch.float64)
     w = 0.7
-    L.check(lib.fh_relation_kd(dt, L.DT_BF16, _p(sq), _p(tq), _p(d), _p(partials), _p(out), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
+    L.check(lib.fh_relation_kd(dt, tdt, _p(sq), _p(tq), _p(d), _p(partials), _p(out), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
                                which, mode, w, _st()), "fh_relation_kd")
     leaf = sq.double().requires_grad_(True)
     both = None if s_len is None else torch.minimum(s_len, t_len)
@@ -547,7 +550,7 @@ def test_relation_transfer_loss_and_gradient(dt, which, mode, B, T, masked):
     assert abs(out.item() - ref.item()) < (2e-5 if dt == L.DT_F32 else 1e-4) * max(1.0, abs(ref.item())), (out.item(), ref.item())
     assert _rel(d, g) < 2e-4
     # a second call ACCUMULATES into d_qkv
-    L.check(lib.fh_relation_kd(dt, L.DT_BF16, _p(sq), _p(tq), _p(d), _p(partials), _p(out), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
+    L.check(lib.fh_relation_kd(dt, tdt, _p(sq), _p(tq), _p(d), _p(partials), _p(out), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
                                which, mode, w, _st()), "fh_relation_kd")
     assert _rel(d, 2 * g) < 2e-4
 
