@@ -245,6 +245,28 @@ def run_variants(task, cfg, args, dev, budget_s: float):
                                       "deviation of this mode from the fp32 reference: DESIGN.md section 2"}
         del t16
         torch.cuda.empty_cache()
+    # ---- the ex.yaml recipe (DistilHuBERT-style student without a TR layer) with and without attention-logit + value-relation transfer
+    # (utils/utils.py:193-280, train.py:327-370): what the fused relation kernels cost in a step
+    if left() > 45:
+        ex_path = os.path.join(ROOT, "conf", "ex.yaml")
+        res = {}
+        for name, w in (("off", 0.0), ("on", 1.0)):
+            with open(ex_path) as f:
+                ce = yaml.load(f, Loader=yaml.FullLoader)
+            ce["train"].update(accumulate_grad_batches=1, attn_loss_weight=w, attn_loss_type="kldiv", v_rel_loss_weight=w)
+            te = W2V2Distil(ce, dtype=args.dtype, device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native",
+                            teacher=task.teacher_model)
+            te.configure_optimizers(num_training_steps=100)
+            batches = [fixed_length_batch(64, SAMPLES_10S, seed=90 + i, device=dev) for i in range(2)]
+            dt, utt, smp = time_steps(te, batches, 3, 2)
+            res[name] = (utt / dt, dt / 3 * 1e3)
+            del te
+            torch.cuda.empty_cache()
+        out["ex_yaml_attention_transfer"] = {
+            "per_gpu_batch": 64, "utt_per_s": round(res["on"][0], 1), "ms_per_step": round(res["on"][1], 2),
+            "utt_per_s_without_transfer": round(res["off"][0], 1), "ms_per_step_without_transfer": round(res["off"][1], 2),
+            "workload": "ex.yaml (768-wide, 2 layers, no TR layer: T = 499) with attn_loss_weight = v_rel_loss_weight = 1 (kl-div): the last "
+                        "layer's attention-logit and value-relation transfer as fused relation kernels (fh_relation_kd), fixed 10 s clips"}
     # ---- 24-layer student + HuBERT-Large-shaped teacher
     if left() > 45:
         c2 = copy.deepcopy(cfg)
