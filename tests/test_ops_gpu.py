@@ -553,6 +553,11 @@ def test_relation_transfer_loss_and_gradient(dt, tdt, which, mode, B, T, masked)
     L.check(lib.fh_relation_kd(dt, tdt, _p(sq), _p(tq), _p(d), _p(partials), _p(out), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
                                which, mode, w, _st()), "fh_relation_kd")
     assert _rel(d, 2 * g) < 2e-4
+    # loss only (validation): no gradient buffer
+    out2 = torch.empty(1, device=DEV, dtype=torch.float64)
+    L.check(lib.fh_relation_kd(dt, tdt, _p(sq), _p(tq), None, _p(partials), _p(out2), _p(s_len), _p(t_len), B, T, H, H * dhs, H * dht,
+                               which, mode, w, _st()), "fh_relation_kd")
+    assert out2.item() == out.item()
 
 
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
