@@ -168,7 +168,8 @@ class W2V2Distil:
         self._amp_since_growth = 0
         self._amp_seen_skipped = 0
         self.amp_state = torch.zeros(8, dtype=torch.int32, device=self.device) if self.amp else None
-        self._amp_host = torch.zeros(8, dtype=torch.int32).pin_memory() if (self.amp and self.device.type == "cuda") else None
+        self._amp_host = torch.zeros(2, 8, dtype=torch.int32).pin_memory() if (self.amp and self.device.type == "cuda") else None
+        self._amp_slot, self._amp_event = 0, None
         self.sync = GradSync(self.engine.grads)
         if self.sync.active and self.device.type == "cuda":
             # data parallel: RCCL's collective kernels run beside the step; the persistent GEMM loop (which otherwise owns every CU
@@ -480,12 +481,22 @@ class W2V2Distil:
             self.student_model._flat_version = self.student_model.flat._version
 
     def _amp_after_step(self):
-        """GradScaler.update without a sync: the device state is copied to pinned memory behind the optimizer kernels and the copy
-        of an EARLIER step is read here; a skip seen there halves the scale (once per skipped step), 2000 steps without one double it.
-        The scale only changes between optimizer steps, so an accumulation window is summed under one scale."""
+        """GradScaler.update one step behind the device: the device state is copied to pinned memory behind the optimizer kernels and
+        the copy of the PREVIOUS optimizer step is read here (its event is waited for: the host runs at most one step ahead of the
+        device, which still has the step just enqueued to work on).  The lag is exactly one step on every rank -- the counters are
+        identical across ranks at the same step (the overflow check runs on the all-reduced gradient), so every rank changes its scale
+        at the same step; a copy read "whenever it has landed" could move one rank's scale a step before another's, and the ranks
+        would then sum gradients taken under different scales.  A skip halves the scale (once per skipped step), 2000 steps without
+        one double it.  The scale only changes between optimizer steps, so an accumulation window is summed under one scale."""
         if self._amp_host is not None:
-            skipped = int(self._amp_host[2])          # whatever copy has landed (at worst one step old)
-            self._amp_host.copy_(self.amp_state, non_blocking=True)
+            skipped = self._amp_seen_skipped
+            if self._amp_event is not None:
+                self._amp_event.synchronize()
+                skipped = int(self._amp_host[self._amp_slot][2])
+            self._amp_slot ^= 1
+            self._amp_host[self._amp_slot].copy_(self.amp_state, non_blocking=True)
+            self._amp_event = torch.cuda.Event()
+            self._amp_event.record()
         else:
             skipped = int(self.amp_state[2])
         if skipped > self._amp_seen_skipped:
@@ -672,7 +683,8 @@ class W2V2Distil:
                 self.amp_state[1] = int(a["applied"])
                 self.amp_state[2] = int(a["skipped"])
                 if self._amp_host is not None:
-                    self._amp_host.copy_(self.amp_state.cpu())
+                    self._amp_host[:] = self.amp_state.cpu()
+                    self._amp_event = None
             self.num_training_steps = ex["num_training_steps"]
             self._micro = int(ex["micro"])
             self.rand_l = list(ex["rand_l"])
