@@ -184,6 +184,107 @@ __global__ void __launch_bounds__(256) posconv_wide_kernel(const T* __restrict__
   }
 }
 
+// ---- 48 channels per group (HuBERT / wav2vec 2.0 Base: 768 / 16), 16-bit: the reduction index FLATTENED over (tap, input channel).
+// Per tap the padded form multiplies two 32-wide K slabs of which the second is half zeros (48 -> 64); two taps are 96 = 3 x 32
+// reduction elements exactly: slab 0 = tap 2p channels 0..31, slab 1 = tap 2p channels 32..47 | tap 2p+1 channels 0..15, slab 2 = tap 2p+1
+// channels 16..47 -- a lane's 8 consecutive elements never straddle a tap (48 % 8 == 0), so an X fragment is still one 16-byte LDS
+// read, at row + (0 | 1) of the staged window.  36 instead of 48 MFMAs per tap pair and frame tile.
+constexpr bool flat48(int dtype, int cg, int K) { return dtype != 0 && cg == 48 && K % 8 == 0; }
+template <typename T>
+__global__ void wnw_layout48_kernel(const float* __restrict__ gsc, const float* __restrict__ v, const float* __restrict__ norm2,
+                                    T* __restrict__ w_fwd, int G, int K) {
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)G * (K / 2) * 9 * 512;
+  if (o >= n) return;
+  const int e = (int)(o % 8), lane = (int)((o / 8) % 64), cb = (int)((o / 512) % 3), sl = (int)((o / (512 * 3)) % 3);
+  const int p = (int)((o / (512 * 9)) % (K / 2)), g = (int)(o / ((long)512 * 9 * (K / 2)));
+  const int kk = 32 * sl + 8 * (lane >> 4) + e, j = 2 * p + kk / 48, ci = kk % 48, co = 16 * cb + (lane & 15);
+  w_fwd[o] = from_f<T>(gsc[j] * v[((long)(g * 48 + co) * 48 + ci) * K + j] * rsqrtf(norm2[j]));
+}
+
+template <typename T, int NTT>
+__global__ void __launch_bounds__(256) posconv_wide48_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ y, int B, int Tn,
+                                                             int D, int K, int pad_left) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int RS = PW<T>::RS, cg = 48;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  constexpr int TTW = 64 * NTT;
+  const int t0 = blockIdx.x * TTW, g = blockIdx.y, b = blockIdx.z;
+  const int nrows = TTW + K - 1;
+  const int units = CPW / 2;
+  for (int idx = threadIdx.x; idx < nrows * units; idx += blockDim.x) {
+    const int row = idx / units, u = idx - row * units;
+    const int t = t0 - pad_left + row;
+    float f[2] = {0.f, 0.f};
+    if (t >= 0 && t < Tn && 2 * u + 1 < cg) ld2w(x + ((long)b * Tn + t) * D + g * cg + 2 * u, f);
+    st2w(reinterpret_cast<T*>(lds + row * RS) + 2 * u, f);
+  }
+  __syncthreads();
+  f32x4 acc[3][NTT];
+#pragma unroll
+  for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const T* wg = w + (long)g * (K / 2) * 9 * 512;
+  int xoff[3];   // byte offset of this lane's 8 reduction elements of slab sl inside the window rows of a tap pair
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    const int kk = 32 * sl + 8 * q;
+    xoff[sl] = (kk / 48) * RS + (kk % 48) * 2;
+  }
+  const int np = K / 2;
+  // weight fragments of tap pair p + 3 are requested (from L2) while pair p's 36 MFMAs per frame tile run; ring of four register sets
+  bf16x8 wr[4][3][3];
+  auto load_pair = [&](int slot, int p) {
+    const T* wp = wg + (long)(p < np ? p : np - 1) * 9 * 512;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int cb = 0; cb < 3; ++cb) wr[slot][sl][cb] = *reinterpret_cast<const bf16x8*>(wp + ((sl * 3 + cb) * 64 + lane) * 8);
+  };
+#pragma unroll
+  for (int u = 0; u < 3; ++u) load_pair(u, u);
+  for (int p0 = 0; p0 < np; p0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u;
+      load_pair((u + 3) & 3, p + 3);
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        bf16x8 xf[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+          xf[tt] = *reinterpret_cast<const bf16x8*>(lds + (wave * (16 * NTT) + tt * 16 + r + 2 * p) * RS + xoff[sl]);
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+          for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = mfma16<T>(wr[u][sl][cb], xf[tt], acc[cb][tt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const int tl = wave * (16 * NTT) + tt * 16 + r;
+    const int t = t0 + tl;
+    if (t >= Tn) continue;
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int co = cb * 16 + q * 4 + 2 * h;
+        const long off = ((long)b * Tn + t) * D + g * cg + co;
+        float v[2] = {acc[cb][tt][2 * h] + bias[g * cg + co], acc[cb][tt][2 * h + 1] + bias[g * cg + co + 1]};
+        float xv[2];
+        ld2w(reinterpret_cast<const T*>(lds + (tl + pad_left) * RS) + co, xv);
+        v[0] = xv[0] + gelu_t<T>(v[0]);
+        v[1] = xv[1] + gelu_t<T>(v[1]);
+        st2w(y + off, v);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int fh_posconv_wide_prepare(int dtype, const float* g, const float* v, void* w_fwd, float* norm2, int D, int groups,
@@ -193,6 +294,15 @@ extern "C" int fh_posconv_wide_prepare(int dtype, const float* g, const float* v
   if (cg > CPW || cg % 2 || K > 1024) return -551;
   hipLaunchKernelGGL(wnw_norm2_kernel, dim3(K), dim3(256), 0, st, v, norm2, D * cg, K);
   FH_CHECK_LAUNCH();
+  if (flat48(dtype, cg, K)) {   // (the flattened layout is smaller than the padded one: same buffer)
+    const long nf = (long)groups * (K / 2) * 9 * 512;
+    if (dtype == 2)
+      hipLaunchKernelGGL(wnw_layout48_kernel<f16>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, g, v, norm2, (f16*)w_fwd, groups, K);
+    else
+      hipLaunchKernelGGL(wnw_layout48_kernel<bf16>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, g, v, norm2, (bf16*)w_fwd, groups, K);
+    FH_CHECK_LAUNCH();
+    return 0;
+  }
   const long n = (long)groups * K * CPW * CPW;
   if (dtype == 0)
     hipLaunchKernelGGL(wnw_layout_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, v, norm2, (float*)w_fwd,
@@ -220,6 +330,22 @@ extern "C" int fh_posconv_wide_forward(int dtype, const void* x, const void* w_f
   }
   const int TTW = 64 * ntt;
   dim3 grid((T + TTW - 1) / TTW, groups, B), block(256);
+  if (flat48(dtype, cg, K)) {
+#define FH_PW48(TY, NT)                                                                                                        \
+  do {                                                                                                                       \
+    const size_t smem = (size_t)(64 * NT + K - 1) * PW<TY>::RS;                                                              \
+    hipFuncSetAttribute((const void*)posconv_wide48_kernel<TY, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+    hipLaunchKernelGGL((posconv_wide48_kernel<TY, NT>), grid, block, smem, st, (const TY*)x, (const TY*)w_fwd, bias, (TY*)y, B, T, D, \
+                       K, K / 2);                                                                                            \
+  } while (0)
+    if (dtype == 2 && ntt == 8) FH_PW48(f16, 8);
+    else if (dtype == 2) FH_PW48(f16, 4);
+    else if (ntt == 8) FH_PW48(bf16, 8);
+    else FH_PW48(bf16, 4);
+#undef FH_PW48
+    FH_CHECK_LAUNCH();
+    return 0;
+  }
 #define FH_PW_LAUNCH(TY, NT)                                                                                                   \
   do {                                                                                                                       \
     const size_t smem = (size_t)(64 * NT + K - 1) * PW<TY>::RS;                                                              \
