@@ -1294,11 +1294,12 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.ep.c0_rstd = x.W<float>(p.c0_rstd);
       g.ep.c0_wpart = reinterpret_cast<float*>(x.W<float2>(p.c0_scratch) + (long)B * nchunk * c.conv_dim[0] + (long)B * fh_conv0_ab_width(c.conv_dim[0]));
       g.ep.c0_S = s.S; g.ep.c0_K = c.conv_k[0]; g.ep.c0_stride = c.conv_stride[0];
+      RC((int)hipMemsetAsync(g.ep.c0_wpart, 0, (size_t)B * c.conv_dim[0] * 12 * sizeof(float), x.st));   // one block of sums per utterance, accumulated
       RC(fh_gemm_launch(g, dt, x.st));
       RC(fh_conv0_bwd_launch(dt, wave, x.params + p.pl.conv_w[0], x.params + p.pl.gn_w, x.params + p.pl.gn_b, nullptr,
                              x.W<float>(p.c0_mean), x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch),
                              x.W<float2>(p.c0_scratch) + (long)B * nchunk * c.conv_dim[0], grads + p.pl.conv_w[0], grads + p.pl.gn_w,
-                             grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st, 1, (int)nchunk));
+                             grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st, 1, /*blocks of sums per utterance*/ 1));
       return 0;
     }
     if (kk == sd || (kk == 1 && sd == 1)) {

@@ -1331,8 +1331,12 @@ __device__ __forceinline__ void conv0_wgrad_epilogue(const GemmParams& p, const 
     }
   }
   __syncthreads();
-  float* out = ep.c0_wpart + ((long)b * ntile + ti) * C0 * PER;
-  for (int i = threadIdx.x; i < C0 * PER; i += blockDim.x) out[i] = red[i] + red[C0 * PER + i];
+  // ONE block of sums per utterance, accumulated with fp32 atomics (zeroed by the caller): a partial block per tile was 125 x 6 KiB per
+  // utterance -- 98 MB at B = 128 -- which the fp64 combine behind it then read back at the end of the step (0.63 ms beside the
+  // concurrent weight-gradient stream); the 1536 atomics of a tile leave as the tile retires, spread over the launch
+  (void)ntile; (void)ti;
+  float* out = ep.c0_wpart + (long)b * C0 * PER;
+  for (int i = threadIdx.x; i < C0 * PER; i += blockDim.x) atomicAdd(out + i, red[i] + red[C0 * PER + i]);
 }
 
 template <int N> __device__ __forceinline__ void wait_vm_barrier() {

@@ -91,9 +91,9 @@ typedef struct {
   /* conv-0 weight-gradient epilogue (modules/module.py:65-71 backward, round 3): with c0_wpart set the product is d loss / d y0 of ONE
    * utterance per group (rows = frames, N = C0 = 128 columns = channels: the k = 1 conv layer 1's data gradient) and is CONSUMED in
    * registers instead of stored: g = v * GELU'(GroupNorm(conv0(wave))) with the conv recomputed from the waveform, and the sums
-   * A_j = sum_t g x_j[t] (j < c0_K), S1 = sum g, S2 = sum g xhat of the tile's 256 frames go to
-   * c0_wpart[((group * tiles + tile) * C0 + channel) * (10 + 2) + j]  (what conv0_bwd_onepass_kernel leaves; fh_conv0_backward's
-   * combine step finishes).  d loss / d y0 (1.05 GB at B = 128) is never written or read back.  16-bit, c0_K <= 10, loop 4. */
+   * A_j = sum_t g x_j[t] (j < c0_K), S1 = sum g, S2 = sum g xhat of the tile's 256 frames are ADDED (fp32 atomics; zero it first) to
+   * c0_wpart[(group * C0 + channel) * (10 + 2) + j]  (one block of sums per utterance, the layout conv0_bwd_onepass_kernel leaves with
+   * one block; fh_conv0_backward's combine step finishes).  d loss / d y0 (1.05 GB at B = 128) is never written or read back.  16-bit, c0_K <= 10, loop 4. */
   const float* c0_wave;    /* [groups][c0_S] */
   const float* c0_w;       /* [C0][c0_K] */
   const float* c0_gamma;   /* [C0] */
