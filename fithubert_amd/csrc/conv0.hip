@@ -365,9 +365,9 @@ int fh_conv0_bwd_blocks(int B, int nchunk) {
 // width (in float2) of the per-utterance block between the statistics partials and the backward's partial sums: MAXK + MAXK^2 fp64
 // waveform sums (or, historically, C0 (a, b) pairs)
 int fh_conv0_ab_width(int C0) { return C0 > MAXK + MAXK * MAXK ? C0 : MAXK + MAXK * MAXK; }
-long fh_conv0_fused_scratch_n(int B, int T0, int C0) {
+long fh_conv0_fused_scratch_n(int B, int T0, int C0) {   // (one block of backward sums per utterance: the GEMM epilogue accumulates)
   const long nchunk = fh_conv0_nchunk(T0);
-  return 2L * B * nchunk * C0 + 2L * B * fh_conv0_ab_width(C0) + (long)B * nchunk * C0 * (MAXK + 2);
+  return 2L * B * nchunk * C0 + 2L * B * fh_conv0_ab_width(C0) + (long)B * C0 * (MAXK + 2);
 }
 long fh_conv0_scratch_n(int B, int T0, int C0) {
   const long nchunk = fh_conv0_nchunk(T0);

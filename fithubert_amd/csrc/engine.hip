@@ -339,7 +339,7 @@ struct WsLayout {
 // FH_CONV0_FUSED_BWD=0 restores the two kernels (A/B)
 inline bool conv0_bwd_fusable(const fh_student_config& c) {
   static const int on = [] { const char* e = getenv("FH_CONV0_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on && c.dtype != 0 && c.n_conv >= 2 && c.conv_k[1] == 1 && c.conv_stride[1] == 1 && c.conv_dim[0] == 128 && c.conv_k[0] <= 10 &&
+  return on && c.dtype != 0 && c.n_conv >= 2 && c.conv_k[1] == 1 && c.conv_stride[1] == 1 && c.conv_dim[0] == 128 && c.conv_k[0] == 10 /* the epilogue's and the combine's sum layouts agree at 10 taps */ &&
          256 * c.conv_stride[0] + 16 <= 2048 && c.feature_grad_mult > 0.f;
 }
 
