@@ -1186,8 +1186,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     g.C = x.W(p.dx1tr);
     g.M = (int)M2; g.N = s.f * D; g.Kseg = D;
     g.ldc = (long)s.f * D; g.c_rpb = s.T2; g.c_bstride = (long)s.Tp * D;
-    RC(fh_gemm_launch(g, dt, x.st));
-    RC(fh_zero_rows_launch(dt, x.W(p.dx1tr), B, s.Tp, D, s.f * s.T2, x.st));
+    RC(fh_gemm_launch(g, dt, x.st));   // (the frames past f x T2, which the conv does not reach, were zeroed at the head of the backward)
     GemmOperand A = fh_operand(x.W(p.x1), FH_R_STRIDED, (long)s.f * D);
     A.rpb = s.T2; A.bstride = (long)s.Tp * D;
     RC(wgrad(x, dy_next, D, A, grads + p.pl.tr_w, D, s.f * D, M2, 1, 0, 0, /*jdiv*/ D, /*sj1*/ 1, /*sj0*/ s.f, 0, 0, 0,
@@ -1203,10 +1202,6 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
                              (int)s.Mp, D, x.drop(c.dropout, SITE_ENC), x.drop(0.f, 0), x.st));
   RC(fh_posconv_bwd_data_launch(dt, x.W(p.dpsum), x.W(p.zc), x.rel(p.wl.pos_wb), x.W(p.dzc), x.W(p.dx0), B, s.Tp, D,
                                 c.conv_pos_groups, c.conv_pos, x.st));
-  {
-    const long cp = fh_posconv_cp(D / c.conv_pos_groups);
-    RC((int)hipMemsetAsync(x.W(p.pos_dws), 0, (long)c.conv_pos_groups * c.conv_pos * cp * cp * 4, x.st));
-  }
   RC(fh_posconv_bwd_weight_launch(dt, x.W(p.dzc), x.W(p.x0), x.W<float>(p.pos_dws), grads + p.pl.pos_b, B, s.Tp, D,
                                   c.conv_pos_groups, c.conv_pos, x.st));
   RC(fh_posconv_wn_bwd_launch(x.params + p.pl.pos_g, x.params + p.pl.pos_v, (const float*)x.rel(p.wl.pos_norm),
@@ -1375,7 +1370,19 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
   g_notify.seg = 0;
   g_notify.heads_done = g_notify.layers_done = false;
   int rc = 0;
-  if (conv0_bwd_fusable(x.p.c) && x.p.c.feature_grad_mult > 0.f) {
+  {
+    // small fills whose consumers sit deep in the backward, issued HERE: in front of their consumers each of them waited 0.2 - 0.7 ms
+    // for a CU beside the weight-gradient stream's large launches (per-dispatch timeline, tools/timeline_list.py) -- the frames of the
+    // time-reduction conv's data gradient that the conv does not reach, and the positional conv's weight-gradient accumulators
+    const Plan& p = x.p;
+    const fh_student_config& c = p.c;
+    const Shapes& s = p.sh;
+    const int D = c.embed_dim;
+    if (c.tr_factor > 0) rc = fh_zero_rows_launch(x.dt, x.W(p.dx1tr), s.B, s.Tp, D, s.f * s.T2, x.st);
+    const long cp = fh_posconv_cp(D / c.conv_pos_groups);
+    if (!rc) rc = (int)hipMemsetAsync(x.W(p.pos_dws), 0, (long)c.conv_pos_groups * c.conv_pos * cp * cp * 4, x.st);
+  }
+  if (!rc && conv0_bwd_fusable(x.p.c) && x.p.c.feature_grad_mult > 0.f) {
     // the utterances' blocks of conv-0 weight-gradient sums, which layer 1's data-gradient epilogue accumulates into: zeroed HERE, at
     // the head of the backward -- in front of that launch the 0.8 MB fill waited 0.74 ms for a CU beside the weight-gradient stream
     const Plan& p = x.p;
