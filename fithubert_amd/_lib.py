@@ -143,6 +143,7 @@ SIGNATURES = {
     "fh_gemm_stream_loops": (_I, [_P, C.c_uint]),
     "fh_gemm_last_loop": (_I, []),
     "fh_gemm_reserve_cus": (_I, [_I]),
+    "fh_gemm_stream_reserve_cus": (_I, [_P, _I]),
     "fh_gemm_tune": (_I, [_I]),
     "fh_gemm_tune_export": (_I, [_P, _P, _P, _I]),
     "fh_gemm_tune_import": (_I, [_P, _P, _P, _I]),

@@ -223,6 +223,16 @@ extern "C" int fh_gemm_reserve_cus(int n) {
   if (n >= 0) fh_g_reserve_cus = n;
   return old;
 }
+namespace { std::unordered_map<hipStream_t, int> g_stream_reserve; }
+int fh_stream_reserve_cus(hipStream_t st) {
+  if (g_stream_reserve.empty()) return 0;
+  auto it = g_stream_reserve.find(st);
+  return it == g_stream_reserve.end() ? 0 : it->second;
+}
+extern "C" int fh_gemm_stream_reserve_cus(fh_stream_t stream, int n) {
+  if (n > 0) g_stream_reserve[(hipStream_t)stream] = n; else g_stream_reserve.erase((hipStream_t)stream);
+  return 0;
+}
 extern "C" int fh_gemm_stream_loops(fh_stream_t stream, unsigned mask) {
   if (mask) g_stream_mask[(hipStream_t)stream] = mask; else g_stream_mask.erase((hipStream_t)stream);
   return 0;

@@ -20,6 +20,7 @@
 
 // host state shared by the translation units (defined in gemm.hip)
 extern int fh_g_reserve_cus, fh_g_last_loop, fh_g_last_splitk;
+int fh_stream_reserve_cus(hipStream_t st);   // CUs loop 8 leaves free on launches of this stream (gemm.hip: fh_gemm_stream_reserve_cus)
 
 namespace {
 
@@ -2470,7 +2471,8 @@ template <typename H> int launch_8ph_stream(const GemmParams& p, hipStream_t str
   if (total > 0x7fffffffL) return -122;
   // a persistent workgroup owns its CU's registers and LDS for the whole launch (up to milliseconds): with fh_gemm_reserve_cus the
   // grid leaves CUs free for kernels that must make progress meanwhile (the collective kernels of a data-parallel run)
-  int pgrid = (ncu - fh_g_reserve_cus) & ~7;
+  const int sres = fh_stream_reserve_cus(stream);
+  int pgrid = (ncu - (sres > fh_g_reserve_cus ? sres : fh_g_reserve_cus)) & ~7;
   if (pgrid < 8) pgrid = 8;
   dim3 grid((unsigned)(total < pgrid ? total : pgrid), 1, 1), block(512);
   const size_t smem = 131072 + 8 * EPS_WAVE;

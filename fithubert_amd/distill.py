@@ -171,11 +171,6 @@ class W2V2Distil:
         self._amp_host = torch.zeros(2, 8, dtype=torch.int32).pin_memory() if (self.amp and self.device.type == "cuda") else None
         self._amp_slot, self._amp_event = 0, None
         self.sync = GradSync(self.engine.grads)
-        if self.sync.active and self.device.type == "cuda":
-            # data parallel: RCCL's collective kernels run beside the step; the persistent GEMM loop (which otherwise owns every CU
-            # for the length of a launch) leaves one CU per XCD to them
-            from . import _lib as _L
-            _L.lib().fh_gemm_reserve_cus(8)
         if os.environ.get("FH_RESERVE_CUS") and self.device.type == "cuda":   # A/B: CUs the persistent GEMM loop leaves to other kernels
             from . import _lib as _L
             _L.lib().fh_gemm_reserve_cus(int(os.environ["FH_RESERVE_CUS"]))
@@ -186,6 +181,13 @@ class W2V2Distil:
         # the frozen teacher runs on its own HIP stream: its forward for batch i+1 overlaps the student's forward /
         # backward of batch i (and the gradient all-reduce), filling CUs the student's short kernels leave idle
         self.teacher_stream = _low_priority_stream(self.device) if self.device.type == "cuda" else None
+        if self.sync.active and self.teacher_stream is not None:
+            # data parallel: RCCL's collective kernels run beside the step.  A persistent GEMM launch owns every CU it runs on until
+            # it ends; the frozen teacher's (low-priority stream, up to 1.6 ms a launch) leave one CU per XCD to the collectives --
+            # the student's own persistent launches end within 0.1 - 0.4 ms and keep all CUs (FH_DP_RESERVE_CUS overrides the 8;
+            # a guess until a multi-GPU node has timed it: SCALE runs have been skipped so far)
+            from . import _lib as _L
+            _L.lib().fh_gemm_stream_reserve_cus(self.teacher_stream.cuda_stream, int(os.environ.get("FH_DP_RESERVE_CUS", "8")))
         if os.environ.get("FH_TEACHER_STREAM", "1") == "0":   # A/B: teacher serialised on the main stream
             self.teacher_stream = None
         # FH_TEACHER_LOOPS / FH_STUDENT_LOOPS = comma-separated GEMM main loops a stream's per-shape choice may use (fh_gemm_stream_loops)

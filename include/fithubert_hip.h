@@ -140,6 +140,10 @@ int fh_gemm_last_loop(void);
  * A persistent workgroup holds its CU's registers and LDS for the whole launch, so kernels of other streams that must make
  * progress meanwhile -- RCCL's collectives in a data-parallel run (train.py:494) -- need CUs it does not occupy. */
 int fh_gemm_reserve_cus(int n);
+/* The same for the launches of ONE stream (n <= 0 removes the entry; the larger of the two values applies): a data-parallel run holds
+ * CUs back on the frozen teacher's low-priority stream only -- its persistent launches are the long ones (up to 1.6 ms), the
+ * student's leave every CU within ~0.1 - 0.4 ms. */
+int fh_gemm_stream_reserve_cus(fh_stream_t stream, int n);
 /* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
  * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the
  * output several times -- only for throw-away passes (StudentEngine.autotune).  mode 0: stop measuring; unmeasured shapes

@@ -437,6 +437,13 @@ def test_streaming_8_phase_loop(M, N, K, groups, opts):
             finally:
                 L.lib().fh_gemm_reserve_cus(prev)
             assert torch.equal(got40, base)
+            # ... and the per-stream form (what a data-parallel run sets on the frozen teacher's stream)
+            L.lib().fh_gemm_stream_reserve_cus(_stream(), 40)
+            try:
+                got40s, _ = run(8)
+            finally:
+                L.lib().fh_gemm_stream_reserve_cus(_stream(), 0)
+            assert torch.equal(got40s, base)
     finally:
         L.lib().fh_gemm_set_path(9)
     assert not torch.isnan(got.float()).any()
