@@ -155,6 +155,50 @@ def cpu_baseline(cfg, seconds_budget: float = 28.0):
             "sweep": sweep}
 
 
+def kd_loss_delta(dev, fixture: str = "student_full_10s"):
+    """The second half of BASELINE.json's metric, "KD-loss delta vs ref", measured in THIS run: an eval forward (dropout off) of the
+    HIP engine in each compute mode on the committed golden fixture of BASELINE.json configs[1]'s utterance size (2 x 160,000 samples,
+    full 12-layer fithubert.yaml student; tests/golden/student_full_10s.npz holds the UNMODIFIED reference's loss on the same seeded
+    weights, waveform and stand-in teacher tensors -- oracle/gen_golden.py) and the difference of the fused KD-loss kernel's total
+    from the reference's (train.py:236-378).  Checker leg, like cpu_baseline: the oracle package is used only to regenerate the
+    fixture's seeded weights; what is measured is the HIP path, what it is compared with is the reference's recorded number."""
+    import numpy as np
+    from fithubert_amd.config import CustomStudentModelConfig
+    from fithubert_amd.engine import StudentEngine
+    from oracle.student_ref import random_state_dict   # seeded weights of the fixture (test infrastructure, checker use only)
+
+    fx = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+    cfg = dict(yaml.safe_load(str(fx["cfg_yaml"])), dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    sd = random_state_dict(cfg, seed=int(fx["weight_seed"]))
+    n, lens = int(fx["samples"]), [int(v) for v in fx["lengths"]]
+    wav = float(fx["wav_rms"]) * torch.randn(2, n, generator=torch.Generator().manual_seed(int(fx["wav_seed"])))
+    assert np.allclose(wav[:, :64].numpy(), fx["wav_head"]), "fixture waveform not reproduced"
+    for b, m in enumerate(lens):
+        wav[b, m:] = 0
+    tg = torch.Generator().manual_seed(int(fx["teacher_seed"]))
+    Tt, rl = int(fx["teacher_T"]), [int(v) for v in fx["rand_l"]]
+    teacher = torch.stack([torch.randn(Tt, 2, 768, generator=tg).transpose(0, 1) for _ in range(12)]).contiguous().to(dev)
+    w = torch.zeros(12); w[rl] = 0.1; w[11] = 1.0
+    ref, ref_layers = float(fx["loss"]), np.asarray(fx["layer_losses"], dtype=np.float64)
+    out = {"fixture": f"tests/golden/{fixture}.npz", "reference_loss": ref,
+           "what": "HIP engine eval forward + fused KD-loss kernel, total loss minus the unmodified reference's fp32 loss on identical seeded "
+                   "weights / waveform / teacher tensors (2 x 10 s, full fithubert.yaml student, dropout off); target 1e-4 (north star)"}
+    for dtype in ("float32", "bf16", "float16"):
+        eng = StudentEngine(CustomStudentModelConfig(**cfg), dtype=dtype, device=dev)
+        eng.load_state_dict(sd)
+        ws = eng.forward(wav.to(dev), lens if min(lens) < n else None, training=False)
+        res, _ = eng.kd_loss(ws, teacher, w.to(dev), torch.arange(12, dtype=torch.int32, device=dev), want_grad=False)
+        res = res.double().cpu().numpy()
+        out[dtype] = float(res[12] - ref)
+        want = np.zeros(12)                       # the fixture holds the WEIGHTED terms in rand_l order, then the last layer
+        want[rl] = ref_layers[:len(rl)] / 0.1
+        want[11] = ref_layers[-1]
+        out[dtype + "_max_layer_delta"] = float(np.abs(res[:12] - want).max())   # unweighted per-layer means
+        del eng, ws
+        torch.cuda.empty_cache()
+    return out
+
+
 def time_steps(task, batches, steps: int, warm: int):
     """-> (seconds, utterances, valid samples) for `steps` training steps cycling over `batches`, after `warm` untimed ones."""
     n = len(batches)
@@ -366,6 +410,7 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3, help="timed steps (the last ones) with per-launch HIP-event GEMM timing")
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (fixed 2-16 s buckets, LibriSpeech-shaped "
                     "buckets, 24-layer student + Large teacher), which is measured after the timed region at N = 1")
+    ap.add_argument("--no-kd-delta", action="store_true", help="skip the in-run KD-loss parity measurement (kd_loss_delta)")
     ap.add_argument("--variants-budget", type=float, default=150.0, help="seconds the variants block may take (entries that do not fit are left out)")
     args = ap.parse_args()
 
@@ -520,7 +565,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         res = {
-            "metric": "distillation utterances/sec (10 s@16 kHz)",
+            "metric": "distillation utterances/sec (10 s@16 kHz); KD-loss delta vs ref in kd_loss_delta",
             "value": round(value, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
@@ -539,6 +584,11 @@ def main():
             "final_loss": loss,
             "roofline": roof,
         }
+        if world == 1 and not args.no_kd_delta:
+            try:
+                res["kd_loss_delta"] = kd_loss_delta(dev)
+            except Exception as e:
+                res["kd_loss_delta"] = {"error": repr(e)}
         if world == 1 and not variant and not args.no_variants:
             try:
                 res["variants"] = run_variants(task, cfg, args, dev, args.variants_budget)

@@ -144,6 +144,10 @@ SIGNATURES = {
     "fh_gemm_last_loop": (_I, []),
     "fh_gemm_reserve_cus": (_I, [_I]),
     "fh_gemm_stream_reserve_cus": (_I, [_P, _I]),
+    "fh_stream_create_cu_range": (_I, [_I, _I, C.POINTER(_P)]),
+    "fh_stream_destroy": (_I, [_P]),
+    "fh_stream_cu_census": (_I, [_P, _I, _P]),
+    "fh_student_side_stream": (_I, [_P]),
     "fh_gemm_tune": (_I, [_I]),
     "fh_gemm_tune_export": (_I, [_P, _P, _P, _I]),
     "fh_gemm_tune_import": (_I, [_P, _P, _P, _I]),

@@ -520,10 +520,16 @@ inline int splitk_for(long tiles, long red) {
 // stream (end of backward: the workspace goes back to the allocator only after that).  Off while the GEMM tuner is timing
 // launches, and with FH_WGRAD_STREAM=0.
 struct SideStream {
-  hipStream_t s = nullptr;
+  hipStream_t s = nullptr, own = nullptr;
   hipEvent_t ev[32];
   int next = 0, state = -1;  // -1 unknown, 0 off, 1 on
   bool used = false;
+  // fh_student_side_stream: the caller's stream (e.g. one restricted to a share of the CUs) in place of the library's own
+  void replace(hipStream_t caller) {
+    on();
+    if (!own) own = s;
+    s = caller ? caller : own;
+  }
   bool on() {
     if (state < 0) {
       const char* e = getenv("FH_WGRAD_STREAM");
@@ -1472,6 +1478,11 @@ int fh_student_frames(const fh_student_config* c, int S, int* T_conv, int* T_enc
   if (T_conv) *T_conv = s.Tp;
   if (T_enc) *T_enc = s.T2;
   return 0;
+}
+
+int fh_student_side_stream(fh_stream_t stream) {
+  g_wside.replace((hipStream_t)stream);
+  return g_wside.state == 1 ? 0 : 1;
 }
 
 int fh_student_prepare(const fh_student_config* c, const float* params, void* wc, fh_stream_t stream) {

@@ -233,6 +233,49 @@ extern "C" int fh_gemm_stream_reserve_cus(fh_stream_t stream, int n) {
   if (n > 0) g_stream_reserve[(hipStream_t)stream] = n; else g_stream_reserve.erase((hipStream_t)stream);
   return 0;
 }
+// A HIP stream whose kernels may only run on `count` CUs (hipExtStreamCreateWithCUMask): mask bits [first, first + count) of the
+// device's CU mask.  The KFD deals consecutive mask bits round-robin over the XCDs, so a contiguous bit range is an (almost) equal
+// share of every XCD (tools/cu_partition.py prints the census of a masked launch).  Loop 8's persistent grid on that stream is
+// sized to the share (fh_gemm_stream_reserve_cus).
+extern "C" int fh_stream_create_cu_range(int first, int count, fh_stream_t* out) {
+  if (!out || first < 0 || count < 1) return -1;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -121;
+  const int ncu = prop.multiProcessorCount;
+  if (first + count > ncu) return -2;
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> mask(words, 0u);
+  for (int i = first; i < first + count; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) return -3;
+  *out = (fh_stream_t)st;
+  if (count < ncu) g_stream_reserve[st] = ncu - (count & ~7);
+  return 0;
+}
+// Where a launch on `stream` lands: one 64-thread workgroup per entry records (XCC id << 16 | HW_ID[15:0]) after spinning ~20 us so
+// that the workgroups spread over every CU the stream may use.
+namespace {
+__global__ void cu_census_kernel(unsigned* out) {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf;    // HW_REG_XCC_ID[3:0]
+  const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) & 0xffff;  // HW_REG_HW_ID: wave / simd / pipe / cu / sh / se
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < 2000) {}                               // 100 MHz ticks
+  if (threadIdx.x == 0) out[blockIdx.x] = xcc << 16 | hw;
+}
+}  // namespace
+extern "C" int fh_stream_cu_census(unsigned* out, int n, fh_stream_t stream) {
+  if (!out || n < 1) return -1;
+  hipLaunchKernelGGL(cu_census_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int fh_stream_destroy(fh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!st) return 0;
+  g_stream_reserve.erase(st);
+  g_stream_mask.erase(st);
+  return hipStreamDestroy(st) == hipSuccess ? 0 : -1;
+}
 extern "C" int fh_gemm_stream_loops(fh_stream_t stream, unsigned mask) {
   if (mask) g_stream_mask[(hipStream_t)stream] = mask; else g_stream_mask.erase((hipStream_t)stream);
   return 0;

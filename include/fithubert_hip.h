@@ -144,6 +144,14 @@ int fh_gemm_reserve_cus(int n);
  * CUs back on the frozen teacher's low-priority stream only -- its persistent launches are the long ones (up to 1.6 ms), the
  * student's leave every CU within ~0.1 - 0.4 ms. */
 int fh_gemm_stream_reserve_cus(fh_stream_t stream, int n);
+/* A HIP stream restricted to `count` of the device's CUs: bits [first, first + count) of the CU mask (hipExtStreamCreateWithCUMask;
+ * consecutive bits are dealt round-robin over the 8 XCDs, so a contiguous range is an equal share of every XCD).  Partitions the chip
+ * between the frozen teacher's forward (train.py:131-134) and the student's forward / backward instead of letting their kernels share
+ * CUs; the persistent GEMM loop sizes its grid to the share.  The handle is a hipStream_t; fh_stream_destroy releases it. */
+int fh_stream_create_cu_range(int first, int count, fh_stream_t* out);
+int fh_stream_destroy(fh_stream_t stream);
+/* Diagnostic: n single-wave workgroups on `stream`, each writing (XCC id << 16 | HW_REG_HW_ID[15:0]) -- which CUs a stream reaches. */
+int fh_stream_cu_census(unsigned* out, int n, fh_stream_t stream);
 /* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
  * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the
  * output several times -- only for throw-away passes (StudentEngine.autotune).  mode 0: stop measuring; unmeasured shapes
@@ -335,6 +343,10 @@ int fh_student_ws_info(const fh_student_config* c, const fh_student_call* k, con
 /* frames after the conv frontend / after time reduction for S samples */
 int fh_student_frames(const fh_student_config* c, int S, int* T_conv, int* T_enc);
 
+/* The stream the student's backward issues its parameter gradients on (weight / bias gradients whose only consumer is the optimizer,
+ * train.py:407-421): by default a lowest-priority stream of the library; a caller that partitions the chip's CUs between streams
+ * (fh_stream_create_cu_range) hands its own here.  NULL restores the library's.  Returns 0, or 1 when side-stream issue is off. */
+int fh_student_side_stream(fh_stream_t stream);
 /* fp32 master params -> compute-dtype / kernel-layout weights (once per optimizer step) */
 int fh_student_prepare(const fh_student_config* c, const float* params, void* wc, fh_stream_t stream);
 /* lens: device int [2][B] = valid frames after the frontend, valid frames after time reduction; NULL = no padding */

@@ -3,7 +3,7 @@ captured from the reference.
 
 Tolerances: dtype float (exact-fp32 MFMA): hidden states <= 2e-4 of the tensor scale, KD loss <= 1e-4 absolute
 (the north star's parity figure), gradients <= 2e-3 relative.  dtype bf16: hidden states rel-L2 <= 2e-2, KD loss
-<= 1.5e-3 relative on the full config (measured 0.7-2.5e-4; 2.3-5.6e-4 of it is the rounding of the WEIGHTS to bf16 alone,
+within BF16_LOSS_TOL_ABS ABSOLUTE per fixture (<= 2 x measured; 2.3-5.6e-4 of it is the rounding of the WEIGHTS to bf16 alone,
 DESIGN.md section 2), gradient norms <= 6e-2 relative (bf16 keeps 8 significant bits).  dtype float16 (IEEE half operands, the
 reference's own AMP precision, train.py:469,496): hidden states rel-L2 <= 4e-3, KD loss within FP16_LOSS_TOL ABSOLUTE of the fp32
 reference -- the bound is the deviation of the reference's own AMP arithmetic from its fp32 arithmetic on the same inputs
@@ -28,7 +28,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # arithmetic (the unmodified reference under torch.autocast(float16), tools/ref_amp_delta.py -> profiles/r03_reference_amp_delta.txt)
 # deviates by -1.78e-4 on the 2 s fixture: no fp16 computation can promise less than the reference's own.  Measured values of this
 # build are printed by the tests (pytest -s) and recorded in DESIGN.md section 2.
-FP16_LOSS_TOL = {"student_full_2s": 3e-4, "student_full_10s": 3e-4, "student_full_libri_max": 3e-4}
+# Round 4: bounds at <= 2 x the measured deviation (profiles/r03_fp16_loss_delta.txt: -1.59e-4 / -1.06e-4 / -1.35e-4).
+FP16_LOSS_TOL = {"student_full_2s": 2.5e-4, "student_full_10s": 2e-4, "student_full_libri_max": 2e-4}
+# bf16, ABSOLUTE, per fixture, <= 2 x measured (-1.30e-3 / -1.00e-3 / -4.1e-4; 2.3 - 5.6e-4 of it is rounding the WEIGHTS to bf16 alone)
+BF16_LOSS_TOL_ABS = {"student_full_2s": 2.2e-3, "student_full_10s": 1.8e-3, "student_full_libri_max": 8e-4}
 
 
 def _rel_max(a, b):
@@ -183,7 +186,7 @@ def test_full_fithubert_config_2s(dtype, tol_l2, golden_dir):
     loss = out[12].item()
     ref = float(fx["loss"])
     print(f"\n[KD-loss parity] student_full_2s {dtype}: loss {loss:.6f} reference {ref:.6f} delta {loss - ref:+.2e}")
-    tol = {"float32": 1e-4, "bf16": 1.5e-3 * ref, "float16": FP16_LOSS_TOL["student_full_2s"]}[dtype]   # bf16 measured 2.4e-4 relative
+    tol = {"float32": 1e-4, "bf16": BF16_LOSS_TOL_ABS["student_full_2s"], "float16": FP16_LOSS_TOL["student_full_2s"]}[dtype]   # absolute
     assert abs(loss - ref) < tol, (loss, ref)
     # padded pair
     lens = [int(n) for n in fx["pad_from"]]
@@ -513,7 +516,7 @@ def test_frozen_extractor_feature_grad_mult_zero_gradients_are_complete_and_stab
 
 # bf16 KD-loss deviation from the reference (eval forward, identical weights / inputs): the test bound per fixture.  Measured values
 # are printed by the test (pytest -s) and recorded in DESIGN.md section 2.
-BF16_LOSS_TOL = {"student_full_10s": 1.5e-3, "student_full_libri_max": 1.5e-3}   # measured 2.4e-4 / 1.0e-4 (tools/bf16_delta.py, profiles/r02_bf16_loss_delta.txt)
+BF16_LOSS_TOL = BF16_LOSS_TOL_ABS   # ABSOLUTE since round 4 (was 1.5e-3 relative = 6e-3 absolute)
 
 
 @pytest.mark.parametrize("name", ["student_full_10s", "student_full_libri_max"])
@@ -574,7 +577,7 @@ def test_full_config_at_baseline_and_librispeech_sizes(name, dtype, tol_l2, tol_
     elif dtype == "float16":
         assert abs(loss - ref) < FP16_LOSS_TOL[name], (loss, ref)            # ABSOLUTE
     else:
-        assert abs(loss - ref) < BF16_LOSS_TOL[name] * ref, (loss, ref)
+        assert abs(loss - ref) < BF16_LOSS_TOL[name], (loss, ref)            # ABSOLUTE
     bad = []
     for k, gv in eng.param_views(eng.grads).items():
         key = "gradnorm/" + k
