@@ -50,8 +50,8 @@ def balanced_rank_buckets(bucket_samples: Sequence[int], epoch: int, rank: int, 
     """Per step every rank takes a bucket from the same length neighbourhood (buckets are length-sorted), so the
     per-step work is balanced across ranks; the order of the steps is shuffled per epoch."""
     order = sorted(range(len(bucket_samples)), key=lambda i: -bucket_samples[i])
-    pad = (-len(order)) % world
-    order += order[:pad]
+    while len(order) % world:          # the last group repeats its own shortest bucket (padding with the head of the list, as the
+        order.append(order[-1])        # plain deal does, paired the shortest bucket with the longest)
     groups = [order[i:i + world] for i in range(0, len(order), world)]
     random.Random(seed + epoch).shuffle(groups)
     return [g[rank] for g in groups]

@@ -541,16 +541,34 @@ class W2V2Distil:
         return {"v_loss": total}
 
     def fit(self, train_data, eval_data=None, num_epochs: Optional[int] = None, output_dir: Optional[str] = None, patience: int = 15,
-            save_top_k: int = 3, rank: int = 0, world: int = 1, log=None) -> Dict[str, object]:
+            save_top_k: int = 3, rank: int = 0, world: int = 1, log=None, balance: Optional[bool] = None) -> Dict[str, object]:
         """The reference's Trainer configuration in one loop (train.py:475-501): shuffled length buckets dealt out rank-strided,
         gradient accumulation, ``training_epoch_end`` re-sampling, validation ``v_loss`` per epoch, ModelCheckpoint(save_last,
         save_top_k=3, monitor v_loss) and EarlyStopping(patience 15).  Datasets index whole buckets (``LibriDataset`` /
-        ``SyntheticLibriDataset``)."""
+        ``SyntheticLibriDataset``).
+
+        ``balance`` (default: on for world > 1 when the dataset reports ``bucket_samples()``): the ranks of one step take buckets
+        from the same LENGTH neighbourhood (``dataset.balanced_rank_buckets``) instead of DistributedSampler's rank-strided deal
+        of a shuffled list (utils/dataset.py:27-53 sorts by length, so a plain deal pairs a 24 s bucket with a 2 s one and every
+        step waits for the longest); the order of the steps is still shuffled per epoch with the shared seed.  Every rank
+        sees ceil(n / world) buckets either way."""
         import os as _os
-        from .dataset import rank_buckets, to_device
+        from .dataset import balanced_rank_buckets, rank_buckets, to_device
         num_epochs = int(num_epochs if num_epochs is not None else self.train_cfg["num_epochs"])
-        per_rank = max(1, len(train_data) // max(1, world))
-        steps_per_epoch = -(-per_rank // max(1, self.accumulate))   # the partial window at the epoch end is stepped too (flush_accumulation)
+        if balance is None:
+            balance = world > 1 and hasattr(train_data, "bucket_samples")
+        bucket_samples = list(train_data.bucket_samples()) if balance else None
+
+        def epoch_order(epoch):
+            if balance:
+                return balanced_rank_buckets(bucket_samples, epoch, rank, world, seed=0)
+            return rank_buckets(len(train_data), epoch, rank, world, seed=0, shuffle=True)
+
+        # optimizer steps fit() really takes per epoch: every rank walks ceil(n / world) buckets (the deal pads to a multiple of
+        # world) and the partial accumulation window at the epoch end is stepped too (flush_accumulation) -- deliberately not the
+        # reference's floor(num_epochs * batches / accumulate) of train.py:412, which leaves the last steps of a run at lr = 0
+        per_rank = -(-len(train_data) // max(1, world))
+        steps_per_epoch = -(-per_rank // max(1, self.accumulate))
         if not self.num_training_steps:
             self.configure_optimizers(max(1, steps_per_epoch * num_epochs))
         first_epoch = 0
@@ -567,7 +585,7 @@ class W2V2Distil:
             bad_epochs, best_v = int(es.get("wait_count", 0)), float(es.get("best_score", float("inf")))
             best = [(float(v), str(pth)) for v, pth in mc.get("best_k_models", [])]
         for epoch in range(first_epoch, num_epochs):
-            order = rank_buckets(len(train_data), epoch, rank, world, seed=0, shuffle=True)
+            order = epoch_order(epoch)
             nxt = to_dev(train_data[order[0]])
             tl = None
             for i, _ in enumerate(order):

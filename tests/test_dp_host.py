@@ -312,3 +312,40 @@ def test_bench_gpus_n_without_launcher_refuses_cleanly_when_devices_are_missing(
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode not in (0, 2) and "needs 2 visible devices" in r.stderr and "torch.distributed.run" not in r.stderr
     assert r.stdout.strip() == ""                                         # no JSON line
+
+
+def test_fit_walks_balanced_buckets_under_data_parallel_and_sizes_the_schedule_to_the_steps_taken():
+    """fit() with world > 1 (round 4): every step's ranks draw buckets from one length neighbourhood (dataset.balanced_rank_buckets
+    over the dataset's bucket_samples(); utils/dataset.py:27-53 sorts by length, so DistributedSampler's plain deal makes every
+    step wait for the rank holding the longest bucket), each bucket is visited once per epoch over the ranks, and the warm-up /
+    decay schedule is as long as the optimizer steps really taken (ceil(ceil(n / world) / accumulate) per epoch)."""
+    from fithubert_amd.dataset import SyntheticLibriDataset, balanced_rank_buckets, rank_buckets
+    lens = [400 + 37 * i for i in range(26)]                    # 13 buckets of 2, length-sorted by the dataset
+    seen = {}
+    for balance in (True, False):
+        per_step = []
+        for rank in range(2):
+            from fithubert_amd.distill import W2V2Distil
+            ds = SyntheticLibriDataset(lens, batch_size=2, seed=0)
+            task = W2V2Distil(_cfg(accumulate=2), dtype="float32", device="cpu", teacher=StubTeacher(), seed=0, student_model=StubStudent())
+            walked = []
+            orig = task.training_step
+
+            def spy(batch, batch_idx=0, next_batch=None, _o=orig, _w=walked):
+                _w.append(int(batch["x"].shape[1]))
+                return _o(batch, batch_idx=batch_idx, next_batch=next_batch)
+
+            task.training_step = spy
+            task.fit(ds, num_epochs=1, rank=rank, world=2, balance=balance)
+            assert len(walked) == 7                               # ceil(13 / 2) buckets per rank
+            assert task.num_training_steps == 4 == task.opt_step  # ceil(7 / 2): the schedule ends with the last step, not before it
+            per_step.append(walked)
+        spread = [abs(a - b) for a, b in zip(*per_step)]
+        seen[balance] = max(spread)
+        covered = sorted(per_step[0] + per_step[1])
+        tops = sorted(max(lens[i] for i in b) for b in SyntheticLibriDataset(lens, 2).buckets)
+        assert len(set(covered)) == 13 and set(covered) == set(tops)   # every bucket visited (one repeated to pad the deal)
+    assert seen[True] <= 2 * 37 * 2 and seen[False] > seen[True]      # neighbours in the sorted list vs anything
+    # the default: balanced under world > 1, the reference's plain deal on one rank
+    ds = SyntheticLibriDataset(lens, batch_size=2, seed=0)
+    assert balanced_rank_buckets(ds.bucket_samples(), 0, 1, 2) != rank_buckets(len(ds), 0, 1, 2)
