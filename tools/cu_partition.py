@@ -52,8 +52,19 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--configs", default="base,t224,t192,t160,t128,t192_s64,t160_s96,t128_s128,t192_w64,t160_w96,t128_w128,base")
+    ap.add_argument("--configs", default="t224,t192,t160,t128,t192_s64,t160_s96,t128_s128,t96_s160,t160_s128,t192_s128,t128_s192,t192_w64,t128_w128")
+    ap.add_argument("--one", default="", help="(internal) measure base / this config / base in this process and print one JSON line")
+    ap.add_argument("--census", action="store_true")
     args = ap.parse_args()
+    if not args.one and not args.census:
+        # one fresh process per configuration: every masked stream is a hardware queue of its own, and streams created for earlier
+        # configurations of the same process kept their queues (the first version of this tool degraded from 52 to 90 ms that way)
+        import subprocess
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--census"])
+        for name in args.configs.split(","):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name, "--batch", str(args.batch), "--steps", str(args.steps),
+                            "--warmup", str(args.warmup)])
+        return
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     with open(os.path.join(ROOT, "conf", "fithubert.yaml")) as f:
@@ -64,11 +75,12 @@ def main():
     pool = [fixed_length_batch(args.batch, 160000, seed=i, device=str(dev)) for i in range(4)]
     lib = L.lib()
 
-    # census: what a contiguous mask range reaches
-    for first, count in ((0, 256), (0, 128), (128, 128), (0, 64), (192, 64), (0, 32)):
-        st = masked_stream(first, count, dev)
-        print(json.dumps({"census": f"bits [{first}, {first + count})", "cus_per_xcc": census(st)}), flush=True)
-    print(json.dumps({"census": "default stream", "cus_per_xcc": census(None)}), flush=True)
+    if args.census:   # what a contiguous mask range reaches
+        for first, count in ((0, 256), (0, 128), (128, 128), (192, 64), (0, 32)):
+            st = masked_stream(first, count, dev)
+            print(json.dumps({"census": f"bits [{first}, {first + count})", "cus_per_xcc": census(st)}), flush=True)
+        print(json.dumps({"census": "default stream", "cus_per_xcc": census(None)}), flush=True)
+        return
 
     default_teacher = task.teacher_stream
     step_no = [0]
@@ -81,33 +93,41 @@ def main():
 
     run(args.warmup)       # tunes the GEMM table on the default streams
     torch.cuda.synchronize()
-    for name in args.configs.split(","):
-        t_n = s_m = w_m = 0
-        for tok in name.split("_"):
-            if tok.startswith("t"):
-                t_n = int(tok[1:])
-            elif tok.startswith("s"):
-                s_m = int(tok[1:])
-            elif tok.startswith("w"):
-                w_m = int(tok[1:])
-        task._next_teacher = None
+
+    def timed(n):
+        run(2)
         torch.cuda.synchronize()
-        task.teacher_stream = masked_stream(256 - t_n, t_n, dev) if t_n else default_teacher
-        side = masked_stream(0, s_m or w_m, dev) if (s_m or w_m) else None
-        lib.fh_student_side_stream(side.cuda_stream if side is not None else None)
-        main_st = masked_stream(0, s_m, dev) if s_m else torch.cuda.current_stream(dev)
-        with torch.cuda.stream(main_st):
-            run(2)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(args.steps)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.steps
-        task._next_teacher = None
+        t0 = time.perf_counter()
+        run(n)
         torch.cuda.synchronize()
-        print(json.dumps({"config": name, "teacher_cus": t_n or 256, "student_cus": s_m or 256, "wgrad_stream_cus": (s_m or w_m) or 256,
-                          "ms_per_step": round(dt * 1e3, 3), "utt_per_s": round(args.batch / dt, 1)}), flush=True)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    name = args.one
+    t_n = s_m = w_m = 0
+    for tok in name.split("_"):
+        if tok.startswith("t"):
+            t_n = int(tok[1:])
+        elif tok.startswith("s"):
+            s_m = int(tok[1:])
+        elif tok.startswith("w"):
+            w_m = int(tok[1:])
+    base0 = timed(args.steps)
+    task._next_teacher = None
+    torch.cuda.synchronize()
+    task.teacher_stream = masked_stream(256 - t_n, t_n, dev) if t_n else default_teacher
+    side = masked_stream(0, s_m or w_m, dev) if (s_m or w_m) else None
+    lib.fh_student_side_stream(side.cuda_stream if side is not None else None)
+    main_st = masked_stream(0, s_m, dev) if s_m else torch.cuda.current_stream(dev)
+    with torch.cuda.stream(main_st):
+        part = timed(args.steps)
+    task._next_teacher = None
+    torch.cuda.synchronize()
+    task.teacher_stream = default_teacher
     lib.fh_student_side_stream(None)
+    base1 = timed(args.steps)
+    print(json.dumps({"config": name, "teacher_cus": t_n or 256, "student_cus": s_m or 256, "wgrad_stream_cus": (s_m or w_m) or 256,
+                      "ms_per_step": round(part, 3), "base_before_ms": round(base0, 3), "base_after_ms": round(base1, 3),
+                      "vs_base": round(part / (0.5 * (base0 + base1)), 4), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default")}), flush=True)
 
 
 if __name__ == "__main__":
