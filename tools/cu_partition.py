@@ -67,6 +67,13 @@ def main():
         return
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    if args.census:   # what a contiguous mask range reaches
+        for first, count in ((0, 256), (0, 128), (128, 128), (192, 64), (0, 32)):
+            st = masked_stream(first, count, dev)
+            print(json.dumps({"census": f"bits [{first}, {first + count})", "cus_per_xcc": census(st)}), flush=True)
+        print(json.dumps({"census": "default stream", "cus_per_xcc": census(None)}), flush=True)
+        return
+
     with open(os.path.join(ROOT, "conf", "fithubert.yaml")) as f:
         cfg = yaml.load(f, Loader=yaml.FullLoader)
     cfg["train"]["accumulate_grad_batches"] = 1
@@ -74,13 +81,6 @@ def main():
     task.configure_optimizers(num_training_steps=1000)
     pool = [fixed_length_batch(args.batch, 160000, seed=i, device=str(dev)) for i in range(4)]
     lib = L.lib()
-
-    if args.census:   # what a contiguous mask range reaches
-        for first, count in ((0, 256), (0, 128), (128, 128), (192, 64), (0, 32)):
-            st = masked_stream(first, count, dev)
-            print(json.dumps({"census": f"bits [{first}, {first + count})", "cus_per_xcc": census(st)}), flush=True)
-        print(json.dumps({"census": "default stream", "cus_per_xcc": census(None)}), flush=True)
-        return
 
     default_teacher = task.teacher_stream
     step_no = [0]
