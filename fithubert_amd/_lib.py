@@ -86,7 +86,7 @@ class StudentConfigC(C.Structure):
         ("layers", C.c_int), ("conv_pos", C.c_int), ("conv_pos_groups", C.c_int), ("tr_factor", C.c_int),
         ("pred_dim", C.c_int), ("dropout", C.c_float), ("attention_dropout", C.c_float),
         ("activation_dropout", C.c_float), ("dropout_input", C.c_float), ("feature_grad_mult", C.c_float),
-        ("n_tasks", C.c_int), ("inter_dim", C.c_int), ("cnn_head", C.c_int),
+        ("n_tasks", C.c_int), ("inter_dim", C.c_int), ("cnn_head", C.c_int), ("tr_index", C.c_int),
     ]
 
 

@@ -168,13 +168,13 @@ struct ParamLayout {
     pos_g = add("encoder.pos_conv.0.weight_g", {1, 1, c.conv_pos});
     pos_v = add("encoder.pos_conv.0.weight_v", {D, D / c.conv_pos_groups, c.conv_pos});
     tr_w = tr_b = -1;
-    if (c.tr_factor > 0) {
-      tr_w = add("encoder.layers.0.weight", {D, D, c.tr_factor});
-      tr_b = add("encoder.layers.0.bias", {D});
+    if (c.tr_factor > 0) {  // the TR conv is module tr_layer_index of encoder.layers (module.py:247-248)
+      tr_w = add("encoder.layers." + std::to_string(c.tr_index) + ".weight", {D, D, c.tr_factor});
+      tr_b = add("encoder.layers." + std::to_string(c.tr_index) + ".bias", {D});
     }
     layer0 = total;
     for (int l = 0; l < c.layers; ++l) {
-      const std::string p = "encoder.layers." + std::to_string(l + (c.tr_factor > 0 ? 1 : 0)) + ".";
+      const std::string p = "encoder.layers." + std::to_string(l + (c.tr_factor > 0 && l >= c.tr_index ? 1 : 0)) + ".";
       const long base = total;
       long o;
       o = add(p + "self_attn.q_proj.weight", {D, D}); if (!l) l_qkv_w = o - base;
@@ -200,7 +200,7 @@ struct ParamLayout {
     ups_w = ups_b = -1;
     const long f = c.tr_factor > 0 ? c.tr_factor : 1;
     if (c.tr_factor > 0) {
-      ups_w = add("upsampler.weight", {D, D, f});  // present in the reference state dict, never used (model.py:342-348)
+      ups_w = add("upsampler.weight", {D, D, f});  // model.py:341-348: used by the DistilHuBERT-style head only (model.py:503-506)
       ups_b = add("upsampler.bias", {D});
     }
     if (c.cnn_head) {
@@ -252,6 +252,16 @@ struct Shapes {
   int T[FH_MAX_CONV];  // frames after conv layer i
   int Tp, T2, f;       // frames after the frontend, after time reduction, reduction factor (1 if none)
   long Mp, M2;
+  // tr_layer_index > 0: transformer layers [0, idx) run on the Tp frames, [idx, L) on the T2 reduced ones.  Every per-layer array
+  // keeps ONE row stride Ms (= Mp then; M2 in the shipped idx == 0 layout, which is unchanged), a layer uses the first M(l) rows of
+  // its slot; `xo` gets one more slot: 0 = encoder LayerNorm output, l + 1 = output of layer l < idx, idx + 1 = TR output,
+  // l + 2 = output of layer l >= idx.
+  int idx, Ts;
+  long Ms;
+  int Tl(int l) const { return l < idx ? Tp : T2; }
+  long Ml(int l) const { return l < idx ? Mp : M2; }
+  int slot_in(int l) const { return l + (idx > 0 && l >= idx ? 1 : 0); }
+  int slots(int L) const { return L + 1 + (idx > 0 ? 1 : 0); }
 };
 
 inline int make_shapes(const fh_student_config& c, int B, int S, Shapes& s) {
@@ -268,6 +278,9 @@ inline int make_shapes(const fh_student_config& c, int B, int S, Shapes& s) {
   if (s.T2 < 1) return -801;
   s.Mp = (long)B * s.Tp;
   s.M2 = (long)B * s.T2;
+  s.idx = c.tr_factor > 0 ? c.tr_index : 0;
+  s.Ts = s.idx > 0 ? s.Tp : s.T2;
+  s.Ms = (long)B * s.Ts;
   return 0;
 }
 
@@ -367,7 +380,8 @@ struct Plan {
     ok = make_shapes(c, k.B, k.S, sh);
     if (ok != 0) return;
     const long B = k.B, D = c.embed_dim, Fd = c.ffn_dim, P = c.pred_dim, L = c.layers, H = c.heads;
-    const long Mp = sh.Mp, M2 = sh.M2;
+    const long Mp = sh.Mp, M2 = sh.M2, Ms = sh.Ms;
+    const int Ts = sh.Ts;
     const bool tr = k.training != 0;
     for (int i = 0; i < c.n_conv; ++i) {
       y[i] = ws.add("y" + std::to_string(i), {B, sh.T[i], c.conv_dim[i]}, es);
@@ -389,32 +403,34 @@ struct Plan {
     ln1_mean = ws.add("ln1_mean", {Mp}, 4);
     ln1_rstd = ws.add("ln1_rstd", {Mp}, 4);
     x1 = ws.add("x1", {B, sh.Tp, D}, es);
-    // slot 0 = input of layer 0 (time-reduced), slot l+1 = output of layer l
-    xo = ws.add("xo", {L + 1, B, sh.T2, D}, es);
-    qkv = ws.add("qkv", {L, M2, 3 * D}, es);
-    attn = ws.add("attn", {L, M2, D}, es);
-    lse = ws.add("lse", {L, B * H, sh.T2}, 4);
-    s1 = ws.add("s1", {L, M2, D}, es);
-    st1_mean = ws.add("st1_mean", {L, M2}, 4);
-    st1_rstd = ws.add("st1_rstd", {L, M2}, 4);
-    xa = ws.add("xa", {L, M2, D}, es);
-    z1 = ws.add("z1", {L, M2, Fd}, es);
-    hbuf = ws.add("h", {L, M2, Fd}, es);
-    f2 = ws.add("f2", {L, B, sh.T2, D}, es);
-    s2 = ws.add("s2", {L, M2, D}, es);
-    st2_mean = ws.add("st2_mean", {L, M2}, 4);
-    st2_rstd = ws.add("st2_rstd", {L, M2}, 4);
+    // tr_layer_index == 0 (or no TR layer): slot 0 = input of layer 0 (time-reduced), slot l + 1 = output of layer l.
+    // tr_layer_index > 0: slot stride = the T' frames; see Shapes
+    xo = ws.add("xo", {sh.slots((int)L), B, Ts, D}, es);
+    qkv = ws.add("qkv", {L, Ms, 3 * D}, es);
+    attn = ws.add("attn", {L, Ms, D}, es);
+    lse = ws.add("lse", {L, B * H, Ts}, 4);
+    s1 = ws.add("s1", {L, Ms, D}, es);
+    st1_mean = ws.add("st1_mean", {L, Ms}, 4);
+    st1_rstd = ws.add("st1_rstd", {L, Ms}, 4);
+    xa = ws.add("xa", {L, Ms, D}, es);
+    z1 = ws.add("z1", {L, Ms, Fd}, es);
+    hbuf = ws.add("h", {L, Ms, Fd}, es);
+    f2 = ws.add("f2", {L, B, Ts, D}, es);
+    s2 = ws.add("s2", {L, Ms, D}, es);
+    st2_mean = ws.add("st2_mean", {L, Ms}, 4);
+    st2_rstd = ws.add("st2_rstd", {L, Ms}, 4);
     const long Lh = c.n_tasks > 0 ? c.n_tasks : (k.heads_on ? L : 1);
+    const long Mh = c.n_tasks > 0 ? M2 * sh.f : M2;   // rows the DistilHuBERT-style head runs on (behind the shared upsampler: model.py:503-506)
     if (c.n_tasks > 0) {
       const long IN = (long)c.inter_dim * c.n_tasks;
-      u = -1;
-      if (tr) hz = ws.add("hz", {M2, IN}, es);
-      hh = ws.add("hh", {M2, IN}, es);
-      if (tr) dhz = ws.add("dhz", {M2, IN}, es);
-    } else if (c.tr_factor == 0) {
-      u = -1;
+      if (c.tr_factor > 0) u = ws.add("u", {B, (long)sh.T2 * sh.f, D}, es);
+      if (tr) hz = ws.add("hz", {Mh, IN}, es);
+      hh = ws.add("hh", {Mh, IN}, es);
+      if (tr) dhz = ws.add("dhz", {Mh, IN}, es);
     }
-    pred = ws.add("pred", {Lh, B, sh.T2 * sh.f, P}, es);
+    // layer-wise heads with heads on and tr_layer_index > 0: the heads of the layers in front of the TR conv see T' frames, so a head's
+    // slot holds Ts * f frames and a layer fills the first T(l) * f of them
+    pred = ws.add("pred", {Lh, B, (c.n_tasks == 0 && k.heads_on ? (long)Ts : (long)sh.T2) * sh.f, P}, es);
     if (c.cnn_head) {
       gfeat = ws.add("gfeat", {B, sh.Tp, D}, es);
       cnn_pred = ws.add("cnn_pred", {B, sh.Tp, P}, es);
@@ -422,24 +438,26 @@ struct Plan {
     }
     if (tr) {
       du = -1;
+      if (c.n_tasks > 0 && c.tr_factor > 0) du = ws.add("du", {B, (long)sh.T2 * sh.f, D}, es);
       if (c.n_tasks == 0 && c.tr_factor > 0) {  // gradient of the merged head weights / this pass's d_pred column sums
         dwm = ws.add("dwm", {Lh, (long)sh.f * P, D}, 4);
         if (c.dtype != 0) dwm16 = ws.add("dwm16", {Lh, (long)sh.f * P, D}, 2);
         dbl = ws.add("dbl", {Lh, P}, 4);
       }
-      ghead = ws.add("ghead", {L, M2, D}, es);
-      dxin = ws.add("dxin", {2, M2, D}, es);
-      ds2 = ws.add("ds2", {M2, D}, es);
-      df2 = ws.add("df2", {L, M2, D}, es);
-      dz1 = ws.add("dz1", {L, M2, Fd}, es);
-      dx1b = ws.add("dx1b", {M2, D}, es);
-      ds1 = ws.add("ds1", {M2, D}, es);
-      dao = ws.add("dao", {L, M2, D}, es);
-      da = ws.add("da", {M2, D}, es);
-      dqkv = ws.add("dqkv", {L, M2, 3 * D}, es);
-      delta = ws.add("delta", {B * H, sh.T2}, 4);
-      {  // fp32 dQ partials of the any-length fused attention backward (16-bit modes, T2 > 256)
-        const long n = fh_attention_bwd_scratch_floats(c.dtype, (int)B, sh.T2, (int)H, (int)(D / H));
+      ghead = ws.add("ghead", {L, Ms, D}, es);
+      dxin = ws.add("dxin", {2, Ms, D}, es);
+      ds2 = ws.add("ds2", {Ms, D}, es);
+      df2 = ws.add("df2", {L, Ms, D}, es);
+      dz1 = ws.add("dz1", {L, Ms, Fd}, es);
+      dx1b = ws.add("dx1b", {Ms, D}, es);
+      ds1 = ws.add("ds1", {Ms, D}, es);
+      dao = ws.add("dao", {L, Ms, D}, es);
+      da = ws.add("da", {Ms, D}, es);
+      dqkv = ws.add("dqkv", {L, Ms, 3 * D}, es);
+      delta = ws.add("delta", {B * H, Ts}, 4);
+      {  // fp32 dQ partials of the any-length fused attention backward (16-bit modes, T > 256)
+        long n = fh_attention_bwd_scratch_floats(c.dtype, (int)B, sh.T2, (int)H, (int)(D / H));
+        if (sh.idx > 0) { const long n2 = fh_attention_bwd_scratch_floats(c.dtype, (int)B, sh.Tp, (int)H, (int)(D / H)); if (n2 > n) n = n2; }
         if (n > 0) attn_scr = ws.add("attn_scr", {n}, 4);
       }
       dx1tr = ws.add("dx1tr", {B, sh.Tp, D}, es);
@@ -465,9 +483,10 @@ inline int validate(const fh_student_config& c) {
     if (c.conv_dim[i] % 64) return -813;
   if (c.embed_dim % c.heads || c.embed_dim % c.conv_pos_groups || c.embed_dim % vec || c.ffn_dim % vec || c.pred_dim % 8)
     return -814;
-  if (c.tr_factor != 0 && c.tr_factor != 2) return -815;  // shipped configs: conv1d TR with factor 2 at index 0
+  if (c.tr_factor != 0 && (c.tr_factor < 2 || c.tr_factor > 8)) return -815;
+  if (c.tr_index < 0 || c.tr_index > c.layers || (c.tr_factor == 0 && c.tr_index != 0)) return -819;
   if (!fh_posconv_cp(c.embed_dim / c.conv_pos_groups) || (c.embed_dim / c.conv_pos_groups) % 2) return -818;
-  if (c.n_tasks < 0 || (c.n_tasks > 0 && (c.inter_dim <= 0 || c.inter_dim % vec || c.tr_factor != 0))) return -817;
+  if (c.n_tasks < 0 || (c.n_tasks > 0 && (c.inter_dim <= 0 || c.inter_dim % vec))) return -817;
   for (int i = 1; i < c.n_conv; ++i) {
     const int kk = c.conv_k[i], s = c.conv_stride[i];
     if (!((kk == s) || (kk == 1 && s == 1) || (kk == 3 && s == 2))) return -816;
@@ -655,6 +674,9 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
       hipLaunchKernelGGL(head_bias_merge_kernel, dim3((c.layers * P + 3) / 4), dim3(256), 0, st, params, p.pl.head0,
                          p.pl.head_stride, p.pl.h_lin_w, p.pl.h_lin_b, p.pl.h_up_b, (float*)(wc + p.wl.head_bm), c.layers, P, D);
       FH_CHECK_LAUNCH();
+    } else {
+      // the shared upsampler in front of the DistilHuBERT-style head (model.py:341-348): ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin]
+      RC(fh_permute3_cast_launch(dt, params + p.pl.ups_w, wc + p.wl.head_wup, D, D, c.tr_factor, 2, 1, 0, st));
     }
   }
   RC(fh_posconv_prep_launch(dt, params + p.pl.pos_g, params + p.pl.pos_v, wc + p.wl.pos_wf, wc + p.wl.pos_wb,
@@ -746,91 +768,115 @@ int forward(const Ctx& x, const float* wave, const int* lens, const fh_student_k
   // ---- positional conv + residual, LayerNorm, dropout   module.py:276-294
   RC(fh_posconv_fwd_launch(dt, x.W(p.x0), x.rel(p.wl.pos_wf), prm + p.pl.pos_b, x.W(p.zc), x.W(p.psum), B, s.Tp, D,
                            c.conv_pos_groups, c.conv_pos, x.st));
-  RC(fh_layernorm_fwd_launch(dt, x.W(p.psum), prm + p.pl.enc_ln_w, prm + p.pl.enc_ln_b, c.tr_factor > 0 ? x.W(p.x1) : x.W(p.xo),
+  const bool tr_first = c.tr_factor > 0 && s.idx == 0;   // the shipped layout: the encoder LayerNorm writes x1, the TR conv slot 0
+  RC(fh_layernorm_fwd_launch(dt, x.W(p.psum), prm + p.pl.enc_ln_w, prm + p.pl.enc_ln_b, tr_first ? x.W(p.x1) : x.W(p.xo),
                              x.W<float>(p.ln1_mean), x.W<float>(p.ln1_rstd), (int)s.Mp, D, 1e-5f, x.drop(c.dropout, SITE_ENC), x.st));
-  // ---- time-reduction conv (k = s = factor)   module.py:317-321
-  if (c.tr_factor > 0) {
+  const long Ms = s.Ms;
+  // ---- time-reduction conv (k = s = factor) in front of layer tr_layer_index   module.py:247-248,317-321
+  auto tr_conv = [&]() -> int {
     GemmParams g = fh_gemm_params();
-    g.X = fh_operand(x.W(p.x1), FH_R_CONTIG, (long)s.f * D);
+    g.X = fh_operand(tr_first ? x.W(p.x1) : (void*)x.at(p.xo, (long)s.idx * Ms * D), FH_R_CONTIG, (long)s.f * D);
     g.X.rpb = s.T2; g.X.bstride = (long)s.Tp * D;
     g.Y = fh_operand(x.rel(p.wl.tr_wf), FH_R_CONTIG, (long)s.f * D);
-    g.C = x.W(p.xo);
+    g.C = tr_first ? x.W(p.xo) : (void*)x.at(p.xo, (long)(s.idx + 1) * Ms * D);
     g.M = (int)s.M2; g.N = D; g.Kseg = s.f * D; g.ldc = D;
     g.ep.bias = prm + p.pl.tr_b;
-    RC(fh_gemm_launch(g, dt, x.st));
-  }
+    return fh_gemm_launch(g, dt, x.st);
+  };
   // ---- transformer layers (post-LN)   module.py:557-582
-  const long M2 = s.M2;
   const float scale = 1.0f / sqrtf((float)(D / H));
   for (int l = 0; l < L; ++l) {
+    if (c.tr_factor > 0 && l == s.idx) RC(tr_conv());
+    const long M2 = s.Ml(l);             // rows of THIS layer (T' frames in front of the TR conv, reduced frames behind it)
+    const int Tl = s.Tl(l);
+    const int* len_l = l < s.idx ? len_p : len_2;
     const float* lp = prm + p.pl.layer0 + (long)l * p.pl.layer_stride;
     const long lpo = p.pl.layer0 + (long)l * p.pl.layer_stride;
-    unsigned char* xin = x.at(p.xo, (long)l * M2 * D);
-    unsigned char* xout = x.at(p.xo, (long)(l + 1) * M2 * D);
+    unsigned char* xin = x.at(p.xo, (long)s.slot_in(l) * Ms * D);
+    unsigned char* xout = x.at(p.xo, (long)(s.slot_in(l) + 1) * Ms * D);
     const uint32_t site = SITE_LAYER0 + 4 * l;
     {  // fused q|k|v projection
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(xin, FH_R_CONTIG, D);
       g.Y = fh_operand(x.nat(lpo + p.pl.l_qkv_w), FH_R_CONTIG, D);
-      g.C = x.at(p.qkv, (long)l * M2 * 3 * D);
+      g.C = x.at(p.qkv, (long)l * Ms * 3 * D);
       g.M = (int)M2; g.N = 3 * D; g.Kseg = D; g.ldc = 3 * D;
       g.ep.bias = lp + p.pl.l_qkv_b;
       RC(fh_gemm_launch(g, dt, x.st));
     }
-    RC(fh_attention_fwd_launch(dt, x.at(p.qkv, (long)l * M2 * 3 * D), x.at(p.attn, (long)l * M2 * D),
-                               x.W<float>(p.lse) + (long)l * B * H * s.T2, len_2, B, s.T2, H, D / H, scale,
+    RC(fh_attention_fwd_launch(dt, x.at(p.qkv, (long)l * Ms * 3 * D), x.at(p.attn, (long)l * Ms * D),
+                               x.W<float>(p.lse) + (long)l * B * H * s.Ts, len_l, B, Tl, H, D / H, scale,
                                x.drop(c.attention_dropout, site + 0), x.st));
     {  // out_proj + dropout1 + residual
       GemmParams g = fh_gemm_params();
-      g.X = fh_operand(x.at(p.attn, (long)l * M2 * D), FH_R_CONTIG, D);
+      g.X = fh_operand(x.at(p.attn, (long)l * Ms * D), FH_R_CONTIG, D);
       g.Y = fh_operand(x.nat(lpo + p.pl.l_o_w), FH_R_CONTIG, D);
-      g.C = x.at(p.s1, (long)l * M2 * D);
+      g.C = x.at(p.s1, (long)l * Ms * D);
       g.M = (int)M2; g.N = D; g.Kseg = D; g.ldc = D;
       g.ep.bias = lp + p.pl.l_o_b;
       g.ep.drop = x.drop(c.dropout, site + 1);
       g.ep.residual = xin;
       RC(fh_gemm_launch(g, dt, x.st));
     }
-    RC(fh_layernorm_fwd_launch(dt, x.at(p.s1, (long)l * M2 * D), lp + p.pl.l_ln1_w, lp + p.pl.l_ln1_b, x.at(p.xa, (long)l * M2 * D),
-                               x.W<float>(p.st1_mean) + l * M2, x.W<float>(p.st1_rstd) + l * M2, (int)M2, D, 1e-5f,
+    RC(fh_layernorm_fwd_launch(dt, x.at(p.s1, (long)l * Ms * D), lp + p.pl.l_ln1_w, lp + p.pl.l_ln1_b, x.at(p.xa, (long)l * Ms * D),
+                               x.W<float>(p.st1_mean) + l * Ms, x.W<float>(p.st1_rstd) + l * Ms, (int)M2, D, 1e-5f,
                                x.drop(0.f, 0), x.st));
     {  // fc1 + GELU + dropout2
       GemmParams g = fh_gemm_params();
-      g.X = fh_operand(x.at(p.xa, (long)l * M2 * D), FH_R_CONTIG, D);
+      g.X = fh_operand(x.at(p.xa, (long)l * Ms * D), FH_R_CONTIG, D);
       g.Y = fh_operand(x.nat(lpo + p.pl.l_fc1_w), FH_R_CONTIG, D);
-      g.C = x.at(p.hbuf, (long)l * M2 * Fd);
+      g.C = x.at(p.hbuf, (long)l * Ms * Fd);
       g.M = (int)M2; g.N = Fd; g.Kseg = D; g.ldc = Fd;
       g.ep.bias = lp + p.pl.l_fc1_b;
       g.ep.act = FH_ACT_GELU;
-      if (tr) g.ep.preact = x.at(p.z1, (long)l * M2 * Fd);
+      if (tr) g.ep.preact = x.at(p.z1, (long)l * Ms * Fd);
       g.ep.drop = x.drop(c.activation_dropout, site + 2);
       RC(fh_gemm_launch(g, dt, x.st));
     }
     {  // fc2 (layer_result) + dropout3 + residual
       GemmParams g = fh_gemm_params();
-      g.X = fh_operand(x.at(p.hbuf, (long)l * M2 * Fd), FH_R_CONTIG, Fd);
+      g.X = fh_operand(x.at(p.hbuf, (long)l * Ms * Fd), FH_R_CONTIG, Fd);
       g.Y = fh_operand(x.nat(lpo + p.pl.l_fc2_w), FH_R_CONTIG, Fd);
-      g.C = x.at(p.s2, (long)l * M2 * D);
+      g.C = x.at(p.s2, (long)l * Ms * D);
       g.M = (int)M2; g.N = D; g.Kseg = Fd; g.ldc = D;
       g.ep.bias = lp + p.pl.l_fc2_b;
-      g.ep.preact = x.at(p.f2, (long)l * M2 * D);
+      g.ep.preact = x.at(p.f2, (long)l * Ms * D);
       g.ep.drop = x.drop(c.dropout, site + 3);
-      g.ep.residual = x.at(p.xa, (long)l * M2 * D);
+      g.ep.residual = x.at(p.xa, (long)l * Ms * D);
       RC(fh_gemm_launch(g, dt, x.st));
     }
-    RC(fh_layernorm_fwd_launch(dt, x.at(p.s2, (long)l * M2 * D), lp + p.pl.l_ln2_w, lp + p.pl.l_ln2_b, xout,
-                               x.W<float>(p.st2_mean) + l * M2, x.W<float>(p.st2_rstd) + l * M2, (int)M2, D, 1e-5f,
+    RC(fh_layernorm_fwd_launch(dt, x.at(p.s2, (long)l * Ms * D), lp + p.pl.l_ln2_w, lp + p.pl.l_ln2_b, xout,
+                               x.W<float>(p.st2_mean) + l * Ms, x.W<float>(p.st2_rstd) + l * Ms, (int)M2, D, 1e-5f,
                                x.drop(0.f, 0), x.st));
   }
-  // ---- DistilHuBERT-style head on the last layer (model.py:508-516): Linear -> GELU -> SplitLinear (module.py:606-619)
+  if (c.tr_factor > 0 && s.idx == L) RC(tr_conv());   // tr_layer_index == encoder_layers: the TR conv is the encoder's last module
+  const long M2 = s.M2;
+  const unsigned char* enc_out = x.at(p.xo, (long)(s.slots(L) - 1) * Ms * D);   // the encoder's output x (reduced frames whenever a TR layer exists)
+  // ---- DistilHuBERT-style head on the encoder output (model.py:503-516): [shared upsampler ->] Linear -> GELU -> SplitLinear (module.py:606-619)
   if (c.n_tasks > 0) {
     if (!p.k.heads_on) return 0;
     const int Nt = c.n_tasks, I = c.inter_dim;
+    const void* head_in = enc_out;
+    long Mh = M2;
+    if (c.tr_factor > 0) {
+      // model.py:401-407,504-505: x = upsampler(x), ConvTranspose1d(D, D, k = s = f) over time == one GEMM whose row m holds the f
+      // up-sampled frames of x_m:  u[m][(j, co)] = sum_ci x[m][ci] W[ci][co][j] + b[co]
+      GemmParams gu = fh_gemm_params();
+      gu.X = fh_operand(enc_out, FH_R_CONTIG, D);
+      gu.Y = fh_operand(x.rel(p.wl.head_wup), FH_R_CONTIG, D);   // [j][co][ci]
+      gu.C = x.W(p.u);
+      gu.M = (int)M2; gu.N = s.f * D; gu.Kseg = D; gu.ldc = (long)s.f * D;
+      gu.ep.bias = prm + p.pl.ups_b;
+      gu.ep.bias_mod = D;
+      RC(fh_gemm_launch(gu, dt, x.st));
+      head_in = x.W(p.u);
+      Mh = M2 * s.f;
+    }
     GemmParams g = fh_gemm_params();
-    g.X = fh_operand(x.at(p.xo, (long)L * M2 * D), FH_R_CONTIG, D);
+    g.X = fh_operand(head_in, FH_R_CONTIG, D);
     g.Y = fh_operand(x.nat(p.pl.sp_w0), FH_R_CONTIG, D);
     g.C = x.W(p.hh);
-    g.M = (int)M2; g.N = I * Nt; g.Kseg = D; g.ldc = (long)I * Nt;
+    g.M = (int)Mh; g.N = I * Nt; g.Kseg = D; g.ldc = (long)I * Nt;
     g.ep.bias = prm + p.pl.sp_b0;
     g.ep.act = FH_ACT_GELU;
     if (tr) g.ep.preact = x.W(p.hz);
@@ -845,8 +891,8 @@ int forward(const Ctx& x, const float* wave, const int* lens, const fh_student_k
       g2.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_CONTIG, I);  // nn.Linear weight [P][I]
     }
     g2.C = x.W(p.pred);
-    g2.M = (int)M2; g2.N = P; g2.Kseg = I; g2.ldc = P;
-    g2.c_gstride = M2 * P;
+    g2.M = (int)Mh; g2.N = P; g2.Kseg = I; g2.ldc = P;
+    g2.c_gstride = Mh * P;
     g2.groups = Nt;
     g2.ep.bias = prm + p.pl.sp_b2;
     g2.ep.bias_gstride = P;
@@ -858,42 +904,51 @@ int forward(const Ctx& x, const float* wave, const int* lens, const fh_student_k
     const int Lh = p.k.heads_on ? L : 1;
     const int l0 = p.k.heads_on ? 0 : L - 1;
     const long hp0 = p.pl.head0 + (long)l0 * p.pl.head_stride;
-    const void* lin_in = x.at(p.xo, (long)(l0 + 1) * M2 * D);
-    long lin_in_g = M2 * D;
     if (c.tr_factor > 0) {
-      // merged head: pred[l][m][(j, p)] = x[l][m] . Wm[l][(j, p)] + bm[l][p]  -- row m of C holds the f up-sampled frames
-      GemmParams g = fh_gemm_params();
-      g.X = fh_operand(lin_in, FH_R_CONTIG, D);
-      g.X.gstride = M2 * D;
-      g.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wm) + (long)l0 * s.f * P * D * p.es, FH_R_CONTIG, D);
-      g.Y.gstride = (long)s.f * P * D;
-      g.C = x.W(p.pred);
-      g.M = (int)M2; g.N = s.f * P; g.Kseg = D; g.ldc = (long)s.f * P;
-      g.c_gstride = M2 * s.f * P;
-      g.groups = Lh;
-      g.ep.bias = (const float*)x.rel(p.wl.head_bm) + (long)l0 * P;
-      g.ep.bias_gstride = P;
-      g.ep.bias_mod = P;
-      if (kd && kd->teacher) {
-        // KD loss in this GEMM's epilogue (train.py:250-293): the workspace tensor "pred" receives d loss / d pred, `pred` itself is
-        // never written; row m = (utterance, reduced frame), column = (sub-frame j, feature)
-        if (!tr || !p.k.heads_on) return -823;
-        g.c_rpb = s.T2;
-        g.c_bstride = (long)s.T2 * s.f * P;
-        g.ep.kd_teacher = kd->teacher;
-        g.ep.kd_tdtype = kd->teacher_dtype;
-        g.ep.kd_lstride = kd->teacher_lstride;
-        g.ep.kd_layer = kd->teacher_layer;
-        g.ep.kd_w = kd->layer_w;
-        g.ep.kd_Tt = kd->Tt;
-        g.ep.kd_P = P;
-        g.ep.kd_type = kd->loss_type;
-        g.ep.kd_grad_scale = kd->grad_scale;
-        g.ep.kd_count = (float)((long)B * s.T2 * s.f * P);
-        g.ep.kd_partials = kd->partials;
-        if (kd->Tt < s.T2 * s.f) return -824;
+      // merged head: pred[l][m][(j, p)] = x[l][m] . Wm[l][(j, p)] + bm[l][p]  -- row m of C holds the f up-sampled frames.
+      // Heads on: one grouped launch per run of layers with equal frame counts (all of them when tr_layer_index == 0).  Heads off:
+      // final_proj on the encoder output (model.py:500-502)
+      const long pred_g = (p.k.heads_on ? Ms : M2) * s.f * P;
+      auto head_group = [&](int la, int n, long rows, const void* in) -> int {
+        GemmParams g = fh_gemm_params();
+        g.X = fh_operand(in, FH_R_CONTIG, D);
+        g.X.gstride = Ms * D;
+        g.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wm) + (long)la * s.f * P * D * p.es, FH_R_CONTIG, D);
+        g.Y.gstride = (long)s.f * P * D;
+        g.C = x.at(p.pred, (long)(la - l0) * pred_g);
+        g.M = (int)rows; g.N = s.f * P; g.Kseg = D; g.ldc = (long)s.f * P;
+        g.c_gstride = pred_g;
+        g.groups = n;
+        g.ep.bias = (const float*)x.rel(p.wl.head_bm) + (long)la * P;
+        g.ep.bias_gstride = P;
+        g.ep.bias_mod = P;
+        if (kd && kd->teacher) {
+          // KD loss in this GEMM's epilogue (train.py:250-293): the workspace tensor "pred" receives d loss / d pred, `pred` itself is
+          // never written; row m = (utterance, reduced frame), column = (sub-frame j, feature)
+          if (!tr || !p.k.heads_on || s.idx > 0) return -823;
+          g.c_rpb = s.T2;
+          g.c_bstride = (long)s.T2 * s.f * P;
+          g.ep.kd_teacher = kd->teacher;
+          g.ep.kd_tdtype = kd->teacher_dtype;
+          g.ep.kd_lstride = kd->teacher_lstride;
+          g.ep.kd_layer = kd->teacher_layer;
+          g.ep.kd_w = kd->layer_w;
+          g.ep.kd_Tt = kd->Tt;
+          g.ep.kd_P = P;
+          g.ep.kd_type = kd->loss_type;
+          g.ep.kd_grad_scale = kd->grad_scale;
+          g.ep.kd_count = (float)((long)B * s.T2 * s.f * P);
+          g.ep.kd_partials = kd->partials;
+          if (kd->Tt < s.T2 * s.f) return -824;
+        }
+        return fh_gemm_launch(g, dt, x.st);
+      };
+      if (!p.k.heads_on) {
+        RC(head_group(l0, 1, M2, enc_out));
+      } else {
+        if (s.idx > 0) RC(head_group(0, s.idx, s.Mp, x.at(p.xo, 1L * Ms * D)));
+        if (s.idx < L) RC(head_group(s.idx, L - s.idx, M2, x.at(p.xo, (long)(s.slot_in(s.idx) + 1) * Ms * D)));
       }
-      RC(fh_gemm_launch(g, dt, x.st));
       if (kd && kd->teacher) {
         const int nblk = (int)(((M2 + 63) / 64) * ((s.f * P + 63) / 64));
         RC(fh_kd_loss_final_launch(kd->partials, kd->layer_w, kd->out_losses, Lh, nblk, (double)B * s.T2 * s.f * P, x.st));
@@ -901,8 +956,8 @@ int forward(const Ctx& x, const float* wave, const int* lens, const fh_student_k
       return 0;
     }
     GemmParams g = fh_gemm_params();
-    g.X = fh_operand(lin_in, FH_R_CONTIG, D);
-    g.X.gstride = lin_in_g;
+    g.X = fh_operand(x.at(p.xo, (long)(l0 + 1) * M2 * D), FH_R_CONTIG, D);
+    g.X.gstride = M2 * D;
     g.Y = fh_operand(x.nat(hp0 + p.pl.h_lin_w), FH_R_CONTIG, D);
     g.Y.gstride = p.pl.head_stride;
     g.C = x.W(p.pred);
@@ -925,11 +980,17 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
   if (!p.k.training) return -820;
   const int* len_p = lens;
   const int* len_2 = lens ? lens + B : nullptr;
-  const long M2 = s.M2;
+  const long M2 = s.M2, Ms = s.Ms;
   const float scale = 1.0f / sqrtf((float)(D / H));
   const int Lh = p.k.heads_on ? L : 1;
   const int l0 = p.k.heads_on ? 0 : L - 1;
   const long hp0 = p.pl.head0 + (long)l0 * p.pl.head_stride;
+  const bool tr_first = c.tr_factor > 0 && s.idx == 0;
+  const bool tr_last = c.tr_factor > 0 && s.idx == L;      // the TR conv is the encoder's last module: its output is the encoder output
+  const unsigned char* enc_out = x.at(p.xo, (long)(s.slots(L) - 1) * Ms * D);
+  // gradient w.r.t. the ENCODER OUTPUT (the DistilHuBERT-style head, or final_proj with the heads off): slot L - 1 of ghead -- the
+  // output of the last transformer layer, or of the TR conv when that comes last
+  unsigned char* g_enc = x.at(p.ghead, (long)(L - 1) * Ms * D);
 
   // ---------------- heads: d_pred -> du -> ghead (+ d_hidden), and head weight gradients
   bool have_ghead = false;
@@ -937,10 +998,13 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
   if (d_pred && split_head) {
     const int Nt = c.n_tasks, I = c.inter_dim;
     const long IN = (long)I * Nt;
+    const bool ups = c.tr_factor > 0;                      // shared upsampler in front of the head (model.py:503-506)
+    const long Mh = ups ? M2 * s.f : M2;
+    const void* head_in = ups ? (const void*)x.W(p.u) : (const void*)enc_out;
     {  // dhz[:, n-block] = (d_pred[n] . W2[n]^T) * gelu'(hz)
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(d_pred, FH_R_CONTIG, P);
-      g.X.gstride = M2 * P;
+      g.X.gstride = Mh * P;
       if (Nt > 1) {
         g.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_CONTIG, P);
         g.Y.gstride = (long)I * P;
@@ -948,7 +1012,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
         g.Y = fh_operand(x.nat(p.pl.sp_w2), FH_R_STRIDED, I);
       }
       g.C = x.W(p.dhz);
-      g.M = (int)M2; g.N = I; g.Kseg = P; g.ldc = IN;
+      g.M = (int)Mh; g.N = I; g.Kseg = P; g.ldc = IN;
       g.c_gstride = I;
       g.groups = Nt;
       g.ep.gelu_aux = x.W(p.hz);
@@ -957,44 +1021,66 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     {  // dW2[n][r][j] += sum_m hh[m][n*I + r] * d_pred[n][m][j] ; db2[n] = colsum(d_pred[n])
       if (Nt > 1) {
         GemmOperand A = fh_operand(d_pred, FH_R_STRIDED, P);
-        A.gstride = M2 * P;
-        RC(wgrad(x, x.W(p.hh), IN, A, grads + p.pl.sp_w2, I, P, M2, Nt, I, (long)I * P));
+        A.gstride = Mh * P;
+        RC(wgrad(x, x.W(p.hh), IN, A, grads + p.pl.sp_w2, I, P, Mh, Nt, I, (long)I * P));
       } else {  // dW[j][r] += sum_m d_pred[m][j] * hh[m][r]
         GemmOperand A = fh_operand(x.W(p.hh), FH_R_STRIDED, I);
-        RC(wgrad(x, d_pred, P, A, grads + p.pl.sp_w2, P, I, M2, 1, 0, 0));
+        RC(wgrad(x, d_pred, P, A, grads + p.pl.sp_w2, P, I, Mh, 1, 0, 0));
       }
-      RC(fh_colsum_launch(dt, d_pred, grads + p.pl.sp_b2, (int)M2, P, P, Nt, M2 * P, P, 0, 1.f, x.st));
+      RC(fh_colsum_launch(dt, d_pred, grads + p.pl.sp_b2, (int)Mh, P, P, Nt, Mh * P, P, 0, 1.f, x.st));
     }
-    {  // ghead[L-1] = dhz . W0 (+ d_hidden[L-1])
+    {  // gradient w.r.t. the head's input = dhz . W0: the encoder output's gradient (+ d_hidden[L-1]), or du behind the shared upsampler
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.W(p.dhz), FH_R_CONTIG, IN);
       g.Y = fh_operand(x.nat(p.pl.sp_w0), FH_R_STRIDED, D);
-      g.C = x.at(p.ghead, (long)(L - 1) * M2 * D);
-      g.M = (int)M2; g.N = D; g.Kseg = (int)IN; g.ldc = D;
-      if (d_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)(L - 1) * M2 * D * p.es;
+      g.C = ups ? (void*)x.W(p.du) : (void*)g_enc;
+      g.M = (int)Mh; g.N = D; g.Kseg = (int)IN; g.ldc = D;
+      if (d_hidden && !ups && !tr_last) g.ep.residual = (const unsigned char*)d_hidden + (long)(L - 1) * Ms * D * p.es;
       RC(fh_gemm_launch(g, dt, x.st));
-      GemmOperand A = fh_operand(x.at(p.xo, (long)L * M2 * D), FH_R_STRIDED, D);
-      RC(wgrad(x, x.W(p.dhz), IN, A, grads + p.pl.sp_w0, (int)IN, D, M2, 1, 0, 0));
-      RC(fh_colsum_launch(dt, x.W(p.dhz), grads + p.pl.sp_b0, (int)M2, (int)IN, IN, 1, 0, 0, 0, 1.f, x.st));
+      GemmOperand A = fh_operand(head_in, FH_R_STRIDED, D);
+      RC(wgrad(x, x.W(p.dhz), IN, A, grads + p.pl.sp_w0, (int)IN, D, Mh, 1, 0, 0));
+      RC(fh_colsum_launch(dt, x.W(p.dhz), grads + p.pl.sp_b0, (int)Mh, (int)IN, IN, 1, 0, 0, 0, 1.f, x.st));
+    }
+    if (ups) {
+      // shared upsampler backward (ConvTranspose1d k = s = f as one GEMM, see the forward): du as [M2][(j, co)]
+      //   d enc_out[m][ci] = sum_(j,co) du[m][(j,co)] W[ci][co][j]   (+ d_hidden[L-1])
+      //   dW[ci][co][j]   += sum_m enc_out[m][ci] du[m][(j,co)] ;  db[co] += sum_(m,j) du[m][(j,co)]
+      GemmParams g = fh_gemm_params();
+      g.X = fh_operand(x.W(p.du), FH_R_CONTIG, (long)s.f * D);
+      g.Y = fh_operand(x.rel(p.wl.head_wup), FH_R_STRIDED, D);   // [(j, co)][ci]: the reduction index is the row
+      g.C = g_enc;
+      g.M = (int)M2; g.N = D; g.Kseg = s.f * D; g.ldc = D;
+      if (d_hidden && !tr_last) g.ep.residual = (const unsigned char*)d_hidden + (long)(L - 1) * Ms * D * p.es;
+      RC(fh_gemm_launch(g, dt, x.st));
+      GemmOperand A = fh_operand(enc_out, FH_R_STRIDED, D);
+      RC(wgrad(x, x.W(p.du), (long)s.f * D, A, grads + p.pl.ups_w, s.f * D, D, M2, 1, 0, 0, /*jdiv*/ 1, /*sj1*/ (long)D * s.f, /*sj0*/ 0,
+               /*idiv*/ D, /*si1*/ 1, /*si0*/ s.f));
+      RC(fh_colsum_launch(dt, x.W(p.du), grads + p.pl.ups_b, (int)(M2 * s.f), D, D, 1, 0, 0, 0, 1.f, x.st));
     }
     have_ghead = true;
   } else if (d_pred) {
-    const void* dlin_in;  // gradient w.r.t. the Linear's input
     if (c.tr_factor > 0) {
       const long fP = (long)s.f * P;
-      const unsigned char* wm = (const unsigned char*)x.rel(p.wl.head_wm) + (long)l0 * fP * D * p.es;
-      {  // ghead[l] = d_pred[l] (as [M2][f*P]) . Wm[l]  (+ d_hidden)
+      const long pred_g = (p.k.heads_on ? Ms : M2) * fP;     // a head's slot in pred / d_pred (forward)
+      // ghead[l] = d_pred[l] (as [rows][f*P]) . Wm[l]  (+ d_hidden): one grouped launch per run of layers with equal frame counts
+      auto ghead_group = [&](int la, int n, long rows, unsigned char* out, bool add_hidden) -> int {
         GemmParams g = fh_gemm_params();
-        g.X = fh_operand(d_pred, FH_R_CONTIG, fP);
-        g.X.gstride = M2 * fP;
-        g.Y = fh_operand(wm, FH_R_STRIDED, D);
+        g.X = fh_operand((const unsigned char*)d_pred + (long)(la - l0) * pred_g * p.es, FH_R_CONTIG, fP);
+        g.X.gstride = pred_g;
+        g.Y = fh_operand((const unsigned char*)x.rel(p.wl.head_wm) + (long)la * fP * D * p.es, FH_R_STRIDED, D);
         g.Y.gstride = fP * D;
-        g.C = x.at(p.ghead, (long)l0 * M2 * D);
-        g.M = (int)M2; g.N = D; g.Kseg = (int)fP; g.ldc = D;
-        g.c_gstride = M2 * D;
-        g.groups = Lh;
-        if (d_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)l0 * M2 * D * p.es;
-        RC(fh_gemm_launch(g, dt, x.st));
+        g.C = out;
+        g.M = (int)rows; g.N = D; g.Kseg = (int)fP; g.ldc = D;
+        g.c_gstride = Ms * D;
+        g.groups = n;
+        if (d_hidden && add_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)la * Ms * D * p.es;
+        return fh_gemm_launch(g, dt, x.st);
+      };
+      if (!p.k.heads_on) {
+        RC(ghead_group(l0, 1, M2, g_enc, !tr_last));
+      } else {
+        if (s.idx > 0) RC(ghead_group(0, s.idx, s.Mp, x.at(p.ghead, 0), true));
+        if (s.idx < L) RC(ghead_group(s.idx, L - s.idx, M2, x.at(p.ghead, (long)s.idx * Ms * D), true));
       }
       // The heads' PARAMETER gradients are a branch of their own -- d_pred and the layer outputs in, the gradient buffer out, nothing
       // of the data-gradient chain reads them -- so the whole branch goes to the side stream (in order there).
@@ -1002,11 +1088,18 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       // dWm[l][(j, p)][ci] = sum_m d_pred[l][m][(j, p)] * x[l][m][ci]   (fp32 scratch), this pass's column sums of d_pred
       RC((int)hipMemsetAsync(x.W(p.dwm), 0, (long)Lh * fP * D * 4, hs));
       RC((int)hipMemsetAsync(x.W(p.dbl), 0, (long)Lh * P * 4, hs));
-      {
-        GemmOperand A = fh_operand(x.at(p.xo, (long)(l0 + 1) * M2 * D), FH_R_STRIDED, D);
-        A.gstride = M2 * D;
-        RC(wgrad(x, d_pred, fP, A, x.W<float>(p.dwm), (int)fP, D, M2, Lh, M2 * fP, fP * D, 0, 0, 0, 0, 0, 0, -1, hs));
-        RC(fh_colsum_launch(dt, d_pred, x.W<float>(p.dbl), (int)(M2 * s.f), P, P, Lh, M2 * fP, P, 0, 1.f, hs));
+      auto head_wgrad_group = [&](int la, int n, long rows, const void* in) -> int {
+        GemmOperand A = fh_operand(in, FH_R_STRIDED, D);
+        A.gstride = Ms * D;
+        const unsigned char* dp = (const unsigned char*)d_pred + (long)(la - l0) * pred_g * p.es;
+        RC(wgrad(x, dp, fP, A, x.W<float>(p.dwm) + (long)(la - l0) * fP * D, (int)fP, D, rows, n, pred_g, fP * D, 0, 0, 0, 0, 0, 0, -1, hs));
+        return fh_colsum_launch(dt, dp, x.W<float>(p.dbl) + (long)(la - l0) * P, (int)(rows * s.f), P, P, n, pred_g, P, 0, 1.f, hs);
+      };
+      if (!p.k.heads_on) {
+        RC(head_wgrad_group(l0, 1, M2, enc_out));
+      } else {
+        if (s.idx > 0) RC(head_wgrad_group(0, s.idx, s.Mp, x.at(p.xo, 1L * Ms * D)));
+        if (s.idx < L) RC(head_wgrad_group(s.idx, L - s.idx, M2, x.at(p.xo, (long)(s.slot_in(s.idx) + 1) * Ms * D)));
       }
       // chain rule onto the reference's parameters, accumulated into the gradient buffer: in the compute dtype (fp32 mode: exact fp32
       // GEMMs on the fp32 masters; bf16 mode: the fp32 merged-weight gradient is rounded to bf16 once and the four grouped products run
@@ -1050,7 +1143,6 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       hipLaunchKernelGGL(head_bias_bwd_kernel, dim3(Lh, (D + 15) / 16), dim3(256), 0, hs, x.params, grads, hp0, p.pl.head_stride, p.pl.h_lin_w,
                          p.pl.h_lin_b, p.pl.h_up_b, (const float*)x.W<float>(p.dbl), P, D);
       FH_CHECK_LAUNCH();
-      dlin_in = nullptr;
     } else {
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(d_pred, FH_R_CONTIG, P);
@@ -1063,9 +1155,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.groups = Lh;
       if (d_hidden) g.ep.residual = (const unsigned char*)d_hidden + (long)l0 * M2 * D * p.es;
       RC(fh_gemm_launch(g, dt, x.st));
-      dlin_in = nullptr;
     }
-    (void)dlin_in;
     have_ghead = true;
     // weight grads of the heads (Linear only; the time-reduced recipe handled them through the merged weights above)
     if (c.tr_factor == 0) {
@@ -1085,60 +1175,90 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
   // ---------------- grouped weight / bias gradients of layers [l0, l0 + nl): one launch per linear, on the side stream.  Issued
   // once for all layers behind the layer loop (chunks of 4 layers from inside the loop were measured: the smaller groups lose more
   // than the extra overlap gains).
-  auto layer_wgrads = [&](int l0, int nl) -> int {
+  auto layer_wgrads = [&](int l0, int nl, long M2) -> int {   // M2 = rows of every layer of the run
+    if (nl <= 0) return 0;
     const long lo = p.pl.layer0 + (long)l0 * p.pl.layer_stride, ls = p.pl.layer_stride;
     const hipStream_t ws_ = g_wside.fork(x.st);
-    GemmOperand A = fh_operand(x.at(p.hbuf, (long)l0 * M2 * Fd), FH_R_STRIDED, Fd);
-    A.gstride = M2 * Fd;
-    RC(wgrad(x, x.at(p.df2, (long)l0 * M2 * D), D, A, grads + lo + p.pl.l_fc2_w, D, Fd, M2, nl, M2 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
-    RC(fh_colsum_launch(dt, x.at(p.df2, (long)l0 * M2 * D), grads + lo + p.pl.l_fc2_b, (int)M2, D, D, nl, M2 * D, ls, 0, 1.f, ws_));
-    A = fh_operand(x.at(p.xa, (long)l0 * M2 * D), FH_R_STRIDED, D);
-    A.gstride = M2 * D;
-    RC(wgrad(x, x.at(p.dz1, (long)l0 * M2 * Fd), Fd, A, grads + lo + p.pl.l_fc1_w, Fd, D, M2, nl, M2 * Fd, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
-    RC(fh_colsum_launch(dt, x.at(p.dz1, (long)l0 * M2 * Fd), grads + lo + p.pl.l_fc1_b, (int)M2, Fd, Fd, nl, M2 * Fd, ls, 0, 1.f, ws_));
-    A = fh_operand(x.at(p.attn, (long)l0 * M2 * D), FH_R_STRIDED, D);
-    A.gstride = M2 * D;
-    RC(wgrad(x, x.at(p.dao, (long)l0 * M2 * D), D, A, grads + lo + p.pl.l_o_w, D, D, M2, nl, M2 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
-    RC(fh_colsum_launch(dt, x.at(p.dao, (long)l0 * M2 * D), grads + lo + p.pl.l_o_b, (int)M2, D, D, nl, M2 * D, ls, 0, 1.f, ws_));
-    A = fh_operand(x.at(p.xo, (long)l0 * M2 * D), FH_R_STRIDED, D);  // layer inputs = slots 0..L-1
-    A.gstride = M2 * D;
-    RC(wgrad(x, x.at(p.dqkv, (long)l0 * M2 * 3 * D), 3 * D, A, grads + lo + p.pl.l_qkv_w, 3 * D, D, M2, nl, M2 * 3 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
-    RC(fh_colsum_launch(dt, x.at(p.dqkv, (long)l0 * M2 * 3 * D), grads + lo + p.pl.l_qkv_b, (int)M2, 3 * D, 3 * D, nl, M2 * 3 * D, ls, 0, 1.f, ws_));
+    GemmOperand A = fh_operand(x.at(p.hbuf, (long)l0 * Ms * Fd), FH_R_STRIDED, Fd);
+    A.gstride = Ms * Fd;
+    RC(wgrad(x, x.at(p.df2, (long)l0 * Ms * D), D, A, grads + lo + p.pl.l_fc2_w, D, Fd, M2, nl, Ms * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.df2, (long)l0 * Ms * D), grads + lo + p.pl.l_fc2_b, (int)M2, D, D, nl, Ms * D, ls, 0, 1.f, ws_));
+    A = fh_operand(x.at(p.xa, (long)l0 * Ms * D), FH_R_STRIDED, D);
+    A.gstride = Ms * D;
+    RC(wgrad(x, x.at(p.dz1, (long)l0 * Ms * Fd), Fd, A, grads + lo + p.pl.l_fc1_w, Fd, D, M2, nl, Ms * Fd, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.dz1, (long)l0 * Ms * Fd), grads + lo + p.pl.l_fc1_b, (int)M2, Fd, Fd, nl, Ms * Fd, ls, 0, 1.f, ws_));
+    A = fh_operand(x.at(p.attn, (long)l0 * Ms * D), FH_R_STRIDED, D);
+    A.gstride = Ms * D;
+    RC(wgrad(x, x.at(p.dao, (long)l0 * Ms * D), D, A, grads + lo + p.pl.l_o_w, D, D, M2, nl, Ms * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.dao, (long)l0 * Ms * D), grads + lo + p.pl.l_o_b, (int)M2, D, D, nl, Ms * D, ls, 0, 1.f, ws_));
+    A = fh_operand(x.at(p.xo, (long)s.slot_in(l0) * Ms * D), FH_R_STRIDED, D);  // layer inputs = consecutive slots
+    A.gstride = Ms * D;
+    RC(wgrad(x, x.at(p.dqkv, (long)l0 * Ms * 3 * D), 3 * D, A, grads + lo + p.pl.l_qkv_w, 3 * D, D, M2, nl, Ms * 3 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
+    RC(fh_colsum_launch(dt, x.at(p.dqkv, (long)l0 * Ms * 3 * D), grads + lo + p.pl.l_qkv_b, (int)M2, 3 * D, 3 * D, nl, Ms * 3 * D, ls, 0, 1.f, ws_));
     return 0;
   };
+  // ---------------- time-reduction conv backward: gradient w.r.t. its output (reduced frames) -> dx1tr (T' frames; the frames past
+  // f x T2, which the conv does not reach, were zeroed at the head of the backward), weight / bias gradients
+  auto tr_backward = [&](const void* dy_tr) -> int {
+    GemmParams g = fh_gemm_params();
+    g.X = fh_operand(dy_tr, FH_R_CONTIG, D);
+    g.Y = fh_operand(x.rel(p.wl.tr_wf), FH_R_STRIDED, (long)s.f * D);
+    g.C = x.W(p.dx1tr);
+    g.M = (int)M2; g.N = s.f * D; g.Kseg = D;
+    g.ldc = (long)s.f * D; g.c_rpb = s.T2; g.c_bstride = (long)s.Tp * D;
+    RC(fh_gemm_launch(g, dt, x.st));
+    GemmOperand A = fh_operand(tr_first ? (const void*)x.W(p.x1) : (const void*)x.at(p.xo, (long)s.idx * Ms * D), FH_R_STRIDED, (long)s.f * D);
+    A.rpb = s.T2; A.bstride = (long)s.Tp * D;
+    RC(wgrad(x, dy_tr, D, A, grads + p.pl.tr_w, D, s.f * D, M2, 1, 0, 0, /*jdiv*/ D, /*sj1*/ 1, /*sj0*/ s.f, 0, 0, 0,
+             /*ldc*/ (long)D * s.f));
+    return fh_colsum_launch(dt, dy_tr, grads + p.pl.tr_b, (int)M2, D, D, 1, 0, 0, 0, 1.f, x.st);
+  };
   // ---------------- transformer layers, last to first
-  const void* dy_next = nullptr;  // gradient w.r.t. xo[l+1] coming from layer l+1
+  const void* dy_next = nullptr;  // gradient w.r.t. the output of layer l coming from what follows it
+  if (tr_last && have_ghead && (split_head || !p.k.heads_on)) {
+    // the encoder output is the TR conv's: its gradient (from the head) goes through the conv first
+    RC(tr_backward(g_enc));
+    dy_next = x.W(p.dx1tr);
+  }
   for (int l = L - 1; l >= 0; --l) {
+    if (c.tr_factor > 0 && !tr_last && l == s.idx - 1) {   // crossing the TR conv: dy_next is the gradient of ITS output
+      if (!dy_next) return -821;
+      RC(tr_backward(dy_next));
+      dy_next = x.W(p.dx1tr);
+    }
+    const long M2 = s.Ml(l);
+    const int Tl = s.Tl(l);
+    const int* len_l = l < s.idx ? len_p : len_2;
     const long lpo = p.pl.layer0 + (long)l * p.pl.layer_stride;
     const float* lp = x.params + lpo;
     float* lg = grads + lpo;
     const uint32_t site = SITE_LAYER0 + 4 * l;
     const void* g_head = nullptr;
-    if (have_ghead && ((p.k.heads_on && !split_head) || l == L - 1)) g_head = x.at(p.ghead, (long)l * M2 * D);
-    else if (d_hidden) g_head = (const unsigned char*)d_hidden + (long)l * M2 * D * p.es;
+    if (have_ghead && ((p.k.heads_on && !split_head) || (l == L - 1 && !tr_last))) g_head = x.at(p.ghead, (long)l * Ms * D);
+    else if (d_hidden) g_head = (const unsigned char*)d_hidden + (long)l * Ms * D * p.es;
     const void* dy = dy_next ? dy_next : g_head;
     const void* dy2 = dy_next ? g_head : nullptr;
     if (!dy) return -821;  // no gradient reaches this layer's output
     // LN2 backward -> ds2 ; df2 = ds2 * mask3
     const bool drop3 = c.dropout > 0.f;
-    unsigned char* df2_l = x.at(p.df2, (long)l * M2 * D);
-    RC(fh_layernorm_bwd_launch(dt, dy, dy2, x.at(p.s2, (long)l * M2 * D), x.W<float>(p.st2_mean) + l * M2,
-                               x.W<float>(p.st2_rstd) + l * M2, lp + p.pl.l_ln2_w, x.W(p.ds2), df2_l, lg + p.pl.l_ln2_w,
+    unsigned char* df2_l = x.at(p.df2, (long)l * Ms * D);
+    RC(fh_layernorm_bwd_launch(dt, dy, dy2, x.at(p.s2, (long)l * Ms * D), x.W<float>(p.st2_mean) + l * Ms,
+                               x.W<float>(p.st2_rstd) + l * Ms, lp + p.pl.l_ln2_w, x.W(p.ds2), df2_l, lg + p.pl.l_ln2_w,
                                lg + p.pl.l_ln2_b, (int)M2, D, x.drop(0.f, 0), x.drop(drop3 ? c.dropout : 0.f, site + 3), x.st));
     {  // dz1 = (df2 . W2) * mask2 * gelu'(z1)
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(df2_l, FH_R_CONTIG, D);
       if (const void* wt = x.layT(l, p.wl.t_fc2)) g.Y = fh_operand(wt, FH_R_CONTIG, D);   // W2^T [Fd][D]
       else g.Y = fh_operand(x.nat(lpo + p.pl.l_fc2_w), FH_R_STRIDED, Fd);
-      g.C = x.at(p.dz1, (long)l * M2 * Fd);
+      g.C = x.at(p.dz1, (long)l * Ms * Fd);
       g.M = (int)M2; g.N = Fd; g.Kseg = D; g.ldc = Fd;
       g.ep.drop = x.drop(c.activation_dropout, site + 2);
-      g.ep.gelu_aux = x.at(p.z1, (long)l * M2 * Fd);
+      g.ep.gelu_aux = x.at(p.z1, (long)l * Ms * Fd);
       RC(fh_gemm_launch(g, dt, x.st));
     }
     {  // dx1 = dz1 . W1 + ds2
       GemmParams g = fh_gemm_params();
-      g.X = fh_operand(x.at(p.dz1, (long)l * M2 * Fd), FH_R_CONTIG, Fd);
+      g.X = fh_operand(x.at(p.dz1, (long)l * Ms * Fd), FH_R_CONTIG, Fd);
       if (const void* wt = x.layT(l, p.wl.t_fc1)) g.Y = fh_operand(wt, FH_R_CONTIG, Fd);  // W1^T [D][Fd]
       else g.Y = fh_operand(x.nat(lpo + p.pl.l_fc1_w), FH_R_STRIDED, D);
       g.C = x.W(p.dx1b);
@@ -1146,9 +1266,9 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.ep.residual = x.W(p.ds2);
       RC(fh_gemm_launch(g, dt, x.st));
     }
-    unsigned char* dao_l = x.at(p.dao, (long)l * M2 * D);
-    RC(fh_layernorm_bwd_launch(dt, x.W(p.dx1b), nullptr, x.at(p.s1, (long)l * M2 * D), x.W<float>(p.st1_mean) + l * M2,
-                               x.W<float>(p.st1_rstd) + l * M2, lp + p.pl.l_ln1_w, x.W(p.ds1), dao_l, lg + p.pl.l_ln1_w,
+    unsigned char* dao_l = x.at(p.dao, (long)l * Ms * D);
+    RC(fh_layernorm_bwd_launch(dt, x.W(p.dx1b), nullptr, x.at(p.s1, (long)l * Ms * D), x.W<float>(p.st1_mean) + l * Ms,
+                               x.W<float>(p.st1_rstd) + l * Ms, lp + p.pl.l_ln1_w, x.W(p.ds1), dao_l, lg + p.pl.l_ln1_w,
                                lg + p.pl.l_ln1_b, (int)M2, D, x.drop(0.f, 0), x.drop(c.dropout, site + 1), x.st));
     {  // da = dao . Wo
       GemmParams g = fh_gemm_params();
@@ -1159,45 +1279,34 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.M = (int)M2; g.N = D; g.Kseg = D; g.ldc = D;
       RC(fh_gemm_launch(g, dt, x.st));
     }
-    RC(fh_attention_bwd_launch(dt, x.at(p.qkv, (long)l * M2 * 3 * D), x.at(p.attn, (long)l * M2 * D), x.W(p.da),
-                               x.W<float>(p.lse) + (long)l * B * H * s.T2, x.W<float>(p.delta),
-                               x.at(p.dqkv, (long)l * M2 * 3 * D), len_2, B, s.T2, H, D / H, scale,
+    RC(fh_attention_bwd_launch(dt, x.at(p.qkv, (long)l * Ms * 3 * D), x.at(p.attn, (long)l * Ms * D), x.W(p.da),
+                               x.W<float>(p.lse) + (long)l * B * H * s.Ts, x.W<float>(p.delta),
+                               x.at(p.dqkv, (long)l * Ms * 3 * D), len_l, B, Tl, H, D / H, scale,
                                x.drop(c.attention_dropout, site + 0), x.st, p.attn_scr >= 0 ? x.W<float>(p.attn_scr) : nullptr));
     if (l == L - 1 && d_qkv_last)  // attention-logit / value-relation transfer gradients enter at the last layer's q|k|v
-      RC(fh_unary_launch(dt, d_qkv_last, x.at(p.dqkv, (long)l * M2 * 3 * D), M2 * 3 * D, 1, x.st));
+      RC(fh_unary_launch(dt, d_qkv_last, x.at(p.dqkv, (long)l * Ms * 3 * D), M2 * 3 * D, 1, x.st));
     {  // dxin = dqkv . Wqkv + ds1
       GemmParams g = fh_gemm_params();
-      g.X = fh_operand(x.at(p.dqkv, (long)l * M2 * 3 * D), FH_R_CONTIG, 3 * D);
+      g.X = fh_operand(x.at(p.dqkv, (long)l * Ms * 3 * D), FH_R_CONTIG, 3 * D);
       if (const void* wt = x.layT(l, p.wl.t_qkv)) g.Y = fh_operand(wt, FH_R_CONTIG, 3 * D);  // Wqkv^T [D][3D]
       else g.Y = fh_operand(x.nat(lpo + p.pl.l_qkv_w), FH_R_STRIDED, D);
-      g.C = x.at(p.dxin, (long)(l & 1) * M2 * D);
+      g.C = x.at(p.dxin, (long)(l & 1) * Ms * D);
       g.M = (int)M2; g.N = D; g.Kseg = 3 * D; g.ldc = D;
       g.ep.residual = x.W(p.ds1);
       RC(fh_gemm_launch(g, dt, x.st));
     }
-    dy_next = x.at(p.dxin, (long)(l & 1) * M2 * D);
+    dy_next = x.at(p.dxin, (long)(l & 1) * Ms * D);
   }
-  RC(layer_wgrads(0, L));
+  RC(layer_wgrads(0, s.idx, s.Mp));          // layers in front of the TR conv (none in the shipped layout)
+  RC(layer_wgrads(s.idx, L - s.idx, s.M2));
   if (g_notify.on()) {  // every transformer layer's weights, biases and LayerNorm parameters
     RC(g_notify.fire(p.pl.layer0, (long)L * p.pl.layer_stride, true));
     g_notify.seg++;
     g_notify.layers_done = true;
   }
-  // ---------------- time-reduction conv backward
   const void* d_x1;  // gradient w.r.t. the encoder LayerNorm(+dropout) output
-  if (c.tr_factor > 0) {
-    GemmParams g = fh_gemm_params();
-    g.X = fh_operand(dy_next, FH_R_CONTIG, D);
-    g.Y = fh_operand(x.rel(p.wl.tr_wf), FH_R_STRIDED, (long)s.f * D);
-    g.C = x.W(p.dx1tr);
-    g.M = (int)M2; g.N = s.f * D; g.Kseg = D;
-    g.ldc = (long)s.f * D; g.c_rpb = s.T2; g.c_bstride = (long)s.Tp * D;
-    RC(fh_gemm_launch(g, dt, x.st));   // (the frames past f x T2, which the conv does not reach, were zeroed at the head of the backward)
-    GemmOperand A = fh_operand(x.W(p.x1), FH_R_STRIDED, (long)s.f * D);
-    A.rpb = s.T2; A.bstride = (long)s.Tp * D;
-    RC(wgrad(x, dy_next, D, A, grads + p.pl.tr_w, D, s.f * D, M2, 1, 0, 0, /*jdiv*/ D, /*sj1*/ 1, /*sj0*/ s.f, 0, 0, 0,
-             /*ldc*/ (long)D * s.f));
-    RC(fh_colsum_launch(dt, dy_next, grads + p.pl.tr_b, (int)M2, D, D, 1, 0, 0, 0, 1.f, x.st));
+  if (tr_first) {
+    RC(tr_backward(dy_next));
     d_x1 = x.W(p.dx1tr);
   } else {
     d_x1 = dy_next;

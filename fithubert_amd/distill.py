@@ -117,6 +117,11 @@ class W2V2Distil:
                                           "enable_tr_layer must be False (the reference's shapes disagree otherwise)")
             self.student_model.return_attn = True
             self.teacher_model.model.return_attn = True
+        if self.model_cfg.get("enable_tr_layer") and int(self.model_cfg.get("tr_layer_index", 0)) > 0 and self.model_cfg.get("layerwise_proj", True):
+            # the reference itself cannot run this: train.py:260-282 stacks the selected layers' projections, and the heads of layers in
+            # front of the TR conv give tr_reduce_factor x T' frames, the others tr_reduce_factor x T2 (torch.stack fails)
+            raise NotImplementedError("layer-wise distillation with tr_layer_index > 0: the reference's loss stacks projections of "
+                                      "different lengths (train.py:260-282); use tr_layer_index = 0 or layerwise_proj = False")
         if t["sim_loss_weight"] > 0 and t["distil_random_layer"] > 0:
             # the reference itself cannot run this: sim_loss is 3-D and train.py:305 takes mean((0, 2, 3))
             raise NotImplementedError("sim_loss_weight > 0 needs distil_random_layer == 0 (train.py:302-306 fails otherwise)")

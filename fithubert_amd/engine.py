@@ -51,14 +51,20 @@ def unsupported(cfg: CustomStudentModelConfig) -> Optional[str]:
         return "encoder_layerdrop > 0 is not built"
     if cfg.required_seq_len_multiple != 1 or cfg.crop_seq_to_multiple != 1:
         return "required_seq_len_multiple / crop_seq_to_multiple must be 1 (as in the shipped configs)"
-    if cfg.enable_tr_layer and (cfg.tr_layer_type != "conv1d" or cfg.tr_layer_index != 0 or cfg.tr_reduce_factor != 2):
-        return "time reduction is built for tr_layer_type='conv1d', tr_layer_index=0, tr_reduce_factor=2 (fithubert.yaml)"
+    if cfg.enable_tr_layer:
+        if cfg.tr_layer_type not in ("conv1d", "fc1", "fc2"):
+            raise NotImplementedError("Wrong type of time reduction layer."                      # modules/module.py:238-242, verbatim
+                                      "Time reduction layers must be one of ['fc1', 'fc2', 'conv1d'].")
+        if cfg.tr_layer_type != "conv1d":
+            return "tr_layer_type 'fc1' / 'fc2' (Linear time reduction over concatenated frames, module.py:215-228) is not built; 'conv1d' is"
+        if not (2 <= cfg.tr_reduce_factor <= 8):
+            return "tr_reduce_factor must be 2..8"
+        if not (0 <= cfg.tr_layer_index <= cfg.encoder_layers):
+            return "tr_layer_index must be 0..encoder_layers"
     if not cfg.layerwise_proj:
         # DistilHuBERT-style head (model.py:364-368): Linear -> GELU -> SplitLinear over len(pred_layer_id) tasks
         if len(cfg.pred_layers()) < 1:
             return "layerwise_proj=False without any pred_layer_id task has no head to train"
-        if cfg.enable_tr_layer:
-            return "layerwise_proj=False together with enable_tr_layer (shared upsampler, model.py:504-505) is not built"
     elif cfg.pred_head_final_dim == cfg.encoder_embed_dim:
         return "pred_head_final_dim == encoder_embed_dim (no lin_proj) is not built"
     return None
@@ -92,6 +98,7 @@ def make_config_c(cfg: CustomStudentModelConfig, dtype: str) -> StudentConfigC:
     c.n_tasks = 0 if cfg.layerwise_proj else len(cfg.pred_layers())
     c.inter_dim = cfg.pred_head_inter_dim if cfg.pred_head_inter_dim > 0 else cfg.encoder_embed_dim  # model.py:334-335
     c.cnn_head = int(cfg._cnn_weight > 0 and cfg.pred_head_final_dim != cfg.encoder_embed_dim)      # model.py:305-310
+    c.tr_index = cfg.tr_layer_index if cfg.enable_tr_layer else 0                                   # module.py:247-248
     return c
 
 
@@ -134,6 +141,53 @@ class Workspace:
         raw = self.buf[off.value: off.value + n * eb.value]
         return raw.view(dt).view(shape)
 
+    # ---- per-layer tensors.  With tr_layer_index > 0 the layers in front of the time-reduction conv run on the T' frames of the
+    # frontend and the rest on the reduced ones; every per-layer array keeps one slot stride (the T' frames) and a layer fills the
+    # first rows of its slot, `xo` has one more slot for the conv's output (csrc/engine.hip: Shapes).  These accessors hide that.
+    def _frames(self, l: int) -> int:
+        tp, t2 = self.eng.frames(self.call.S)
+        return tp if l < self.eng.tr_index else t2
+
+    def _slot(self, name: str, i: int, frames: int) -> torch.Tensor:
+        v = self.view(name)[i]                       # [B, Ts(*f), C] or [B * Ts, C]
+        v = v.reshape(self.call.B, -1, v.shape[-1])
+        return v[:, :frames] if v.shape[1] == frames else v.reshape(-1, v.shape[-1])[: self.call.B * frames].view(self.call.B, frames, -1)
+
+    def layer_out(self, l: int) -> torch.Tensor:
+        """output of transformer layer l, [B, T_l, D]"""
+        e = self.eng
+        return self._slot("xo", l + 1 + (1 if (e.tr_index > 0 and l >= e.tr_index) else 0), self._frames(l))
+
+    def fc2_out(self, l: int) -> torch.Tensor:
+        return self._slot("f2", l, self._frames(l))
+
+    def tr_out(self) -> torch.Tensor:
+        """output of the time-reduction conv, [B, T2, D] (tr_layer_results[0])"""
+        e = self.eng
+        return self._slot("xo", e.tr_index + 1 if e.tr_index > 0 else 0, e.frames(self.call.S)[1])
+
+    def encoder_out(self) -> torch.Tensor:
+        """the encoder's output x: the last layer's, or the TR conv's when tr_layer_index == encoder_layers"""
+        e = self.eng
+        if e.c.tr_factor > 0 and e.tr_index == e.c.layers:
+            return self.tr_out()
+        return self.layer_out(e.c.layers - 1)
+
+    def head_pred(self, i: int) -> torch.Tensor:
+        """prediction of head slot i: [B, T * f, P]; layer-wise heads in front of the TR conv see the T' frames"""
+        e = self.eng
+        f = e.c.tr_factor if e.c.tr_factor > 0 else 1
+        if e.c.n_tasks > 0 or not self.call.heads_on:
+            frames = e.frames(self.call.S)[1] * f
+        else:
+            frames = self._frames(i) * f
+        return self._slot("pred", i, frames)
+
+    def hidden_grad_buffer(self) -> torch.Tensor:
+        """zeros shaped like the d_hidden operand of backward(): [L][slot rows][D] (layer l's gradient in the first rows of slot l)"""
+        f2 = self.view("f2")
+        return torch.zeros(f2.shape[0], f2.shape[1] * f2.shape[2], f2.shape[3], device=f2.device, dtype=f2.dtype)
+
 
 class StudentEngine:
     """Flat fp32 parameters (+ gradients) and the native forward / backward over them."""
@@ -156,6 +210,7 @@ class StudentEngine:
         self._prepared_version = -1
         self.version = 0
         self.layers = cfg.conv_layers()
+        self.tr_index = int(self.c.tr_index) if self.c.tr_factor > 0 else 0
         # per-shape choice of the bf16 GEMM main loop (fh_gemm_tune): measured once per (batch, length class) in a
         # throw-away forward + backward before the first training step of that shape; FH_GEMM_AUTOTUNE=0 turns it off
         self.auto_tune = self.c.dtype != L.DT_F32 and os.environ.get("FH_GEMM_AUTOTUNE", "1") != "0"
@@ -277,8 +332,8 @@ class StudentEngine:
             if heads_on:
                 self.backward(ws, d_pred=(1e-3 * torch.randn_like(ws.view("pred"), dtype=torch.float32)).to(self.elem), grads=scratch)
             else:
-                xo = ws.view("xo")[1:]
-                self.backward(ws, d_hidden=(1e-3 * torch.randn_like(xo, dtype=torch.float32)).to(self.elem).contiguous(), grads=scratch)
+                dh = ws.hidden_grad_buffer()
+                self.backward(ws, d_hidden=(1e-3 * torch.randn_like(dh, dtype=torch.float32)).to(self.elem).contiguous(), grads=scratch)
             torch.cuda.synchronize(self.device)
         finally:
             n = self.lib.fh_gemm_tune(0)

@@ -36,7 +36,9 @@ class _StudentFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero tensors
         pred, xo = ws.view("pred"), ws.view("xo")
         feats, f2 = eng.features_to_distill(ws), ws.view("f2")   # model.py:482-487 (cnn_proj_head output when present)
-        qkv_last = ws.view("qkv")[-1].view(source.shape[0], -1, 3 * eng.c.embed_dim)   # last layer's packed q|k|v projection
+        B = source.shape[0]
+        t_last = ws._frames(eng.c.layers - 1)
+        qkv_last = ws.view("qkv")[-1][: B * t_last].view(B, t_last, 3 * eng.c.embed_dim)   # last layer's packed q|k|v projection
         ctx.mark_non_differentiable(f2)
         return pred, xo, feats, f2, qkv_last
 
@@ -48,9 +50,17 @@ class _StudentFn(torch.autograd.Function):
         g = torch.zeros_like(eng.params)
         d_hidden = None
         if d_xo is not None:
-            if d_xo[0].abs().max().item() != 0:
+            idx, L = eng.tr_index, eng.c.layers
+            tr_slot = idx + 1 if idx > 0 else 0
+            if eng.c.tr_factor > 0 and d_xo[tr_slot].abs().max().item() != 0:
                 raise NotImplementedError("gradient w.r.t. tr_layer_results is not built")
-            d_hidden = d_xo[1:].contiguous()
+            if idx == 0:
+                d_hidden = d_xo[1:].contiguous()
+            else:   # slot l + 1 (+ 1 behind the TR conv's own slot) holds layer l's output: csrc/engine.hip Shapes
+                d_hidden = torch.stack([d_xo[l + 1 + (1 if l >= idx else 0)] for l in range(L)]).contiguous()
+            d_hidden = d_hidden.view(L, -1, d_hidden.shape[-1])
+            if eng.c.tr_factor > 0 and idx == L and d_pred is None:
+                raise NotImplementedError("gradient w.r.t. layer_results alone with tr_layer_index == encoder_layers is not built")
         eng.backward(ctx.ws, d_pred=d_pred.contiguous() if d_pred is not None else None, d_hidden=d_hidden, grads=g,
                      d_cnn=d_feats.contiguous() if d_feats is not None else None,
                      d_qkv_last=d_qkv.contiguous().view(-1, d_qkv.shape[-1]) if d_qkv is not None else None)
@@ -221,24 +231,68 @@ class CustomStudentModel(nn.Module):
                             v.copy_(src[sk].float())
         self.mark_params_updated()
 
+    # ------------------------------------------------------------------ native building blocks outside the engine's plan
+    def _native_linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """y = x w^T + b over the last dim through the library's GEMM (fh_linear_forward); inference only."""
+        import ctypes as C
+        from . import _lib as L
+        eng = self.engine
+        rows = x.reshape(-1, x.shape[-1]).to(eng.elem).contiguous()
+        wc = w.detach().to(eng.elem).contiguous()
+        y = torch.empty(rows.shape[0], wc.shape[0], device=rows.device, dtype=eng.elem)
+        L.check(eng.lib.fh_linear_forward(eng.c.dtype, rows.data_ptr(), wc.data_ptr(), b.detach().float().contiguous().data_ptr(), None, None,
+                                          y.data_ptr(), rows.shape[0], rows.shape[1], wc.shape[0], 0, eng.stream()), "fh_linear_forward")
+        return y.view(*x.shape[:-1], wc.shape[0])
+
+    def _conv_transpose(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """ConvTranspose1d(Cin, Cout, k = s = f) over time on x [B, T, Cin] -> [B, T * f, Cout] as ONE GEMM: frame t becomes the f
+        frames (t f + j), y[t][(j, co)] = sum_ci x[t][ci] w[ci][co][j] + b[co] (the layout move of the weight is not arithmetic)."""
+        cin, cout, f = w.shape
+        wp = w.detach().permute(2, 1, 0).reshape(f * cout, cin)
+        y = self._native_linear(x, wp, b.detach().repeat(f))
+        return y.view(x.shape[0], x.shape[1] * f, cout)
+
+    def _upsample(self, x):
+        """modules/model.py:401-407: the shared ``upsampler`` ConvTranspose1d(D, D, k = s = tr_reduce_factor) over time, B x T x D ->
+        B x (T f) x D; identity without a TR layer (``self.upsampler`` is None there).  Inside ``forward`` the engine runs it natively
+        (layerwise_proj = False with enable_tr_layer, model.py:503-506); this method is the reference's public surface -- inference
+        only, no autograd."""
+        if not self.cfg.enable_tr_layer:
+            return x
+        v = self.engine.param_views()
+        with torch.no_grad():
+            return self._conv_transpose(x, v["upsampler.weight"], v["upsampler.bias"]).to(x.dtype)
+
+    def _final_proj(self, x):
+        """``final_proj`` = the last LayerWiseProjHead (modules/model.py:393-396, module.py:649-661) on x [B, T, D]; inference only."""
+        v = self.engine.param_views()
+        last = f"proj_head.{self.cfg.encoder_layers - 1}."
+        with torch.no_grad():
+            if self.cfg.enable_tr_layer:
+                x = self._conv_transpose(x, v[last + "upsampler.weight"], v[last + "upsampler.bias"])
+            return self._native_linear(x, v[last + "lin_proj.weight"], v[last + "lin_proj.bias"])
+
     def _early_exit(self, source, padding_mask, layer: int):
         """``forward(..., layer=k)`` (modules/model.py:424,554-558 -> modules/module.py:270,303-337): the encoder's module list -- the
-        time-reduction conv at index ``tr_layer_index`` = 0, then the transformer layers -- stops behind module k; ``layer_results``
+        transformer layers with the time-reduction conv inserted at ``tr_layer_index`` -- stops behind module k; ``layer_results``
         holds the transformer layers run so far and the projection applies to module k's output.  An inference surface: it runs a
         truncated copy of the student (same weights, cached per k) without autograd."""
-        n_mod = self.cfg.encoder_layers + (1 if self.cfg.enable_tr_layer else 0)
-        k = int(layer) + 1 - (1 if self.cfg.enable_tr_layer else 0)     # transformer layers that run
+        tr = bool(self.cfg.enable_tr_layer)
+        idx = int(self.cfg.tr_layer_index) if tr else -1
+        k_mod = int(layer)
+        tr_runs = tr and idx <= k_mod
+        k = k_mod + 1 - (1 if tr_runs else 0)                           # transformer layers that run
         if self.layerwise_proj and self._heads_on:
             # the reference indexes layer_results with every head's number (model.py:495-499)
             raise IndexError("list index out of range")
-        if k < 1:
-            raise NotImplementedError("early exit behind the time-reduction conv alone (layer=0 with enable_tr_layer) is not built")
         import dataclasses
-        key = (k, self._heads_on)
+        only_tr = k < 1                                                 # layer=0 with the TR conv first: nothing but the conv runs
+        key = (max(k, 1), tr_runs, self._heads_on)
         cache = self.__dict__.setdefault("_exit_models", {})
         sub = cache.get(key)
         if sub is None:
-            cfg = dataclasses.replace(self.cfg, encoder_layers=k, init_conv_layers=False, init_encoder_layers=0)
+            cfg = dataclasses.replace(self.cfg, encoder_layers=max(k, 1), init_conv_layers=False, init_encoder_layers=0,
+                                      enable_tr_layer=tr_runs, tr_layer_index=min(idx, max(k, 1)) if tr_runs else 0)
             for f in ("_teacher_task_agnostic", "_cnn_weight"):
                 setattr(cfg, f, getattr(self.cfg, f))
             sub = CustomStudentModel(cfg, dtype=self.engine.dtype_name, device=str(self.engine.device))
@@ -247,14 +301,23 @@ class CustomStudentModel(nn.Module):
             cache[key] = sub
         own = self.state_dict()
         want = sub._name_map()
-        sub.load_state_dict({n: own[n] for n in want if n in own}, strict=False)   # final_proj.* / shared heads keep their names
+        sub_sd = sub.state_dict()
+        # a module of the truncated encoder keeps its index; without the TR conv (not reached yet) nothing shifts either
+        src = {n: own[n] for n in want if n in own and tuple(own[n].shape) == tuple(sub_sd[n].shape)}
+        sub.load_state_dict(src, strict=False)                          # final_proj.* / shared heads keep their names
         sub.train(self.training)
         with torch.no_grad():
             res = sub.forward(source, padding_mask)
+            if only_tr:
+                # module 0 is the TR conv: x = its output (module.py:317-321,336-337), no transformer layer has run
+                x = res["tr_layer_results"][0].transpose(0, 1)
+                res = dict(res, layer_results=[], projections=None,
+                           x=(self._final_proj(x) if self.layerwise_proj else (self._upsample(x) if tr else x)))
         return res
 
     def forward(self, source, padding_mask=None, layer=None):
-        if layer is not None and int(layer) < self.cfg.encoder_layers + (1 if self.cfg.enable_tr_layer else 0) - 1:
+        n_mod = self.cfg.encoder_layers + (1 if self.cfg.enable_tr_layer else 0)
+        if layer is not None and int(layer) < n_mod - 1:
             return self._early_exit(source, padding_mask, int(layer))
         if not source.is_cuda:
             raise RuntimeError("CustomStudentModel (fithubert_amd) computes on the GPU only; move `source` to the device")
@@ -270,20 +333,36 @@ class CustomStudentModel(nn.Module):
         self._step_seed = (self._step_seed + 1) & 0x7FFFFFFF
         pred, xo, feats, f2, qkv_last = _StudentFn.apply(self.flat, self, source, lengths, self.training, self._heads_on, self._step_seed)
         L = self.cfg.encoder_layers
-        layer_results = [(xo[i + 1].transpose(0, 1), None, f2[i].transpose(0, 1)) for i in range(L)]
+        eng = self.engine
+        idx = eng.tr_index                                  # 0 without a TR layer
+        tr = bool(self.cfg.enable_tr_layer)
+        Tp_, T2_ = eng.frames(S)
+        f = eng.c.tr_factor if tr else 1
+
+        def rows(t, frames):        # a slot [B, Ts, C] whose first B * frames rows are the tensor [B, frames, C] (csrc/engine.hip: Shapes)
+            if t.shape[1] == frames:
+                return t
+            return t.reshape(-1, t.shape[-1])[: B * frames].view(B, frames, t.shape[-1])
+
+        t_of = lambda l: Tp_ if l < idx else T2_
+        out_of = lambda l: rows(xo[l + 1 + (1 if (idx > 0 and l >= idx) else 0)], t_of(l))
+        layer_results = [(out_of(i).transpose(0, 1), None, rows(f2[i], t_of(i)).transpose(0, 1)) for i in range(L)]
         if self.return_attn:  # utils/utils.py:193-280 patched in by train.py:64-78: (attn_logits, v_rel) of the LAST layer
             from .attn_transfer import attention_extras
             key_len = None
             if lengths is not None:
-                key_len = torch.tensor(self.engine.frame_lengths(lengths)[1], dtype=torch.int32, device=source.device)
+                fl = self.engine.frame_lengths(lengths)
+                key_len = torch.tensor(fl[1] if idx < L else fl[0], dtype=torch.int32, device=source.device)
             extras = attention_extras(qkv_last, self.cfg.encoder_attention_heads, key_len)
             layer_results[-1] = (layer_results[-1][0], extras, layer_results[-1][2])
-        tr_layer_results = [xo[0].transpose(0, 1)] if self.cfg.enable_tr_layer else []
-        if not self.layerwise_proj:  # model.py:503-516: x is the encoder output, projections B x N x T x D
-            x = xo[L]
+        tr_out = rows(xo[idx + 1 if idx > 0 else 0], T2_) if tr else None
+        tr_layer_results = [tr_out.transpose(0, 1)] if tr else []
+        enc_x = tr_out if (tr and idx == L) else out_of(L - 1)          # the encoder's output (module.py:339-343)
+        if not self.layerwise_proj:  # model.py:503-516: x is the encoder output (up-sampled behind a TR layer), projections B x N x T x D
+            x = self._upsample(enc_x) if tr else enc_x
             projections = pred.permute(1, 0, 2, 3) if self._heads_on else None
         elif self._heads_on:
-            projections = [pred[i] for i in range(L)]
+            projections = [rows(pred[i], t_of(i) * f) for i in range(L)]
             x = projections[-1]
         else:
             projections = None

@@ -309,7 +309,7 @@ typedef struct {
   int conv_dim[FH_MAX_CONV], conv_k[FH_MAX_CONV], conv_stride[FH_MAX_CONV];
   int embed_dim, ffn_dim, heads, layers;  /* encoder_embed_dim, encoder_ffn_embed_dim, encoder_attention_heads, encoder_layers */
   int conv_pos, conv_pos_groups;
-  int tr_factor;                   /* time-reduction conv1d at layer index 0 (0 = no TR layer) */
+  int tr_factor;                   /* time-reduction Conv1d(k = s = tr_reduce_factor), modules/module.py:230-236 (0 = no TR layer) */
   int pred_dim;                    /* pred_head_final_dim */
   float dropout, attention_dropout, activation_dropout, dropout_input;
   float feature_grad_mult;
@@ -321,6 +321,11 @@ typedef struct {
   /* CNN distillation (train.py:241-246): 1 = cnn_proj_head GELU -> Linear(embed_dim, pred_dim) on the post_extract_proj output
    * (model.py:305-310, present when pred_dim != embed_dim and cnn_loss_weight > 0); the workspace tensor "cnn_pred" holds it */
   int cnn_head;
+  /* tr_layer_index (modules/module.py:247-248): the TR conv sits in front of transformer layer tr_index (0 .. layers; == layers:
+   * behind the last one).  Layers in front of it run on the T' frames of the conv frontend, the rest on the reduced frames.  With
+   * n_tasks >= 1 and a TR layer the DistilHuBERT-style head reads the encoder output through the shared `upsampler`
+   * ConvTranspose1d (modules/model.py:341-348,401-407,503-506). */
+  int tr_index;
 } fh_student_config;
 
 /* per-call shape info */

@@ -355,3 +355,36 @@ def test_large_teacher_restatement_against_huggingface_stable_layer_norm():
             _close(ours["layer_results"][0][0].transpose(0, 1)[b, :nf], theirs.hidden_states[1][b, :nf], tol=5e-5)
             last = torch.nn.functional.layer_norm(ours["layer_results"][1][0].transpose(0, 1), (1024,), lnw, lnb, 1e-5)
             _close(last[b, :nf], theirs.last_hidden_state[b, :nf], tol=5e-5)
+
+
+@pytest.mark.parametrize("tag", ["idx2", "last", "f3", "split"])
+def test_time_reduction_variants_against_reference_vectors(golden_dir, tag):
+    """tr_layer_index > 0, tr_layer_index == encoder_layers, tr_reduce_factor = 3, and the shared upsampler in front of the
+    DistilHuBERT-style head (layerwise_proj = False with enable_tr_layer): the restatement against vectors captured from the unmodified
+    reference by oracle/gen_golden_tr.py (modules/module.py:230-248,317-328; modules/model.py:341-348,401-407,503-516)."""
+    fx = np.load(os.path.join(golden_dir, "student_tr_variants.npz"))
+    cfg = yaml.safe_load(str(fx[tag + "/cfg_yaml"]))
+    sd = S.random_state_dict(cfg, seed=int(fx[tag + "/weight_seed"]))
+    wav = torch.from_numpy(fx["wav"])
+    with torch.no_grad():
+        out = S.student_forward(sd, cfg, wav, None)
+    if tag != "split":
+        _close(out["tr_layer_results"][0], fx[tag + "/tr"])
+    if tag == "idx2":
+        frames = [out["layer_results"][i][0].shape[0] for i in range(4)]
+        assert frames[0] == frames[1] == 19 and frames[2] == frames[3] == 9
+        for i in range(4):
+            _close(out["layer_results"][i][0][..., ::2], fx[f"idx2/layer{i}"])
+            _close(out["projections"][i][..., ::4], fx[f"idx2/proj{i}"])
+        assert out["projections"][0].shape[1] == 38 and out["projections"][3].shape[1] == 18
+    elif tag == "last":
+        _close(out["projections"][1][..., ::4], fx["last/proj1"])
+        assert out["tr_layer_results"][0].shape[0] == 9 and out["layer_results"][1][0].shape[0] == 19
+    elif tag == "f3":
+        for i in range(3):
+            _close(out["projections"][i][..., ::4], fx[f"f3/proj{i}"])
+        assert out["projections"][0].shape[1] == 3 * out["layer_results"][0][0].shape[0] == 18
+    else:
+        _close(out["x"][..., ::2], fx["split/x"])
+        _close(out["projections"][..., ::4], fx["split/projections"])
+        assert out["x"].shape[1] == 2 * out["layer_results"][3][0].shape[0] == out["projections"].shape[2]
