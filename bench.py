@@ -217,6 +217,81 @@ def time_steps(task, batches, steps: int, warm: int):
     return time.perf_counter() - t0, utt, samples
 
 
+def dp_projection(bucket_samples, bucket_ms, world: int = 8, epochs: int = 3):
+    """PROJECTED data-parallel efficiency of one epoch over length-sorted buckets (utils/dataset.py:27-53) from single-GPU step
+    times: per step every rank runs its bucket and all wait for the slowest (the gradient all-reduce is a barrier), so
+    efficiency = sum_steps mean_r t / sum_steps max_r t, for DistributedSampler's plain deal of a shuffled list (train.py:423-428,
+    494) and for the balanced deal (dataset.balanced_rank_buckets: the ranks of a step draw from one length neighbourhood).
+    `bucket_ms` = measured (bucket max samples x batch, ms per step) pairs; a quadratic in the bucket's padded length is fitted
+    through them (attention is O(T^2), the rest O(T)).  A projection: communication and stragglers are not in it."""
+    import numpy as np
+    from fithubert_amd.dataset import balanced_rank_buckets, rank_buckets
+    xs = np.array([m[0] for m in bucket_ms], dtype=np.float64)
+    ys = np.array([m[1] for m in bucket_ms], dtype=np.float64)
+    coef = np.polyfit(xs / xs.max(), ys, 2 if len(xs) >= 4 else 1)
+    t = np.polyval(coef, np.asarray(bucket_samples, dtype=np.float64) / xs.max())
+    t = np.maximum(t, ys.min() * 0.25)
+    fit_err = float(np.max(np.abs(np.polyval(coef, xs / xs.max()) - ys) / ys))
+    out = {}
+    for name in ("plain", "balanced"):
+        tot_mean = tot_max = 0.0
+        for ep in range(epochs):
+            per_rank = [(balanced_rank_buckets(list(bucket_samples), ep, r, world) if name == "balanced"
+                         else rank_buckets(len(bucket_samples), ep, r, world)) for r in range(world)]
+            for step in zip(*per_rank):
+                ts = t[list(step)]
+                tot_mean += ts.mean()
+                tot_max += ts.max()
+        out[name] = round(float(tot_mean / tot_max), 4)
+    return {"projected": True, "world": world, "efficiency_plain_deal": out["plain"], "efficiency_balanced_deal": out["balanced"],
+            "fit_max_rel_error": round(fit_err, 4), "measured_buckets": [[int(a), round(float(b), 3)] for a, b in bucket_ms],
+            "what": "PROJECTION from single-GPU step times, not a measurement: sum over steps of the ranks' mean step time / of their "
+                    "max, one epoch of the train-clean-100 length table in buckets of the per-GPU batch; all-reduce time and "
+                    "host jitter are not modelled"}
+
+
+def run_libri_workload(task, args, dev, rank: int, world: int):
+    """BASELINE.json configs[2]: data parallel over bucketed variable-length LibriSpeech-shaped synthetic batches.  Every rank walks
+    ITS buckets of the committed train-clean-100 length table (tests/golden, data) -- bucketed as utils/dataset.py:27-53, dealt out
+    by dataset.balanced_rank_buckets (default) or DistributedSampler's plain deal (--assign plain) -- `steps` timed steps over a
+    working set of at most 8 distinct buckets per rank, each seen (and its GEMM shapes tuned) once before the timed region.
+    Returns (elapsed seconds on this rank, utterances, valid samples, per-step ms list, bucket max samples)."""
+    import numpy as np
+    from fithubert_amd.dataset import SyntheticLibriDataset, balanced_rank_buckets, rank_buckets, to_device
+    lens = np.load(os.path.join(ROOT, "tests", "golden", "libri_train_clean_100_lengths.npz"))["lengths_sorted_desc"]
+    ds = SyntheticLibriDataset(lens.tolist(), batch_size=args.libri_batch, seed=0)
+    order = (balanced_rank_buckets(ds.bucket_samples(), 0, rank, world) if args.assign == "balanced"
+             else rank_buckets(len(ds), 0, rank, world))
+    n_set = max(1, min(8, args.steps))
+    work = [to_device(ds[i], dev) for i in order[:n_set]]
+    for i, b in enumerate(work):                   # untimed: every bucket shape once (tuning is blocking by design)
+        task.training_step(b, batch_idx=i, next_batch=work[(i + 1) % n_set])
+    for i in range(args.warmup):
+        task.training_step(work[i % n_set], batch_idx=i, next_batch=work[(i + 1) % n_set])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    utt = smp = 0
+    for j in range(args.steps):
+        b = work[j % n_set]
+        task.training_step(b, batch_idx=args.warmup + j, next_batch=work[(j + 1) % n_set])
+        evs[j + 1].record()
+        utt += b["x"].shape[0]
+        smp += sum(b["_lengths"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    task._next_teacher = None
+    per_step = [evs[j].elapsed_time(evs[j + 1]) for j in range(args.steps)]
+    return elapsed, utt, smp, per_step, [int(b["x"].shape[1]) for b in work]
+
+
 def run_variants(task, cfg, args, dev, budget_s: float):
     """The other regimes SURVEY 8d asks to be reported, measured AFTER the timed region of the headline workload and never part
     of `value`: fixed-length buckets 2..16 s, bucketed LibriSpeech-shaped batches (config 3), and the 24-layer student against
@@ -261,6 +336,19 @@ def run_variants(task, cfg, args, dev, budget_s: float):
             "equiv_10s_per_s": round(smp / SAMPLES_10S / dt, 1), "ms_per_step": round(dt / 4 * 1e3, 2),
             "workload": "BASELINE.json configs[2] per GPU: four random buckets of the LibriSpeech train-clean-100 length table bucketed as the "
                         "reference does (whole set sorted by length, consecutive buckets of 64), zero-padded to the bucket maximum"}
+    # ---- PROJECTED DP-8 efficiency of a LibriSpeech epoch, plain vs balanced deal of the length-sorted buckets (config 3 under DP)
+    if left() > 45 and "librispeech_histogram_buckets" in out:
+        ds = SyntheticLibriDataset(lens.tolist(), batch_size=bsz, seed=0)
+        n_b = len(ds)
+        meas = []
+        for pos in (0, n_b // 12, n_b // 5, n_b // 2, (3 * n_b) // 4, n_b - 1):     # longest ... shortest bucket
+            if left() < 30:
+                break
+            b = to_dev(ds[pos])
+            dt, _, _ = time_steps(task, [b], 2, 2)
+            meas.append((int(b["x"].shape[1]) * int(b["x"].shape[0]), dt / 2 * 1e3))
+        if len(meas) >= 3:
+            out["librispeech_dp8_projection"] = dp_projection(ds.bucket_samples(), meas, world=8)
     # ---- the reference's own training configuration: 3 utterances per GPU, 4 accumulated micro-batches per optimizer step
     # (data/conf/fithubert.yaml:9-10) -- the latency-bound end of the design
     if left() > 30:
@@ -269,12 +357,31 @@ def run_variants(task, cfg, args, dev, budget_s: float):
         t3 = W2V2Distil(c3, dtype=args.dtype, device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native",
                         teacher=task.teacher_model)
         t3.configure_optimizers(num_training_steps=100)
-        batches = [fixed_length_batch(3, SAMPLES_10S, seed=50 + i, device=dev) for i in range(4)]
-        dt, utt, smp = time_steps(t3, batches, 16, 8)
+        batches = [fixed_length_batch(3, SAMPLES_10S, seed=50 + i, device=dev) for i in range(8)]
+        dt, utt, smp = time_steps(t3, batches[:4], 16, 8)
         assert t3.opt_step == 6
-        out["reference_batch_3x4"] = {"per_gpu_batch": 3, "accumulate_grad_batches": 4, "utt_per_s": round(utt / dt, 1),
-                                      "ms_per_micro_batch": round(dt / 16 * 1e3, 2), "ms_per_optimizer_step": round(dt / 4 * 1e3, 2),
-                                      "workload": "fithubert.yaml as shipped: batch_size 3, accumulate_grad_batches 4, fixed 10 s clips"}
+        # the same windows as fit() runs them: four equal-shape unpadded micro-batches of one accumulation window merged into ONE
+        # batch of 12 (W2V2Distil.fuse_window -- exact, nothing couples utterances), one optimizer step per merged batch
+        wins = [t3.fuse_window(batches[0:4]), t3.fuse_window(batches[4:8])]
+        assert all(w is not None for w in wins)
+        for i in range(3):
+            t3.training_step_fused(wins[i % 2], batch_idx=i, next_batch=wins[(i + 1) % 2])
+        torch.cuda.synchronize()
+        t0f = time.perf_counter()
+        for i in range(8):
+            t3.training_step_fused(wins[i % 2], batch_idx=i, next_batch=wins[(i + 1) % 2])
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t0f
+        t3._next_teacher = None
+        out["reference_batch_3x4"] = {"per_gpu_batch": 3, "accumulate_grad_batches": 4, "utt_per_s": round(8 * 12 / dtf, 1),
+                                      "ms_per_optimizer_step": round(dtf / 8 * 1e3, 2),
+                                      "utt_per_s_micro_batch_loop": round(utt / dt, 1),
+                                      "ms_per_micro_batch_in_the_loop": round(dt / 16 * 1e3, 2),
+                                      "ms_per_optimizer_step_in_the_loop": round(dt / 4 * 1e3, 2),
+                                      "workload": "fithubert.yaml as shipped: batch_size 3, accumulate_grad_batches 4, fixed 10 s clips; "
+                                                  "utt_per_s = the accumulation window run as one merged batch of 12 (what fit() does for "
+                                                  "equal-shape unpadded windows: identical gradient, one forward / backward instead of four); "
+                                                  "utt_per_s_micro_batch_loop = the reference's loop of four micro-batches of 3"}
         del t3
     # ---- the same workload in the reference's own precision (train.py:469,496 precision=16): IEEE-half operands, dynamic loss scaling
     if left() > 40 and args.dtype == "bf16":
@@ -410,6 +517,13 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3, help="timed steps (the last ones) with per-launch HIP-event GEMM timing")
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (fixed 2-16 s buckets, LibriSpeech-shaped "
                     "buckets, 24-layer student + Large teacher), which is measured after the timed region at N = 1")
+    ap.add_argument("--workload", default="fixed10s", choices=["fixed10s", "libri"],
+                    help="fixed10s = BASELINE.json configs[1] (the headline); libri = configs[2]: every rank walks its length-sorted "
+                         "LibriSpeech-shaped buckets (train-clean-100 length table), raw and 10 s-equivalent utterances/s")
+    ap.add_argument("--libri-batch", type=int, default=64, help="utterances per bucket (per GPU) of --workload libri")
+    ap.add_argument("--assign", default="balanced", choices=["balanced", "plain"],
+                    help="--workload libri: balanced = the ranks of a step take buckets of one length neighbourhood "
+                         "(dataset.balanced_rank_buckets, what fit() does for world > 1); plain = DistributedSampler's deal")
     ap.add_argument("--no-kd-delta", action="store_true", help="skip the in-run KD-loss parity measurement (kd_loss_delta)")
     ap.add_argument("--variants-budget", type=float, default=150.0, help="seconds the variants block may take (entries that do not fit are left out)")
     args = ap.parse_args()
@@ -451,6 +565,41 @@ def main():
                       teacher_cfg=teacher_cfg)
     total_steps = args.steps + args.warmup
     task.configure_optimizers(num_training_steps=max(total_steps, 100))
+
+    if args.workload == "libri":
+        # ---- BASELINE.json configs[2]: every rank walks its own length-sorted buckets; value = all ranks' utterances / the slowest rank's time
+        elapsed, utt, smp, per_step, tops = run_libri_workload(task, args, dev, rank, world)
+        stats = torch.tensor([elapsed, float(utt), float(smp), sum(per_step) / len(per_step)], device=dev, dtype=torch.float64)
+        if world > 1:
+            allst = [torch.zeros_like(stats) for _ in range(world)]
+            dist.all_gather(allst, stats)
+        else:
+            allst = [stats]
+        allst = [t.cpu().tolist() for t in allst]
+        if rank == 0:
+            t_max = max(a[0] for a in allst)
+            tot_utt, tot_smp = sum(a[1] for a in allst), sum(a[2] for a in allst)
+            rank_ms = [round(a[3], 3) for a in allst]
+            res = {
+                "metric": "distillation utterances/sec (bucketed variable-length LibriSpeech-shaped batches)",
+                "value": round(tot_utt / t_max, 2), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(t_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "equiv_10s_per_s": round(tot_smp / SAMPLES_10S / t_max, 2),
+                "config": {"workload": "BASELINE.json configs[2]: fithubert.yaml student + HuBERT-Base-shaped teacher, data parallel over "
+                                       "length-sorted buckets of the LibriSpeech train-clean-100 length table (utils/dataset.py:27-53), "
+                                       f"{args.assign} deal of the buckets to the ranks, zero-padded to each bucket's maximum",
+                           "per_gpu_batch": args.libri_batch, "global_batch": world * args.libri_batch, "parallelism": f"dp{world}",
+                           "assignment": args.assign, "rank0_bucket_max_samples": tops},
+                "per_rank_mean_ms_per_step": rank_ms,
+                "rank_step_time_spread": round(max(rank_ms) / max(min(rank_ms), 1e-9), 4),
+                "rank0_ms_per_step": [round(v, 3) for v in per_step],
+            }
+            print(json.dumps(res))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B = args.batch
     pool = []

@@ -147,6 +147,7 @@ SIGNATURES = {
     "fh_stream_create_cu_range": (_I, [_I, _I, C.POINTER(_P)]),
     "fh_stream_destroy": (_I, [_P]),
     "fh_stream_cu_census": (_I, [_P, _I, _P]),
+    "fh_debug_copy_reduce": (_I, [_P, _P, C.c_long, _I, _P]),
     "fh_student_side_stream": (_I, [_P]),
     "fh_gemm_tune": (_I, [_I]),
     "fh_gemm_tune_export": (_I, [_P, _P, _P, _I]),

@@ -365,9 +365,12 @@ int fh_conv0_bwd_blocks(int B, int nchunk) {
 // width (in float2) of the per-utterance block between the statistics partials and the backward's partial sums: MAXK + MAXK^2 fp64
 // waveform sums (or, historically, C0 (a, b) pairs)
 int fh_conv0_ab_width(int C0) { return C0 > MAXK + MAXK * MAXK ? C0 : MAXK + MAXK * MAXK; }
+// one block of (K + 2 sums per channel, laid out with the MAXK + 2 pitch the combine reads) per utterance: the GEMM epilogue of layer
+// 1's data gradient accumulates into it, the engine zeroes exactly this many floats at the head of the backward
+long fh_conv0_fused_wpart_floats(int B, int C0) { return (long)B * C0 * (MAXK + 2); }
 long fh_conv0_fused_scratch_n(int B, int T0, int C0) {   // (one block of backward sums per utterance: the GEMM epilogue accumulates)
   const long nchunk = fh_conv0_nchunk(T0);
-  return 2L * B * nchunk * C0 + 2L * B * fh_conv0_ab_width(C0) + (long)B * C0 * (MAXK + 2);
+  return 2L * B * nchunk * C0 + 2L * B * fh_conv0_ab_width(C0) + fh_conv0_fused_wpart_floats(B, C0);
 }
 long fh_conv0_scratch_n(int B, int T0, int C0) {
   const long nchunk = fh_conv0_nchunk(T0);

@@ -324,3 +324,23 @@ int fh_adamw_amp_launch(float* p, const float* g, float* m, float* v, long n, fl
   FH_CHECK_LAUNCH();
   return 0;
 }
+
+// Stand-in for a collective's reduction kernel (tools/rccl_standin.py): `workgroups` workgroups of 512 threads add src into dst,
+// 16 bytes per lane and pass -- RCCL's ring all-reduce runs a few tens of workgroups of this kind next to the step's kernels, and
+// what matters for the data-parallel step is whether they find CUs while a persistent GEMM launch holds the chip.
+namespace {
+__global__ void __launch_bounds__(512) copy_reduce_kernel(float* __restrict__ dst, const float* __restrict__ src, long n4) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(src)[i], b = reinterpret_cast<float4*>(dst)[i];
+    b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+    reinterpret_cast<float4*>(dst)[i] = b;
+  }
+}
+}  // namespace
+extern "C" int fh_debug_copy_reduce(float* dst, const float* src, long n, int workgroups, fh_stream_t stream) {
+  if (!dst || !src || n < 4 || workgroups < 1) return -1;
+  hipLaunchKernelGGL(copy_reduce_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, dst, src, n / 4);
+  FH_CHECK_LAUNCH();
+  return 0;
+}

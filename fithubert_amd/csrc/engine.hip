@@ -368,6 +368,7 @@ struct Plan {
   // workspace offsets
   long y[FH_MAX_CONV], z[FH_MAX_CONV], dz[FH_MAX_CONV];
   long c0_mean, c0_rstd, c0_scratch;
+  bool c0_fused = false;
   long ln0, ln0_mean, ln0_rstd, features, x0, zc, psum, ln1_mean, ln1_rstd, x1;
   long xo, qkv, attn, lse, s1, st1_mean, st1_rstd, xa, z1, hbuf, f2, s2, st2_mean, st2_rstd;
   long u = -1, pred, hz = -1, hh = -1, dhz = -1, gfeat = -1, cnn_pred = -1, dgf = -1, dwm = -1, dwm16 = -1, dbl = -1;
@@ -390,8 +391,9 @@ struct Plan {
     }
     c0_mean = ws.add("c0_mean", {B, c.conv_dim[0]}, 4);
     c0_rstd = ws.add("c0_rstd", {B, c.conv_dim[0]}, 4);
-    c0_scratch = ws.add("c0_scratch", {tr && conv0_bwd_fusable(c) ? fh_conv0_fused_scratch_n((int)B, sh.T[0], c.conv_dim[0])
-                                                                  : fh_conv0_scratch_n((int)B, sh.T[0], c.conv_dim[0])}, 4);
+    c0_fused = tr && conv0_bwd_fusable(c);   // evaluated ONCE: the scratch size, the zeroing and the data-gradient launch all read this flag
+    c0_scratch = ws.add("c0_scratch", {c0_fused ? fh_conv0_fused_scratch_n((int)B, sh.T[0], c.conv_dim[0])
+                                                : fh_conv0_scratch_n((int)B, sh.T[0], c.conv_dim[0])}, 4);
     const long E = c.conv_dim[c.n_conv - 1];
     ln0 = ws.add("ln0", {Mp, E}, es);
     ln0_mean = ws.add("ln0_mean", {Mp}, 4);
@@ -1385,7 +1387,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     unsigned char* dst = x.W<unsigned char>(i - 1 >= 1 ? p.dz[i - 1] : p.dz[0]);
     const unsigned char* aux = i - 1 >= 1 ? x.W<unsigned char>(p.z[i - 1]) : nullptr;
     const void* wf = x.rel(p.wl.conv_wf[i]);
-    if (i == 1 && conv0_bwd_fusable(c)) {
+    if (i == 1 && p.c0_fused) {
       // layer 1's data gradient IS d loss / d y0: its tiles are consumed in the GEMM's epilogue by conv 0's weight-gradient sums (one
       // utterance per group, so that a 256-frame tile shares its GroupNorm statistics and waveform window); dz[0] is never written
       GemmParams g = fh_gemm_params();
@@ -1497,13 +1499,13 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     const long cp = fh_posconv_cp(D / c.conv_pos_groups);
     if (!rc) rc = (int)hipMemsetAsync(x.W(p.pos_dws), 0, (long)c.conv_pos_groups * c.conv_pos * cp * cp * 4, x.st);
   }
-  if (!rc && conv0_bwd_fusable(x.p.c) && x.p.c.feature_grad_mult > 0.f) {
+  if (!rc && x.p.c0_fused) {
     // the utterances' blocks of conv-0 weight-gradient sums, which layer 1's data-gradient epilogue accumulates into: zeroed HERE, at
     // the head of the backward -- in front of that launch the 0.8 MB fill waited 0.74 ms for a CU beside the weight-gradient stream
     const Plan& p = x.p;
     const long B = p.sh.B, nchunk = fh_conv0_nchunk(p.sh.T[0]);
     float* wpart = reinterpret_cast<float*>(x.W<float2>(p.c0_scratch) + B * nchunk * p.c.conv_dim[0] + B * fh_conv0_ab_width(p.c.conv_dim[0]));
-    rc = (int)hipMemsetAsync(wpart, 0, (size_t)B * p.c.conv_dim[0] * 12 * sizeof(float), x.st);
+    rc = (int)hipMemsetAsync(wpart, 0, (size_t)fh_conv0_fused_wpart_floats((int)B, p.c.conv_dim[0]) * sizeof(float), x.st);
   }
   if (!rc) rc = backward_body(x, grads, wave, lens, d_pred, d_hidden, d_cnn, d_qkv_last);
   const int j = g_wside.join(x.st);

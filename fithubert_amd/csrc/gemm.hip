@@ -57,6 +57,11 @@ unsigned long long tune_key_q(const GemmParams& p, int dtype, unsigned mask, int
   mix(p.ep.atomic); mix(p.ep.atomic ? 0 : p.splitk);
   mix(p.ep.preact != nullptr); mix(p.ep.act); mix(p.ep.gelu_aux != nullptr); mix(p.ep.residual != nullptr);
   if (p.ep.aux_factor) mix(104729);
+  // epilogue options that decide whether the streaming loop 8 can take the launch at all (stream_ok): a class measured without them
+  // must not hand "loop 8" to a launch that has them -- the padded-batch projection would drop to the 128-tile fallback
+  if (p.ep.row_len || p.ep.out_f32 || p.ep.tail_cols || (p.c_rpb > 0 && p.c_bstride != (long)p.c_rpb * p.ldc))
+    mix(2750159 + (p.ep.row_len ? 1 : 0) + (p.ep.out_f32 ? 2 : 0) + (p.ep.tail_cols ? 4 : 0) +
+        ((p.c_rpb > 0 && p.c_bstride != (long)p.c_rpb * p.ldc) ? 8 : 0));
   if (p.Y.seg1_limit > 0) mix(7919 + p.Y.seg1_limit);
   if (dtype == 2) mix(15485863);  // f16 launches keep their own measurements
   if (mask) mix(0x5bd1e995L + mask);  // ... and so do launches of a stream with a restricted set of loops

@@ -2561,6 +2561,8 @@ template <typename H> int launch_path_h(const GemmParams& p, int path, hipStream
   if (path == 6 && ring_ok(p, 32)) return launch_pp<H>(p, stream);
   if (path == 7 && ring_ok(p, 64)) return launch_8ph<H>(p, stream);
   if (path == 8 && ring_ok(p, 64) && stream_ok(p)) { fh_g_last_loop = 8; return launch_8ph_stream<H>(p, stream); }
+  // a table entry "loop 8" reached by a launch the streaming loop cannot take (a neighbour class's choice): its non-persistent twin
+  if (path == 8 && ring_ok(p, 64)) { fh_g_last_loop = 7; return launch_8ph<H>(p, stream); }
   return launch_32<H>(p, stream);
 }
 

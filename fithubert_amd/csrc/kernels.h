@@ -15,6 +15,7 @@ int fh_conv0_bwd_launch(int dtype, const float* wave, const float* w, const floa
                         float* dgamma, float* dbeta, int B, int S, int C0, int K, int stride, float grad_scale,
                         hipStream_t st, int stats_ready = 0, int ext_nblk = 0);
 int fh_conv0_ab_width(int C0);   // float2 per utterance between the statistics partials and the backward's partial sums
+long fh_conv0_fused_wpart_floats(int B, int C0);   // floats of the per-utterance sum blocks the fused conv-0 backward accumulates into (zeroed per step)
 long fh_conv0_fused_scratch_n(int B, int T0, int C0);  // scratch when layer 1's data-gradient GEMM leaves the backward's partial sums (ext_nblk = fh_conv0_nchunk)
 
 int fh_conv0_ln_gelu_launch(int dtype, const float* wave, const float* w, const float* bias, const float* gamma, const float* beta, void* y,

@@ -149,6 +149,9 @@ class W2V2Distil:
         self.batch_size = t["batch_size"]
         self.num_gpus = len(t["gpus"]) if isinstance(t["gpus"], list) else t["gpus"]
         self.accumulate = int(t.get("accumulate_grad_batches", 1))
+        # fit(): an accumulation window of equal-shape, unpadded micro-batches runs as ONE batch (fuse_window); FH_FUSE_ACCUMULATION=0
+        # keeps the reference's micro-batch loop
+        self.fuse_accumulation = os.environ.get("FH_FUSE_ACCUMULATION", "1") != "0"
         self._rows_loss = self.sim_loss_weight > 0   # row-wise kernel (rec + cosine); its out[-1] is the fully weighted total
         # KD loss inside the projection heads' GEMM epilogue (fh_student_forward_kd): built and bit-identical, but it takes that GEMM off
         # the streaming loop 8 and its operand-bound epilogue runs serially with the K loop -- 0.4 - 1.1 % SLOWER per step than the
@@ -192,7 +195,12 @@ class W2V2Distil:
             # the student's own persistent launches end within 0.1 - 0.4 ms and keep all CUs (FH_DP_RESERVE_CUS overrides the 8;
             # a guess until a multi-GPU node has timed it: SCALE runs have been skipped so far)
             from . import _lib as _L
-            _L.lib().fh_gemm_stream_reserve_cus(self.teacher_stream.cuda_stream, int(os.environ.get("FH_DP_RESERVE_CUS", "8")))
+            n_res = int(os.environ.get("FH_DP_RESERVE_CUS", "8"))
+            _L.lib().fh_gemm_stream_reserve_cus(self.teacher_stream.cuda_stream, n_res)
+            # ... and, until a multi-GPU A/B says otherwise, on every other stream too: the reserve of the rounds before
+            # the per-stream form existed (FH_DP_RESERVE_STUDENT=0 keeps the student's persistent launches on all CUs)
+            if os.environ.get("FH_DP_RESERVE_STUDENT", "1") != "0":
+                _L.lib().fh_gemm_reserve_cus(n_res)
         if os.environ.get("FH_TEACHER_STREAM", "1") == "0":   # A/B: teacher serialised on the main stream
             self.teacher_stream = None
         # FH_TEACHER_LOOPS / FH_STUDENT_LOOPS = comma-separated GEMM main loops a stream's per-shape choice may use (fh_gemm_stream_loops)
@@ -455,6 +463,36 @@ class W2V2Distil:
             self.optimizer_step()
         return out
 
+    def fuse_window(self, batches):
+        """The micro-batches of ONE accumulation window as one batch, or None when that would not be exact.  Gradient accumulation
+        (train.py:469-471 ``accumulate_grad_batches``) exists to fit a batch into the memory of the reference's GPUs; nothing in the
+        model couples utterances (GroupNorm is per utterance, LayerNorm per frame), so for micro-batches of EQUAL shape WITHOUT
+        padding the gradient of the window -- sum over micro-batches of d(mean loss) / accumulate -- is the gradient of the mean loss
+        of the concatenated batch, and one forward / backward over 4 x 3 utterances replaces four latency-bound ones over 3 (on 288 GB
+        of HBM the merged batch always fits).  Padded or unequal micro-batches are NOT merged: GroupNorm's statistics run over the
+        padded length and the loss averages over padded frames, both change with the padding of the merged batch."""
+        if len(batches) < 2 or self._micro != 0:
+            return None
+        shp = batches[0]["x"].shape
+        for b in batches:
+            if b["x"].shape != shp or b.get("_any_pad", True) or min(b.get("_lengths", [0])) != shp[1]:
+                return None
+        out = {"x": torch.cat([b["x"] for b in batches], 0), "_lengths": [n for b in batches for n in b["_lengths"]], "_any_pad": False,
+               "_fused_micro_batches": len(batches)}
+        if batches[0].get("padding_mask") is not None:
+            out["padding_mask"] = torch.cat([b["padding_mask"] for b in batches], 0)
+        return out
+
+    @torch.no_grad()
+    def training_step_fused(self, merged, batch_idx: int = 0, next_batch=None, seed: Optional[int] = None):
+        """One optimizer step on a window merged by ``fuse_window``: the whole window is ONE micro-batch."""
+        assert self._micro == 0 and merged.get("_fused_micro_batches", 0) == self.accumulate
+        acc, self.accumulate = self.accumulate, 1
+        try:
+            return self.training_step(merged, batch_idx=batch_idx, next_batch=next_batch, seed=seed)
+        finally:
+            self.accumulate = acc
+
     @torch.no_grad()
     def flush_accumulation(self):
         """End of an epoch with a partial accumulation window: reduce and apply what has been summed, as Lightning does on the last
@@ -507,7 +545,10 @@ class W2V2Distil:
         else:
             skipped = int(self.amp_state[2])
         if skipped > self._amp_seen_skipped:
-            self.loss_scale = max(1.0, self.loss_scale * self.amp_backoff ** (skipped - self._amp_seen_skipped))
+            # ONE halving per overflow episode: the host reads the counter one step behind, so the step issued right after an overflow
+            # still ran with the overflowing scale and is (usually) skipped too -- both skips belong to the same episode and cost
+            # scale / 2 as with GradScaler, not scale / 4; a scale that is still too high shows up as the next episode
+            self.loss_scale = max(1.0, self.loss_scale * self.amp_backoff)
             self._amp_seen_skipped = skipped
             self._amp_since_growth = 0
         else:
@@ -591,12 +632,37 @@ class W2V2Distil:
             best = [(float(v), str(pth)) for v, pth in mc.get("best_k_models", [])]
         for epoch in range(first_epoch, num_epochs):
             order = epoch_order(epoch)
-            nxt = to_dev(train_data[order[0]])
             tl = None
-            for i, _ in enumerate(order):
-                cur = nxt
-                nxt = to_dev(train_data[order[i + 1]]) if i + 1 < len(order) else None
-                tl = self.training_step(cur, batch_idx=i, next_batch=nxt)
+            # the epoch as a stream of UNITS: a unit is one micro-batch, or -- accumulate_grad_batches > 1 -- a whole accumulation
+            # window merged into one batch when that is exact (fuse_window).  One unit of look-ahead feeds the teacher's prefetch.
+            loaded = {}                                  # bucket position -> device batch (at most 2 windows alive)
+
+            def get(j):
+                if j not in loaded:
+                    loaded[j] = to_dev(train_data[order[j]])
+                return loaded[j]
+
+            def unit_at(j, pos):
+                """(batch, buckets consumed) starting at bucket position j, `pos` micro-batches into the accumulation window"""
+                acc = self.accumulate
+                if self.fuse_accumulation and acc > 1 and pos == 0 and j + acc <= len(order):
+                    merged = self.fuse_window([get(j + t) for t in range(acc)])
+                    if merged is not None:
+                        return merged, acc
+                return get(j), 1
+
+            j, pos = 0, self._micro
+            cur, n_cur = unit_at(0, pos)
+            while j < len(order):
+                j2, pos2 = j + n_cur, (pos + n_cur) % max(1, self.accumulate)
+                nxt, n_nxt = unit_at(j2, pos2) if j2 < len(order) else (None, 0)
+                if n_cur > 1:
+                    tl = self.training_step_fused(cur, batch_idx=j, next_batch=nxt)
+                else:
+                    tl = self.training_step(cur, batch_idx=j, next_batch=nxt)
+                for t in range(j, j2):
+                    loaded.pop(t, None)
+                j, pos, cur, n_cur = j2, pos2, nxt, n_nxt
             self.flush_accumulation()
             self.training_epoch_end()
             rec = {"epoch": epoch, "train_loss": float(tl[-1].item()) if tl is not None else float("nan")}

@@ -287,7 +287,14 @@ class CustomStudentModel(nn.Module):
             raise IndexError("list index out of range")
         import dataclasses
         only_tr = k < 1                                                 # layer=0 with the TR conv first: nothing but the conv runs
-        key = (max(k, 1), tr_runs, self._heads_on)
+        # the exit lies in front of the TR conv: the truncated encoder has none, but the heads keep their ConvTranspose1d (it is built
+        # from cfg.enable_tr_layer, not from what has run: module.py:625-647) -- the truncated copy runs without heads and the head /
+        # shared upsampler is applied to its encoder output here
+        before_tr = tr and not tr_runs
+        if before_tr and not self.layerwise_proj and self._heads_on:
+            raise NotImplementedError("early exit in front of the TR conv with the DistilHuBERT-style head switched on is not built")
+        heads_in_sub = self._heads_on and not before_tr
+        key = (max(k, 1), tr_runs, heads_in_sub)
         cache = self.__dict__.setdefault("_exit_models", {})
         sub = cache.get(key)
         if sub is None:
@@ -296,7 +303,7 @@ class CustomStudentModel(nn.Module):
             for f in ("_teacher_task_agnostic", "_cnn_weight"):
                 setattr(cfg, f, getattr(self.cfg, f))
             sub = CustomStudentModel(cfg, dtype=self.engine.dtype_name, device=str(self.engine.device))
-            if not self._heads_on:
+            if not heads_in_sub:
                 sub._disable_projection_heads()
             cache[key] = sub
         own = self.state_dict()
@@ -313,6 +320,9 @@ class CustomStudentModel(nn.Module):
                 x = res["tr_layer_results"][0].transpose(0, 1)
                 res = dict(res, layer_results=[], projections=None,
                            x=(self._final_proj(x) if self.layerwise_proj else (self._upsample(x) if tr else x)))
+            elif before_tr:
+                x = res["layer_results"][-1][0].transpose(0, 1)
+                res = dict(res, projections=None, x=(self._final_proj(x) if self.layerwise_proj else self._upsample(x)))
         return res
 
     def forward(self, source, padding_mask=None, layer=None):

@@ -152,6 +152,10 @@ int fh_stream_create_cu_range(int first, int count, fh_stream_t* out);
 int fh_stream_destroy(fh_stream_t stream);
 /* Diagnostic: n single-wave workgroups on `stream`, each writing (XCC id << 16 | HW_REG_HW_ID[15:0]) -- which CUs a stream reaches. */
 int fh_stream_cu_census(unsigned* out, int n, fh_stream_t stream);
+/* Diagnostic stand-in for a collective's reduction kernel: `workgroups` x 512 threads, dst[i] += src[i] over n floats (what an
+ * RCCL ring all-reduce of the student's gradients, train.py:494, runs beside the step; tools/rccl_standin.py times its completion
+ * beside a persistent GEMM launch for different fh_gemm_reserve_cus settings). */
+int fh_debug_copy_reduce(float* dst, const float* src, long n, int workgroups, fh_stream_t stream);
 /* Per-shape main-loop table used by path 9.  mode 1: every bf16 launch of a shape class not seen yet times its candidate
  * loops (and, for atomic weight-gradient launches, split-K factors) on the stream, BLOCKING, writing / accumulating the
  * output several times -- only for throw-away passes (StudentEngine.autotune).  mode 0: stop measuring; unmeasured shapes

@@ -584,3 +584,42 @@ def test_forward_layer_early_exit():
             want = F.linear(up.transpose(1, 2), sd["final_proj.lin_proj.weight"], sd["final_proj.lin_proj.bias"])
             assert res["x"].shape == want.shape and _rel_l2(res["x"], want) < 1e-4, layer
             assert torch.equal(res["padding_mask"], full["padding_mask"])
+
+
+def test_merged_accumulation_window_has_the_gradient_of_the_micro_batch_loop():
+    """W2V2Distil.fuse_window: four unpadded equal-shape micro-batches of an accumulation window as ONE batch (what fit() does) give
+    the gradient the reference's loop accumulates (train.py:469-471): fp32 engine, dropout off, same teacher -- sum_i grad(mean loss_i)
+    / 4 == grad(mean loss of the concatenation)."""
+    import copy
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "conf", "fithubert.yaml")))
+    cfg["distiller"].update(encoder_layers=2, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    cfg["train"].update(distil_random_layer=1, accumulate_grad_batches=4)
+    from fithubert_amd.dataset import fixed_length_batch
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 2
+    task = W2V2Distil(copy.deepcopy(cfg), dtype="float32", device=DEV, teacher_cfg=tc, seed=3, teacher_native_frontend=True)
+    task.configure_optimizers(num_training_steps=10)
+    micro = [fixed_length_batch(2, 16000, seed=200 + i, device=DEV) for i in range(4)]
+    seen = {}
+    orig = task.optimizer_step
+
+    def capture():                       # the gradient buffer as the optimizer sees it, then NO update: both runs start from the same weights
+        seen["g"] = task.engine.grads.clone() * (task.sync.scale / task.accumulate)
+        task._micro = 0
+
+    task.optimizer_step = capture
+    for i, b in enumerate(micro):
+        task.training_step(b, batch_idx=i)
+    loop = seen.pop("g")
+    merged = task.fuse_window(micro)
+    assert merged is not None and merged["x"].shape[0] == 8
+    task._next_teacher = None
+    task.training_step_fused(merged, batch_idx=0)
+    fused = seen.pop("g")
+    rel = ((fused.double() - loop.double()).norm() / loop.double().norm()).item()
+    assert loop.norm().item() > 0 and rel < 2e-3, rel        # fp32 atomics / summation order only
+    # a padded micro-batch keeps the loop
+    padded = dict(micro[1], _any_pad=True)
+    assert task.fuse_window([micro[0], padded, micro[2], micro[3]]) is None

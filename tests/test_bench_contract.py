@@ -52,3 +52,21 @@ def test_variants_block_is_outside_the_headline():
     assert len(v["fixed_length_buckets"]) == 8 and {e["seconds"] for e in v["fixed_length_buckets"]} == {2, 4, 6, 8, 10, 12, 14, 16}
     for key in ("librispeech_histogram_buckets", "student24_hubert_large_teacher"):
         assert v[key]["utt_per_s"] > 0
+
+
+def test_dp_projection_prefers_the_balanced_deal_on_the_librispeech_table():
+    """bench.dp_projection (the `librispeech_dp8_projection` variant): with step time growing in the bucket's padded length the plain
+    DistributedSampler deal of the length-sorted buckets (utils/dataset.py:27-53, train.py:423-428) waits for the longest bucket of
+    every step; the balanced deal (dataset.balanced_rank_buckets, what fit() uses for world > 1) does not."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    lens = np.load(os.path.join(ROOT, "tests", "golden", "libri_train_clean_100_lengths.npz"))["lengths_sorted_desc"]
+    bs = SyntheticLibriDataset(lens.tolist(), batch_size=64).bucket_samples()
+    meas = [(bs[i], 3.0 + 40.0 * bs[i] / bs[0] + 8.0 * (bs[i] / bs[0]) ** 2) for i in (0, 37, 89, 222, 333, 444)]
+    p = bench.dp_projection(bs, meas, world=8)
+    assert p["projected"] is True and p["fit_max_rel_error"] < 1e-6
+    assert 0.7 < p["efficiency_plain_deal"] < 0.9 < p["efficiency_balanced_deal"] <= 1.0
+    json.dumps(p)

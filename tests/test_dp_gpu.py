@@ -142,3 +142,30 @@ def test_two_ranks_train_on_one_gpu_over_gloo():
         if p.returncode != 0 or "DP2_OK" not in so:
             tb = se[se.rfind("Traceback"):] if "Traceback" in se else se[-3000:]
             raise AssertionError(f"rank {rank} failed:\n" + so[-1500:] + "\n" + tb[-4000:])
+
+
+def test_bench_libri_workload_two_ranks_on_one_gpu_over_gloo():
+    """`bench.py --gpus 2 --workload libri` end to end (BASELINE.json configs[2] under data parallelism): two ranks share the test
+    box's one GPU with the collectives staged through gloo; every rank walks ITS balanced buckets of the train-clean-100 length
+    table, rank 0 prints one JSON line with raw and 10 s-equivalent utterances/s and the per-rank step-time spread."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "libri", "--steps", "2", "--warmup", "0",
+           "--libri-batch", "2", "--no-cpu-baseline"]
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=500) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        if p.returncode != 0:
+            tb = se[se.rfind("Traceback"):] if "Traceback" in se else se[-3000:]
+            raise AssertionError(f"rank {rank} failed:\n" + so[-1500:] + "\n" + tb[-4000:])
+    line = [l for l in outs[0][0].splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["assignment"] == "balanced"
+    assert d["value"] > 0 and d["equiv_10s_per_s"] > d["value"]          # the longest buckets are > 10 s
+    assert len(d["per_rank_mean_ms_per_step"]) == 2 and d["rank_step_time_spread"] >= 1.0
+    assert not outs[1][0].strip().startswith("{")                           # only rank 0 prints

@@ -349,3 +349,26 @@ def test_fit_walks_balanced_buckets_under_data_parallel_and_sizes_the_schedule_t
     # the default: balanced under world > 1, the reference's plain deal on one rank
     ds = SyntheticLibriDataset(lens, batch_size=2, seed=0)
     assert balanced_rank_buckets(ds.bucket_samples(), 0, 1, 2) != rank_buckets(len(ds), 0, 1, 2)
+
+
+def test_fit_merges_equal_shape_accumulation_windows_and_only_those():
+    """fit() with accumulate_grad_batches = 2: a window of two unpadded, equal-length buckets runs as ONE forward / backward over the
+    concatenated batch (W2V2Distil.fuse_window; exact: nothing couples utterances, the loss is a mean); padded or unequal buckets
+    keep the reference's micro-batch loop (train.py:469-471).  Same number of optimizer steps either way."""
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    from fithubert_amd.distill import W2V2Distil
+    for lens, want_batches, want_fwd in (([600] * 8, [4, 4], 2),                    # 4 buckets of 2, all equal: 2 merged windows
+                                         ([600, 590, 580, 570, 560, 550, 540, 530], [2, 2, 2, 2], 4)):   # padded buckets: never merged
+        ds = SyntheticLibriDataset(lens, batch_size=2, seed=0)
+        task = W2V2Distil(_cfg(accumulate=2), dtype="float32", device="cpu", teacher=StubTeacher(), seed=0, student_model=StubStudent())
+        task.fit(ds, num_epochs=1)
+        eng = task.engine
+        assert eng.log.count("fwd") == want_fwd and eng.log.count("adamw") == 2 == task.opt_step, eng.log
+        assert [c[0].shape[0] for c in task.teacher_model.calls] == want_batches
+    os.environ["FH_FUSE_ACCUMULATION"] = "0"
+    try:
+        task = W2V2Distil(_cfg(accumulate=2), dtype="float32", device="cpu", teacher=StubTeacher(), seed=0, student_model=StubStudent())
+        task.fit(SyntheticLibriDataset([600] * 8, batch_size=2, seed=0), num_epochs=1)
+        assert task.engine.log.count("fwd") == 4 and task.opt_step == 2
+    finally:
+        del os.environ["FH_FUSE_ACCUMULATION"]
