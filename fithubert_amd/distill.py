@@ -191,11 +191,13 @@ class W2V2Distil:
         self.teacher_stream = _low_priority_stream(self.device) if self.device.type == "cuda" else None
         if self.sync.active and self.teacher_stream is not None:
             # data parallel: RCCL's collective kernels run beside the step.  A persistent GEMM launch owns every CU it runs on until
-            # it ends; the frozen teacher's (low-priority stream, up to 1.6 ms a launch) leave one CU per XCD to the collectives --
-            # the student's own persistent launches end within 0.1 - 0.4 ms and keep all CUs (FH_DP_RESERVE_CUS overrides the 8;
+            # it ends; the frozen teacher's (low-priority stream, up to 1.6 ms a launch) leave two CUs per XCD to the collectives --
+            # the student's own persistent launches end within 0.1 - 0.4 ms (FH_DP_RESERVE_CUS overrides the 16;
             # a guess until a multi-GPU node has timed it: SCALE runs have been skipped so far)
             from . import _lib as _L
-            n_res = int(os.environ.get("FH_DP_RESERVE_CUS", "8"))
+            # 16, not 8: on one GPU a 16-workgroup reduction kernel (tools/rccl_standin.py, profiles/r04_rccl_standin.txt) finished in
+            # 0.29 ms beside the persistent launches with 16 or 32 CUs held back and only BEHIND the whole 3 ms launch with 0 or 8
+            n_res = int(os.environ.get("FH_DP_RESERVE_CUS", "16"))
             _L.lib().fh_gemm_stream_reserve_cus(self.teacher_stream.cuda_stream, n_res)
             # ... and, until a multi-GPU A/B says otherwise, on every other stream too: the reserve of the rounds before
             # the per-stream form existed (FH_DP_RESERVE_STUDENT=0 keeps the student's persistent launches on all CUs)
