@@ -25,10 +25,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-mllvm", "-pragma-unroll-threshold=262144"]
 
 
+def _includes(path: str, seen: set) -> None:
+    """transitive closure of the quoted #includes of `path` (the library's own headers; system headers do not change)"""
+    import re
+    if path in seen or not os.path.exists(path):
+        return
+    seen.add(path)
+    with open(path, "r", errors="replace") as fh:
+        for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), flags=re.M):
+            _includes(os.path.normpath(os.path.join(os.path.dirname(path), m.group(1))), seen)
+
+
 def _deps_hash(src: str) -> str:
+    """sha1 over the source, the headers it (transitively) includes and the flags: a header edit recompiles only its users"""
+    deps: set = set()
+    _includes(os.path.normpath(src), deps)
     h = hashlib.sha1()
-    for f in [src] + sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cuh"))
-                            + glob.glob(os.path.join(HERE, "..", "include", "*.h"))):
+    for f in sorted(deps):
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
