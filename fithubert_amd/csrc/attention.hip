@@ -134,18 +134,15 @@ __global__ void __launch_bounds__(NW * 64, NW >= 8 ? 4 : 2) attn_fwd_kernel(cons
     for (int qt = 0; qt < 2; ++qt) {
       const int query = q0 + 16 * qt + r;
       float mx = -INFINITY;
-      if constexpr (TAIL) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (kt0 + 16 * kb + 4 * q + e >= klen) s[kb][qt][e] = -INFINITY;
-      }
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {   // 8 x v_max3_f32 over the 16 scores of this query in the tile
-        mx = max3_raw(mx, s[kb][qt][0], s[kb][qt][1]);
-        mx = max3_raw(mx, s[kb][qt][2], s[kb][qt][3]);
-      }
+        for (int e = 0; e < 4; ++e) {
+          float v = s[kb][qt][e];
+          if (TAIL && kt0 + 16 * kb + 4 * q + e >= klen) v = -INFINITY;
+          s[kb][qt][e] = v;
+          mx = fmaxf(mx, v);
+        }
       mx = xor_max(mx) * scale_log2e;  // scale > 0: max commutes with it; the per-element scaling rides in the fma below
       const float mnew = fmaxf(m[qt], mx);
       const float alpha = fast_exp2(m[qt] - mnew);

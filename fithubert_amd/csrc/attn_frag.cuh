@@ -166,13 +166,6 @@ __device__ __forceinline__ void row_pairs32(float v, float& a, float& b) {
   a = __uint_as_float(r[0]);
   b = __uint_as_float(r[1]);
 }
-// max of three without the canonicalising `v_max_f32 x, x, x` hipcc puts in front of every fmaxf on an MFMA result (it cannot
-// prove the accumulator is not a signalling NaN): one v_max3_f32 per two new elements instead of two canonicalise + two max
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 __device__ __forceinline__ float xor_max(float v) {
   float a, b;
   row_pairs16(v, a, b);
