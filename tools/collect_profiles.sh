@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries tools/final_measure.sh left in gpurun_out/ into profiles/ (tracked), round-tagged.
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
 tail -1 gpurun_out/bench_default.json > profiles/${R}_bench_default.json
 tail -1 gpurun_out/bench128_under_rocprof.json > profiles/${R}_bench_B128_under_rocprof.json
