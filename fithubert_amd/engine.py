@@ -56,7 +56,9 @@ def unsupported(cfg: CustomStudentModelConfig) -> Optional[str]:
             raise NotImplementedError("Wrong type of time reduction layer."                      # modules/module.py:238-242, verbatim
                                       "Time reduction layers must be one of ['fc1', 'fc2', 'conv1d'].")
         if cfg.tr_layer_type != "conv1d":
-            return "tr_layer_type 'fc1' / 'fc2' (Linear time reduction over concatenated frames, module.py:215-228) is not built; 'conv1d' is"
+            return ("tr_layer_type 'fc1' / 'fc2' (Linear time reduction over concatenated frames, module.py:215-228) is not built; 'conv1d' is "
+                    "(the reference's own concat_channelwise, module.py:360-379, builds its zero padding and result on the CPU and cannot run "
+                    "on a GPU either)")
         if not (2 <= cfg.tr_reduce_factor <= 8):
             return "tr_reduce_factor must be 2..8"
         if not (0 <= cfg.tr_layer_index <= cfg.encoder_layers):
