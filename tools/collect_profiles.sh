@@ -3,12 +3,12 @@
 R=${1:-r04}
 cd "$(dirname "$0")/.."
 tail -1 gpurun_out/bench_default.json > profiles/${R}_bench_default.json
-tail -1 gpurun_out/bench128_under_rocprof.json > profiles/${R}_bench_B128_under_rocprof.json
+tail -1 gpurun_out/benchB_under_rocprof.json > profiles/${R}_bench_B256_under_rocprof.json
 { echo "# FH_GEMM_TABLE=gpurun_out/gemm_table.json rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-isolated"
-  echo "# (table written by a preceding un-profiled run, so no tuning launches; B=128 x 10 s per GPU, bf16, teacher on a side stream; 10 steps + 1 prefetch teacher forward; tools/final_measure.sh)"
-  cat gpurun_out/bench128_kernel_stats.csv; } > profiles/${R}_bench_B128_kernel_stats.csv
+  echo "# (table written by a preceding un-profiled run, so no tuning launches; B=256 x 10 s per GPU, bf16, teacher on a side stream; 10 steps + 1 prefetch teacher forward; tools/final_measure.sh)"
+  cat gpurun_out/benchB_kernel_stats.csv; } > profiles/${R}_bench_B256_kernel_stats.csv
 cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
 python tools/merge_traffic.py profiles/${R}_bench_default.json
-[ -f gpurun_out/student_kernel_stats.csv ] && { echo "# rocprofv3 --kernel-trace --stats -- python tools/student_step.py --batch 128 --steps 8 --warmup 2 (student only: forward + KD loss + backward; GEMM table reused; tools/prof_student.sh)"; cat gpurun_out/student_kernel_stats.csv; } > profiles/${R}_student_step_B128_kernel_stats.csv
-[ -f gpurun_out/teacher_kernel_stats.csv ] && { echo "# rocprofv3 --kernel-trace --stats -- python tools/teacher_step.py --native 1 --batch 128 --steps 8 --warmup 2 (teacher forward only, every kernel native; GEMM table reused from an un-profiled run: no tuning launches in the trace; tools/prof_teacher.sh)"; cat gpurun_out/teacher_kernel_stats.csv; } > profiles/${R}_teacher_fwd_B128_kernel_stats.csv
+[ -f gpurun_out/student_kernel_stats.csv ] && { echo "# rocprofv3 --kernel-trace --stats -- python tools/student_step.py --batch 256 --steps 8 --warmup 2 (student only: forward + KD loss + backward; GEMM table reused; tools/prof_student.sh)"; cat gpurun_out/student_kernel_stats.csv; } > profiles/${R}_student_step_B256_kernel_stats.csv
+[ -f gpurun_out/teacher_kernel_stats.csv ] && { echo "# rocprofv3 --kernel-trace --stats -- python tools/teacher_step.py --native 1 --batch 256 --steps 8 --warmup 2 (teacher forward only, every kernel native; GEMM table reused from an un-profiled run: no tuning launches in the trace; tools/prof_teacher.sh)"; cat gpurun_out/teacher_kernel_stats.csv; } > profiles/${R}_teacher_fwd_B256_kernel_stats.csv
 ls -la profiles/
