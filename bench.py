@@ -80,11 +80,12 @@ CLASS_NOTE = {
 }
 
 
-def classify(r) -> str:
+def classify(r, batch: int = 128) -> str:
     if r["atomic"]:
         return "weight_gradients"
+    # conv-frontend launches have >= 999 rows per utterance, everything behind the frontend at most 499: the threshold scales with the batch
     # (conv layer 1's data gradient is launched per utterance -- groups = B, M = T0 rows each -- since it carries conv 0's weight-gradient sums)
-    big = r["M"] >= 100000 or (r["groups"] > 1 and r["M"] * r["groups"] >= 1000000)
+    big = r["M"] >= 781 * batch or (r["groups"] > 1 and r["M"] * r["groups"] >= 7812 * batch)
     if r["tag"] == 1:
         return "teacher_conv" if big else "teacher_linear"
     if big:
@@ -92,10 +93,10 @@ def classify(r) -> str:
     return "student_layer_gemms"
 
 
-def class_table(launches, steps: int, peak: float):
+def class_table(launches, steps: int, peak: float, batch: int = 128):
     out = {}
     for r in launches:
-        c = out.setdefault(classify(r), {"launches_per_step": 0, "ms_per_step": 0.0, "_fl": 0.0, "_by": 0.0})
+        c = out.setdefault(classify(r, batch), {"launches_per_step": 0, "ms_per_step": 0.0, "_fl": 0.0, "_by": 0.0})
         c["launches_per_step"] += 1
         c["ms_per_step"] += r["ms"]
         c["_fl"] += r["flops"]
@@ -659,7 +660,7 @@ def main():
                              "ms_per_step": round(tot_ms / max(1, min(args.prof_steps, args.steps)), 3)},
                 "note": "HIP events around every GEMM launch during the last %d timed steps" % min(args.prof_steps, args.steps)}
         # the same launches by CLASS: the dominant kernel's average hides the K = 480 layer GEMMs and the HBM-bound conv launches
-        roof["classes"] = {"live": class_table(live, n_prof, peak),
+        roof["classes"] = {"live": class_table(live, n_prof, peak, B),
                            "note": "GEMM launches of the last timed steps grouped by role; ms_per_step sums launch durations (three "
                                    "concurrent streams, so the sum can exceed the step); tflops / algorithmic_tb_per_s = algorithmic "
                                    "FLOPs / bytes (operands read once, output written once) over that time; frac_of_mfma_peak against "
@@ -681,7 +682,7 @@ def main():
         task.teacher_stream = side
         iso = collect_launches(lib)
         ms2, fl2, ln2 = slot_sums(iso, args.dtype != "float32")
-        roof["classes"]["isolated"] = class_table(iso, 2, peak)
+        roof["classes"]["isolated"] = class_table(iso, 2, peak, B)
         if ms2[v] > 0:
             ach2 = fl2[v] / (ms2[v] * 1e-3) / 1e12
             roof["isolated"] = {"achieved": round(ach2, 2), "frac": round(ach2 / roof["peak"], 4),
