@@ -12,7 +12,7 @@ T=gpurun_out/gemm_table.json; rm -f $T
 rm -rf gpurun_out/prof_final gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated --no-variants --gemm-table $T > /dev/null 2>&1
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-FH_GEMM_TABLE=$T rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-isolated --no-variants > gpurun_out/benchB_under_rocprof.json 2> gpurun_out/rocprof.err
+FH_GEMM_TABLE=$T rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python bench.py --steps 8 --warmup 2 --prof-steps 8 --no-kd-delta --no-cpu-baseline --no-isolated --no-variants > gpurun_out/benchB_under_rocprof.json 2> gpurun_out/rocprof.err
 cp $(ls gpurun_out/prof_final/*/*kernel_stats.csv | head -1) gpurun_out/benchB_kernel_stats.csv
 FH_GEMM_TABLE=$T rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated --no-variants --prof-steps 0 > /dev/null 2>&1
 FH_GEMM_TABLE=$T rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated --no-variants --prof-steps 0 > /dev/null 2>&1
