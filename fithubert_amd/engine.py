@@ -151,9 +151,11 @@ class Workspace:
         return tp if l < self.eng.tr_index else t2
 
     def _slot(self, name: str, i: int, frames: int) -> torch.Tensor:
-        v = self.view(name)[i]                       # [B, Ts(*f), C] or [B * Ts, C]
+        v = self.view(name)[i]                       # [B, Ts(*f), C] or [B * Ts, C]: the slot
         v = v.reshape(self.call.B, -1, v.shape[-1])
-        return v[:, :frames] if v.shape[1] == frames else v.reshape(-1, v.shape[-1])[: self.call.B * frames].view(self.call.B, frames, -1)
+        if v.shape[1] == frames:
+            return v
+        return v.reshape(-1, v.shape[-1])[: self.call.B * frames].view(self.call.B, frames, -1)   # the first rows of the slot
 
     def layer_out(self, l: int) -> torch.Tensor:
         """output of transformer layer l, [B, T_l, D]"""

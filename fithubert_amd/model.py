@@ -272,6 +272,27 @@ class CustomStudentModel(nn.Module):
                 x = self._conv_transpose(x, v[last + "upsampler.weight"], v[last + "upsampler.bias"])
             return self._native_linear(x, v[last + "lin_proj.weight"], v[last + "lin_proj.bias"])
 
+    def _split_head(self, x):
+        """The DistilHuBERT-style head (modules/model.py:364-368, module.py:585-619) on x [B, T, D] -> B x N x T x P through native
+        ops: Linear(D, I N) -> GELU -> per-task Linear(I, P); inference only (the engine's plan runs it inside ``forward``)."""
+        from . import _lib as L
+        v = self.engine.param_views()
+        eng = self.engine
+        with torch.no_grad():
+            h = self._native_linear(x, v["proj_head.0.weight"], v["proj_head.0.bias"]).contiguous()
+            L.check(eng.lib.fh_gelu_forward(eng.c.dtype, h.data_ptr(), h.data_ptr(), h.numel(), eng.stream()), "fh_gelu_forward")
+            n = self.n_tasks
+            inter = h.shape[-1] // n
+            outs = []
+            for t in range(n):
+                ht = h[..., t * inter:(t + 1) * inter].contiguous()
+                if n > 1:
+                    w, b = v["proj_head.2.weight"][t].t().contiguous(), v["proj_head.2.bias"].reshape(n, -1)[t]
+                else:
+                    w, b = v["proj_head.2.layer.weight"], v["proj_head.2.layer.bias"]
+                outs.append(self._native_linear(ht, w, b))
+            return torch.stack(outs, dim=1)
+
     def _early_exit(self, source, padding_mask, layer: int):
         """``forward(..., layer=k)`` (modules/model.py:424,554-558 -> modules/module.py:270,303-337): the encoder's module list -- the
         transformer layers with the time-reduction conv inserted at ``tr_layer_index`` -- stops behind module k; ``layer_results``
@@ -291,8 +312,6 @@ class CustomStudentModel(nn.Module):
         # from cfg.enable_tr_layer, not from what has run: module.py:625-647) -- the truncated copy runs without heads and the head /
         # shared upsampler is applied to its encoder output here
         before_tr = tr and not tr_runs
-        if before_tr and not self.layerwise_proj and self._heads_on:
-            raise NotImplementedError("early exit in front of the TR conv with the DistilHuBERT-style head switched on is not built")
         heads_in_sub = self._heads_on and not before_tr
         key = (max(k, 1), tr_runs, heads_in_sub)
         cache = self.__dict__.setdefault("_exit_models", {})
@@ -322,7 +341,11 @@ class CustomStudentModel(nn.Module):
                            x=(self._final_proj(x) if self.layerwise_proj else (self._upsample(x) if tr else x)))
             elif before_tr:
                 x = res["layer_results"][-1][0].transpose(0, 1)
-                res = dict(res, projections=None, x=(self._final_proj(x) if self.layerwise_proj else self._upsample(x)))
+                if self.layerwise_proj:
+                    res = dict(res, projections=None, x=self._final_proj(x))
+                else:   # model.py:503-516: x = upsampler(x), projections = proj_head(x) as B x N x T x D
+                    xu = self._upsample(x)
+                    res = dict(res, x=xu, projections=self._split_head(xu) if self._heads_on else None)
         return res
 
     def forward(self, source, padding_mask=None, layer=None):

@@ -242,6 +242,18 @@ def test_module_surface_upsample_early_exits_and_layer_zero(golden_dir):
         res = m(wav)
     assert _rel_l2(res["x"].float()[..., ::2], fx["split/x"]) < 1e-4
     assert _rel_l2(res["projections"].float()[..., ::4], fx["split/projections"]) < 1e-4
+    # early exit in FRONT of the TR conv (index 1) with the head on: layer 0 only, then upsampler + split head on its output -- the
+    # native composition against torch on the same weights
+    with torch.no_grad():
+        r0 = m(wav, layer=0)
+        x0 = r0["layer_results"][0][0].transpose(0, 1).float()
+        v = m.engine.param_views()
+        xu = torch.nn.functional.conv_transpose1d(x0.transpose(1, 2), v["upsampler.weight"], v["upsampler.bias"], stride=2).transpose(1, 2)
+        h = torch.nn.functional.gelu(torch.nn.functional.linear(xu, v["proj_head.0.weight"], v["proj_head.0.bias"]))
+        hs = h.reshape(h.shape[0], h.shape[1], 2, -1)
+        want = torch.einsum("btni,nip->bntp", hs, v["proj_head.2.weight"]) + v["proj_head.2.bias"].reshape(1, 2, 1, -1)
+    assert len(r0["layer_results"]) == 1 and r0["x"].shape[1] == 2 * x0.shape[1]
+    assert _rel_l2(r0["x"].float(), xu.cpu()) < 1e-4 and _rel_l2(r0["projections"].float(), want.cpu()) < 1e-4
 
 
 def test_fc_time_reduction_types_fail_loudly():
