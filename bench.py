@@ -114,6 +114,15 @@ def class_table(launches, steps: int, peak: float, batch: int = 128):
     return out
 
 
+def _binary_id():
+    """Which library produced this line: hashes of the shared object and of the sources it was compiled from (fithubert_amd/build.py)."""
+    try:
+        from fithubert_amd.build import lib_hash, source_hash
+        return {"lib_sha256": lib_hash(), "source_sha256": source_hash()}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def cpu_baseline(cfg, seconds_budget: float = 28.0):
     """The oracle's full CPU training step (fp32 eager torch) on the host cores, bounded sample: a sweep over thread counts
     (an oversubscribed pool is several times slower than the best one on a many-core host) at batch 1, then batch 2 at the best
@@ -309,6 +318,32 @@ def run_variants(task, cfg, args, dev, budget_s: float):
                    "seen (and its GEMM shapes tuned) once; utterances/s of that variant's own batch, plus 10 s-equivalents/s "
                    "(valid samples / 160000)"}
     to_dev = lambda b: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    # ---- the same workload in the reference's own precision (train.py:469,496 precision=16): IEEE-half operands, dynamic loss scaling
+    if args.dtype == "bf16":   # first: the budget never cuts it (it feeds the line's top-level value_float16)
+        t16 = W2V2Distil(copy.deepcopy(cfg), dtype="float16", device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native")
+        t16.configure_optimizers(num_training_steps=100)
+        batches = [fixed_length_batch(args.batch, SAMPLES_10S, seed=70 + i, device=dev) for i in range(2)]
+        dt, utt, smp = time_steps(t16, batches, 8, 3)
+        c = t16.amp_counters()
+        out["float16"] = {"per_gpu_batch": args.batch, "utt_per_s": round(utt / dt, 1), "ms_per_step": round(dt / 8 * 1e3, 2),
+                          "optimizer_steps_applied": c["applied"], "skipped_for_overflow": c["skipped"], "loss_scale": c["loss_scale"],
+                          "workload": "the headline workload with --dtype float16 (fp16 student + fp16 teacher, fh_adamw_amp); KD-loss "
+                                      "deviation of this mode from the fp32 reference: DESIGN.md section 2"}
+        del t16
+        torch.cuda.empty_cache()
+    # ---- BASELINE.json configs[3] on one GPU: the same student against a wav2vec 2.0 Base teacher (fairseq Wav2Vec2Model: conv-length
+    # padding rule, same widths and FLOPs as HuBERT Base; reference loader utils/utils.py:102-149)
+    if left() > 40:
+        tw = W2V2Distil(copy.deepcopy(cfg), dtype=args.dtype, device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native",
+                        teacher_cfg=TeacherConfig.base("wav2vec2"))
+        tw.configure_optimizers(num_training_steps=100)
+        batches = [fixed_length_batch(args.batch, SAMPLES_10S, seed=80 + i, device=dev) for i in range(2)]
+        dt, utt, smp = time_steps(tw, batches, 5, 3)
+        out["fitw2v2_wav2vec2_teacher"] = {"per_gpu_batch": args.batch, "utt_per_s": round(utt / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 2),
+                                           "workload": "BASELINE.json configs[3] per GPU: fithubert.yaml student + wav2vec 2.0 Base-shaped teacher "
+                                                       "(random init), fixed 10 s clips"}
+        del tw
+        torch.cuda.empty_cache()
     # ---- fixed-length buckets: ~640 s of audio per step in every bucket
     fixed = []
     for sec in (2, 4, 6, 8, 10, 12, 14, 16):
@@ -374,29 +409,19 @@ def run_variants(task, cfg, args, dev, budget_s: float):
         torch.cuda.synchronize()
         dtf = time.perf_counter() - t0f
         t3._next_teacher = None
-        out["reference_batch_3x4"] = {"per_gpu_batch": 3, "accumulate_grad_batches": 4, "utt_per_s": round(8 * 12 / dtf, 1),
-                                      "ms_per_optimizer_step": round(dtf / 8 * 1e3, 2),
+        # `utt_per_s` is the reference's own loop of four micro-batches of 3 (the quantity rounds 2 and 3 reported under that key);
+        # the merged window has its own key (round 4 had put it under `utt_per_s`: ADVICE r4)
+        out["reference_batch_3x4"] = {"per_gpu_batch": 3, "accumulate_grad_batches": 4, "utt_per_s": round(utt / dt, 1),
                                       "utt_per_s_micro_batch_loop": round(utt / dt, 1),
                                       "ms_per_micro_batch_in_the_loop": round(dt / 16 * 1e3, 2),
                                       "ms_per_optimizer_step_in_the_loop": round(dt / 4 * 1e3, 2),
+                                      "utt_per_s_fused_window": round(8 * 12 / dtf, 1),
+                                      "ms_per_optimizer_step_fused_window": round(dtf / 8 * 1e3, 2),
                                       "workload": "fithubert.yaml as shipped: batch_size 3, accumulate_grad_batches 4, fixed 10 s clips; "
-                                                  "utt_per_s = the accumulation window run as one merged batch of 12 (what fit() does for "
-                                                  "equal-shape unpadded windows: identical gradient, one forward / backward instead of four); "
-                                                  "utt_per_s_micro_batch_loop = the reference's loop of four micro-batches of 3"}
+                                                  "utt_per_s (= utt_per_s_micro_batch_loop) = the reference's loop of four micro-batches of 3; "
+                                                  "utt_per_s_fused_window = the accumulation window run as one merged batch of 12 (what fit() "
+                                                  "does for equal-shape unpadded windows: identical gradient, one forward / backward instead of four)"}
         del t3
-    # ---- the same workload in the reference's own precision (train.py:469,496 precision=16): IEEE-half operands, dynamic loss scaling
-    if left() > 40 and args.dtype == "bf16":
-        t16 = W2V2Distil(copy.deepcopy(cfg), dtype="float16", device=dev, seed=0, teacher_native_frontend=args.teacher_frontend == "native")
-        t16.configure_optimizers(num_training_steps=100)
-        batches = [fixed_length_batch(args.batch, SAMPLES_10S, seed=70 + i, device=dev) for i in range(2)]
-        dt, utt, smp = time_steps(t16, batches, 5, 3)
-        c = t16.amp_counters()
-        out["float16"] = {"per_gpu_batch": args.batch, "utt_per_s": round(utt / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 2),
-                          "optimizer_steps_applied": c["applied"], "skipped_for_overflow": c["skipped"], "loss_scale": c["loss_scale"],
-                          "workload": "the headline workload with --dtype float16 (fp16 student + fp16 teacher, fh_adamw_amp); KD-loss "
-                                      "deviation of this mode from the fp32 reference: DESIGN.md section 2"}
-        del t16
-        torch.cuda.empty_cache()
     # ---- the ex.yaml recipe (DistilHuBERT-style student without a TR layer) with and without attention-logit + value-relation transfer
     # (utils/utils.py:193-280, train.py:327-370): what the fused relation kernels cost in a step
     if left() > 45:
@@ -700,6 +725,17 @@ def main():
                 pmc = json.load(f)
             ent = pmc.get("variants", {}).get(roof["kernel"])
             if ent and pmc.get("batch") == B:
+                # attribution: the committed counters name the library / sources they were read from; a line produced by another
+                # binary says so instead of passing the numbers off as its own
+                from fithubert_amd.build import lib_hash, source_hash
+                roof["traffic_binary"] = {"profiled_lib_sha256": pmc.get("lib_sha256"), "profiled_source_sha256": pmc.get("source_sha256"),
+                                          "running_lib_sha256": lib_hash(), "running_source_sha256": source_hash()}
+                same_src = pmc.get("source_sha256") == roof["traffic_binary"]["running_source_sha256"]
+                roof["traffic_binary"]["same_sources"] = bool(same_src)
+                roof["traffic_binary"]["same_library_file"] = pmc.get("lib_sha256") == roof["traffic_binary"]["running_lib_sha256"]
+                if not same_src:
+                    roof["traffic_warning"] = ("profiles/pmc_traffic.json was collected on DIFFERENT kernel sources than the library running now: "
+                                               "traffic / mfma_busy / algorithmic_bytes describe that binary, not this run")
                 roof["traffic"] = ent.get("bytes_per_launch")
                 roof["traffic_source"] = "committed profile (profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on an earlier box; not measured in this run)"
                 roof["traffic_note"] = pmc.get("note")
@@ -735,6 +771,7 @@ def main():
             "step_frac_of_mfma_peak": None if variant else round(value * GF_STEP / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
             "final_loss": loss,
             "roofline": roof,
+            "binary": _binary_id(),
         }
         if world == 1 and not args.no_kd_delta:
             try:
@@ -746,6 +783,15 @@ def main():
                 res["variants"] = run_variants(task, cfg, args, dev, args.variants_budget)
             except Exception as e:  # the headline line must survive a failing side measurement; the failure is reported, not hidden
                 res["variants"] = {"error": repr(e)}
+        # the 16-bit mode at the reference's own precision (train.use_fp16, data/conf/fithubert.yaml) beside the bf16 headline: its
+        # throughput on the headline workload and ITS KD-loss delta, at the top level of the line
+        f16 = (res.get("variants") or {}).get("float16") if isinstance(res.get("variants"), dict) else None
+        if f16 and "utt_per_s" in f16:
+            res["value_float16"] = f16["utt_per_s"]
+            res["value_float16_over_value"] = round(f16["utt_per_s"] / value, 4)
+            kd = res.get("kd_loss_delta") or {}
+            res["kd_loss_delta_float16"] = kd.get("float16")
+            res["kd_loss_delta_" + args.dtype] = kd.get(args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res))

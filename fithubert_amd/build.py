@@ -64,6 +64,32 @@ def _compile(src: str) -> str:
     return obj
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over every file under csrc/ that the library is compiled from (*.hip, *.cuh, *.h), the public header
+    and the compiler flags: names WHICH sources a measurement was taken on (profiles/*, bench.py's `binary` field) independently of
+    git, which the GPU box does not have."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.h")))
+    files.append(os.path.join(HERE, "..", "include", "fithubert_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def lib_hash() -> str:
+    """sha256 (16 hex digits) of the built shared library itself, or '' when it does not exist."""
+    if not os.path.exists(LIB):
+        return ""
+    h = hashlib.sha256()
+    with open(LIB, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
+
+
 def build(verbose: bool = True, jobs: int = 6) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     if not srcs:

@@ -2454,10 +2454,12 @@ template <typename H> int launch_8ph(const GemmParams& p, hipStream_t stream) {
 
 // launches loop 8 can take: the bf16-staged epilogue without per-row operands, one reduction split
 bool stream_ok(const GemmParams& p) {
-  // TIMING-ONLY debug switch (wrong results): offer loop 8 to launches with a GELU' operand / row wrap / tail columns, ignoring them --
+  // TIMING-ONLY debug switch (wrong results; compiled only with -DFH_DEBUG_BUILD): offer loop 8 to launches with a GELU' operand / row wrap / tail columns, ignoring them --
   // an upper bound of what a streaming persistent data-gradient launch could gain
+#ifdef FH_DEBUG_BUILD   // never in the shipped library: an inherited environment variable must not be able to produce wrong gradients
   static const int force = [] { const char* e = getenv("FH_DEBUG_L8_FORCE"); return (e && e[0] == '1') ? 1 : 0; }();
   if (force) return !p.ep.atomic && !p.ep.out_f32 && !p.ep.kd_teacher && !p.ep.c0_wpart && !p.ep.residual && !p.ep.row_len && (p.splitk & 0xffff) <= 1;
+#endif
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
   return !p.ep.atomic && !p.ep.gelu_aux && !p.ep.residual && !p.ep.row_len && !p.ep.out_f32 && !p.ep.tail_cols && !p.ep.kd_teacher && !p.ep.c0_wpart &&
          (p.c_rpb <= 0 || wrap0 == 0) && (p.splitk & 0xffff) <= 1;

@@ -67,6 +67,49 @@ class _StudentFn(torch.autograd.Function):
         return g, None, None, None, None, None, None
 
 
+class _UpsampleFn(torch.autograd.Function):
+    """The shared ``upsampler`` ConvTranspose1d(D, D, k = s = f) on the encoder output WITH autograd (modules/model.py:505-506:
+    ``x = self.upsampler(x.transpose(1, 2)).transpose(1, 2)`` is differentiable in the reference, so a task fine-tuned on ``res['x']``
+    trains the student and ``upsampler.*``).  Forward and backward are native GEMMs (``fh_linear_forward``): ``y = x Wp^T + b`` with
+    ``Wp[(j, co)][ci] = w[ci][co][j]``; ``dx = dy Wp``; ``dw[ci][co][j] = sum_t x[t][ci] dy[t][(j, co)]``; ``db[co] = sum_{t, j} dy``
+    (``fh_colsum``).  The parameter gradient returns as a flat buffer of the engine's layout (zeros outside ``upsampler.*``)."""
+
+    @staticmethod
+    def forward(ctx, flat, model, x):
+        v = model.engine.param_views()
+        ctx.model = model
+        ctx.save_for_backward(x)
+        return model._conv_transpose(x, v["upsampler.weight"], v["upsampler.bias"]).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib as L
+        model = ctx.model
+        eng = model.engine
+        (x,) = ctx.saved_tensors
+        w = eng.param_views()["upsampler.weight"]                      # [cin, cout, f]
+        cin, cout, f = w.shape
+        B, T, _ = x.shape
+        dev = x.device
+        dy2 = dy.reshape(B * T, f * cout).to(eng.elem).contiguous()    # row t: the f up-sampled frames (j, co)
+        wp = w.detach().permute(2, 1, 0).reshape(f * cout, cin)
+        dx = model._native_linear(dy2, wp.t().contiguous(), torch.zeros(cin, device=dev)).view(B, T, cin).to(x.dtype)
+        # the weight gradient contracts over the B T rows: both operands transposed once (a layout move), rows padded to the 16-byte vector
+        K = (B * T + 7) // 8 * 8
+        xt = torch.zeros(cin, K, device=dev, dtype=eng.elem)
+        xt[:, : B * T] = x.reshape(B * T, cin).t()
+        dyt = torch.zeros(f * cout, K, device=dev, dtype=eng.elem)
+        dyt[:, : B * T] = dy2.t()
+        dwp = model._native_linear(xt, dyt, torch.zeros(f * cout, device=dev)).float()          # [cin, (j, co)]
+        g = torch.zeros_like(eng.params)
+        gv = eng.param_views(g)
+        gv["upsampler.weight"].copy_(dwp.view(cin, f, cout).permute(0, 2, 1))
+        db = gv["upsampler.bias"]                                      # out[n % cout] += sum_m dy2[m][n]
+        L.check(eng.lib.fh_colsum(eng.c.dtype, dy2.data_ptr(), db.data_ptr(), B * T, f * cout, f * cout, 1, 0, 0, cout, 1.0, eng.stream()),
+                "fh_colsum")
+        return g, None, dx
+
+
 class _LayerList(list):
     """Stand-in for ``encoder.layers`` (train.py:70 iterates it only when attention transfer is enabled)."""
 
@@ -337,8 +380,11 @@ class CustomStudentModel(nn.Module):
             if only_tr:
                 # module 0 is the TR conv: x = its output (module.py:317-321,336-337), no transformer layer has run
                 x = res["tr_layer_results"][0].transpose(0, 1)
-                res = dict(res, layer_results=[], projections=None,
-                           x=(self._final_proj(x) if self.layerwise_proj else (self._upsample(x) if tr else x)))
+                if self.layerwise_proj:
+                    res = dict(res, layer_results=[], projections=None, x=self._final_proj(x))
+                else:   # model.py:503-516 as in the branch below: x = upsampler(x), projections = proj_head(x) when the head is on
+                    xu = self._upsample(x) if tr else x
+                    res = dict(res, layer_results=[], x=xu, projections=self._split_head(xu) if self._heads_on else None)
             elif before_tr:
                 x = res["layer_results"][-1][0].transpose(0, 1)
                 if self.layerwise_proj:
@@ -392,7 +438,12 @@ class CustomStudentModel(nn.Module):
         tr_layer_results = [tr_out.transpose(0, 1)] if tr else []
         enc_x = tr_out if (tr and idx == L) else out_of(L - 1)          # the encoder's output (module.py:339-343)
         if not self.layerwise_proj:  # model.py:503-516: x is the encoder output (up-sampled behind a TR layer), projections B x N x T x D
-            x = self._upsample(enc_x) if tr else enc_x
+            # behind a TR layer x = upsampler(x) stays differentiable, as in the reference (model.py:505-506): a native node of its own
+            # when autograd is recording (its gradient re-enters the engine through layer_results), the plain native op otherwise
+            if tr and torch.is_grad_enabled() and self.training:
+                x = _UpsampleFn.apply(self.flat, self, enc_x)
+            else:
+                x = self._upsample(enc_x) if tr else enc_x
             projections = pred.permute(1, 0, 2, 3) if self._heads_on else None
         elif self._heads_on:
             projections = [rows(pred[i], t_of(i) * f) for i in range(L)]

@@ -193,6 +193,73 @@ def test_two_ranks_accumulate_exchange_from_inside_backward_and_stay_identical()
     assert torch.allclose(a["params"], p, atol=1e-6), (a["params"] - p).abs().max()
 
 
+def _worker8(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    import numpy as np
+    import torch.distributed as dist
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.dp import assert_replicas_equal, init_distributed
+    init_distributed("gloo")
+    # every 240th utterance of the committed train-clean-100 length table (119 lengths, 392,400 ... 22,560 samples), scaled down
+    # 400 x so that the stub's arithmetic is instant: 39 buckets of 3 (+ one of 2) -> 5 per rank, 3 optimizer steps at accumulate = 2
+    table = np.load(os.path.join(ROOT, "tests", "golden", "libri_train_clean_100_lengths.npz"))["lengths_sorted_desc"]
+    lens = [int(v) // 400 for v in table[::240]]
+    ds = SyntheticLibriDataset(lens, batch_size=3, seed=0)
+    task = W2V2Distil(_cfg(accumulate=2), dtype="float32", device="cpu", teacher=StubTeacher(), seed=0, student_model=StubStudent())
+    task.sync.per = 96                                   # several buckets per gradient segment
+    assert task.rank == rank and task.sync.world == world
+    walked, covered = [], []
+    step0, opt0 = task.training_step, task.optimizer_step
+
+    def spy_step(batch, batch_idx=0, next_batch=None):
+        walked.append(int(batch["x"].shape[1]))
+        return step0(batch, batch_idx=batch_idx, next_batch=next_batch)
+
+    def spy_opt(*a, **k):
+        covered.append((task.sync.covered(), len(task.sync.launched)))   # the exchange that feeds THIS optimizer step
+        return opt0(*a, **k)
+
+    task.training_step, task.optimizer_step = spy_step, spy_opt
+    task.fit(ds, num_epochs=1, rank=rank, world=world)
+    assert_replicas_equal(task.engine.params)
+    out[rank] = dict(walked=walked, covered=covered, opt_step=task.opt_step, steps=task.num_training_steps, n_buckets=len(ds),
+                     tops=[max(lens[i] for i in b) for b in ds.buckets], params=task.engine.params.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_walk_balanced_librispeech_buckets_and_exchange_every_segment_once():
+    """World 8 over gloo (the reference's strategy='ddp', train.py:492-501, over the bucketing of
+    utils/dataset.py:27-53): fit() deals the length-sorted buckets of (a sub-sample of) the committed LibriSpeech length table so that
+    the 8 ranks of a step hold neighbours in length; on every rank each optimizer step's exchange -- launched segment by segment from
+    inside the backward -- tiles the flat gradient buffer exactly once; the schedule is as long as the steps really taken; all eight
+    replicas end bit-identical."""
+    world, port = 8, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker8, args=(world, port, out), nprocs=world, join=True)
+    res = [out[r] for r in range(world)]
+    n, tops = res[0]["n_buckets"], res[0]["tops"]
+    per_rank = -(-n // world)
+    for r in res:
+        assert len(r["walked"]) == per_rank and r["opt_step"] == -(-per_rank // 2) == r["steps"]
+        # one exchange per optimizer step (the last one from flush_accumulation's partial window), each covering the buffer once,
+        # in more buckets than segments
+        assert len(r["covered"]) == r["opt_step"] and all(c and k >= len(SEGMENTS) for c, k in r["covered"]), r["covered"]
+        assert torch.equal(r["params"], res[0]["params"])
+    # balance: the buckets the 8 ranks hold in one step are 8 consecutive entries of the length-sorted list
+    order = sorted(tops, reverse=True)
+    for step in range(per_rank):
+        held = sorted((r["walked"][step] for r in res), reverse=True)
+        i0 = order.index(held[0])
+        assert held[:-1] == order[i0:i0 + world - 1] or held == (order[i0:] + [order[-1]] * world)[:world], (step, held)
+    # every bucket visited once over the ranks (the deal pads the last group with its own shortest bucket)
+    seen = sorted(w for r in res for w in r["walked"])
+    assert set(seen) == set(tops) and len(seen) == per_rank * world
+
+
 # ----------------------------------------------------------------------------------------------------- single process
 def test_prefetched_teacher_forward_is_only_used_for_its_own_batch():
     task = _task(accumulate=1)
@@ -365,6 +432,21 @@ def test_fit_merges_equal_shape_accumulation_windows_and_only_those():
         eng = task.engine
         assert eng.log.count("fwd") == want_fwd and eng.log.count("adamw") == 2 == task.opt_step, eng.log
         assert [c[0].shape[0] for c in task.teacher_model.calls] == want_batches
+    # mixed epoch: unfusable windows (a padded bucket in them) in front of fusable ones -- the look-ahead for the next
+    # window runs while the last micro-batch of the current one has not stepped yet, and must still merge it
+    from fithubert_amd.dataset import rank_buckets
+    lens = [600, 590] + [500] * 14                                                  # bucket 0 padded, buckets 1..7 equal and unpadded
+    ds = SyntheticLibriDataset(lens, batch_size=2, seed=0)
+    order = rank_buckets(len(ds), 0, 0, 1, seed=0, shuffle=True)
+    padded = [max(lens[i] for i in ds.buckets[b]) != min(lens[i] for i in ds.buckets[b]) for b in order]
+    windows = [padded[i:i + 2] for i in range(0, len(order), 2)]
+    assert any(any(w) for w in windows[:-1]), "the padded bucket should not sit in the last window of this seed"
+    want = [4 if (len(w) == 2 and not any(w)) else 2 for w in windows for _ in ((0,) if (len(w) == 2 and not any(w)) else w)]
+    task = W2V2Distil(_cfg(accumulate=2), dtype="float32", device="cpu", teacher=StubTeacher(), seed=0, student_model=StubStudent())
+    task.fit(ds, num_epochs=1)
+    assert [c[0].shape[0] for c in task.teacher_model.calls] == want, (want, padded)
+    first_unfused = next(i for i, w in enumerate(windows) if any(w))
+    assert first_unfused < len(windows) - 1 and want.count(4) == len(windows) - 1 and task.opt_step == len(windows)
     os.environ["FH_FUSE_ACCUMULATION"] = "0"
     try:
         task = W2V2Distil(_cfg(accumulate=2), dtype="float32", device="cpu", teacher=StubTeacher(), seed=0, student_model=StubStudent())

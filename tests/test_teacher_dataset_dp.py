@@ -133,6 +133,48 @@ def test_gradient_allreduce_world2_gloo():
     assert torch.allclose(out[0], p, atol=1e-6)
 
 
+def _dp_wire_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from fithubert_amd.dp import GradSync, assert_replicas_equal, broadcast_parameters, init_distributed
+
+    init_distributed("gloo")
+    torch.manual_seed(100 + rank)
+    params = torch.randn(1000)
+    broadcast_parameters(params)
+    grads = torch.zeros(1000)
+    sync = GradSync(grads, bucket_bytes=512, wire_dtype=torch.bfloat16)    # 4 buckets of 256 bf16 values
+    assert sync.per == 256 and sync.wire.dtype == torch.bfloat16
+    for step in range(3):
+        grads.copy_(torch.randn(1000, generator=torch.Generator().manual_seed(step * 10 + rank)))
+        sync.begin()
+        for seg, (first, count) in enumerate(((700, 300), (200, 500), (0, 200))):   # segments in completion order
+            sync.on_segment(seg, first, count)
+        assert sync.covered()
+        sync.wait()
+        params -= 0.1 * grads * sync.scale
+        assert_replicas_equal(params)
+    out[rank] = (params.clone(), grads.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_on_a_bf16_wire_world2_gloo():
+    """Optional 16-bit gradient exchange (dp.GradSync wire_dtype): every rank term is rounded to bf16, summed on
+    the wire, widened back into the fp32 buffer -- replicas bit-identical, the sum within bf16's rounding of the fp32 one (the
+    reference exchanges fp32: train.py:494; this is torch DDP's bf16_compress_hook arithmetic)."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_dp_wire_worker, args=(world, port, out), nprocs=world, join=True)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    terms = [torch.randn(1000, generator=torch.Generator().manual_seed(2 * 10 + r)) for r in range(world)]
+    want = sum(t.bfloat16() for t in terms).float()                 # bf16 terms, bf16 sum
+    assert torch.equal(out[0][1], want)
+    exact = sum(terms)
+    assert ((out[0][1] - exact).abs() <= 2.0 ** -7 * (terms[0].abs() + terms[1].abs()) + 1e-6).all()
+
+
 def test_product_fails_loudly_without_gpu():
     """No CPU fallback: constructing the engine / model without a GPU raises (it must never silently compute on the host)."""
     if torch.cuda.is_available():

@@ -119,3 +119,37 @@ def test_native_teacher_against_the_oracle_at_full_width(kind, dtype, tol):
             worst = max(worst, e)
             assert e < tol, (kind, dtype, i, b, e)
     print(f"\n[teacher vs oracle] {kind} {dtype}: worst rel-L2 over layers / utterances {worst:.2e} (tolerance {tol:.1e})")
+
+
+def test_native_teacher_against_the_oracle_at_the_longest_librispeech_utterance():
+    """The oracle witness for the long-utterance path: at 392,400 samples (T' = 1226 frames) the teacher's
+    attention leaves the resident-K/V form for the streamed one; ``test_native_teacher_at_the_longest_librispeech_utterance`` above
+    compares two of this package's own paths there.  Here the bf16 HIP path is compared with ``oracle.teacher_ref`` (the CPU
+    restatement pinned against HuggingFace in tests/test_oracle.py) on the same weights: longest utterance beside the median one,
+    right-padded, 3 layers, rel-L2 per layer on the valid frames.  Reference contract utils/utils.py:80-99."""
+    from oracle import teacher_ref as T
+
+    ocfg = dict(T.BASE, encoder_layers=3, model_type="hubert")
+    sd = T.random_teacher_state_dict(ocfg, seed=11)
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 3
+    w = build_teacher(tc, dtype=torch.bfloat16, device=DEV, state_dict={k: v.clone() for k, v in sd.items()}, native_frontend=True)
+    S, lens = 392400, [392400, 223920]
+    g = torch.Generator().manual_seed(6)
+    wav = 0.1 * torch.randn(2, S, generator=g)
+    pm = torch.arange(S)[None, :] >= torch.tensor(lens)[:, None]
+    wav[pm] = 0
+    with torch.no_grad():
+        ref = T.teacher_extract_features(sd, ocfg, wav, pm)                        # one CPU forward
+    got = w.hidden_stack(wav.to(DEV), pm.to(DEV), lengths=lens).float().cpu()
+    assert got.shape == (3, 2, 1226, 768) and w.model._native.layers_native
+    valid = w.model.frame_lengths(lens, S, got.shape[2])
+    assert valid[0] == 1226 and valid[1] < 1226
+    worst = 0.0
+    for i, (x, _) in enumerate(ref["layer_results"]):
+        r = x.transpose(0, 1)
+        for b in range(2):
+            e = ((got[i, b, :valid[b]] - r[b, :valid[b]]).norm() / r[b, :valid[b]].norm()).item()
+            worst = max(worst, e)
+            assert e < 2.5e-2, (i, b, e)
+    print(f"\n[teacher vs oracle, T' = 1226] bf16: worst rel-L2 over layers / utterances {worst:.2e}")

@@ -256,6 +256,44 @@ def test_module_surface_upsample_early_exits_and_layer_zero(golden_dir):
     assert _rel_l2(r0["x"].float(), xu.cpu()) < 1e-4 and _rel_l2(r0["projections"].float(), want.cpu()) < 1e-4
 
 
+def test_upsampled_x_is_differentiable_as_in_the_reference(golden_dir):
+    """layerwise_proj = False behind a TR layer: results["x"] = upsampler(encoder output) carries autograd in the reference
+    (modules/model.py:505-506) -- a loss on it must reach the student's weights AND upsampler.* (ADVICE r4).  fp32 engine against
+    the CPU oracle's autograd on the same weights."""
+    fx = np.load(os.path.join(golden_dir, "student_tr_variants.npz"))
+    wav = torch.from_numpy(fx["wav"])
+    off = dict(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    cfg = dict(yaml.safe_load(str(fx["split/cfg_yaml"])), **off)
+    sd = S.random_state_dict(cfg, seed=int(fx["split/weight_seed"]))
+    g = torch.Generator().manual_seed(5)
+    sd_g = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = S.student_forward(sd_g, cfg, wav, None)
+    tgt = torch.randn(ref["x"].shape, generator=g)
+    (ref["x"] * tgt).sum().backward()
+    m = CustomStudentModel(CustomStudentModelConfig(**cfg), dtype="float32", device=DEV)
+    m.load_state_dict(sd)
+    m.train()
+    res = m(wav.to(DEV))
+    assert res["x"].requires_grad
+    assert _rel_l2(res["x"].detach().float(), ref["x"].detach()) < 1e-4
+    (res["x"].float() * tgt.to(DEV)).sum().backward()
+    gv = m.engine.param_views(m.flat.grad)
+    for k in ("upsampler.weight", "upsampler.bias", "encoder.layers.3.fc2.weight", "encoder.layers.1.weight", "post_extract_proj.weight",
+              "feature_extractor.conv_layers.1.0.weight"):
+        a, b = gv[k].double().cpu(), sd_g[k].grad.double()
+        assert ((a - b).norm() / b.norm()).item() < 3e-3, k
+    # the head's parameters saw no gradient from x
+    assert float(gv["proj_head.0.weight"].abs().max()) == 0.0
+    # layer = 0 with the TR conv first and the head on: projections = proj_head(upsampler(x)) (ADVICE r4, model.py:505-516)
+    cfg0 = dict(cfg, tr_layer_index=0)
+    m0 = CustomStudentModel(CustomStudentModelConfig(**cfg0), dtype="float32", device=DEV)
+    m0.eval()
+    with torch.no_grad():
+        r0 = m0(wav.to(DEV), layer=0)
+    assert r0["layer_results"] == [] and r0["projections"] is not None
+    assert r0["projections"].shape[:3] == (wav.shape[0], m0.n_tasks, r0["x"].shape[1])
+
+
 def test_fc_time_reduction_types_fail_loudly():
     from fithubert_amd.engine import unsupported
     base = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf", "fithubert.yaml")))["distiller"]

@@ -66,7 +66,8 @@ def load(d, counters):
 fa, fn = load(fetch_dir, ["FETCH_SIZE"])
 wa, wn = load(write_dir, ["WRITE_SIZE"])
 fe, nf, wr, nw = fa["FETCH_SIZE"], fn["FETCH_SIZE"], wa["WRITE_SIZE"], wn["WRITE_SIZE"]
-out = {"batch": batch,
+from fithubert_amd.build import lib_hash, source_hash   # which binary these counters were read from (bench.py compares)
+out = {"batch": batch, "lib_sha256": lib_hash(), "source_sha256": source_hash(),
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (separate "
                "passes) over python bench.py; reads x2 (gfx950 FETCH_SIZE correction); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                "(GRBM_GUI_ACTIVE / 8 x 1024 matrix pipes); algorithmic_* from the per-launch GEMM trace (operands read once + output "
