@@ -288,6 +288,7 @@ inline int make_shapes(const fh_student_config& c, int B, int S, Shapes& s) {
 struct WcLayout {
   long cast_off = 0;      // bf16 copy of the whole flat parameter buffer (bf16 mode only)
   long conv_wf[FH_MAX_CONV];
+  long conv_wt[FH_MAX_CONV];   // [k][Cin][Cout]: the data gradients' weight operand with the reduction index (Cout) contiguous (round 5)
   long tr_wf = -1, head_wup = -1, head_wup_stride = 0, pos_wf, pos_wb, pos_norm;
   long head_wm = -1, head_bm = -1, head_wupf = -1;  // merged head weights [L][f*P][D] (compute dtype), merged bias [L][P] fp32,
                                                     // fp32 copy of the permuted upsampler weights [L][f][D][D]
@@ -300,6 +301,8 @@ struct WcLayout {
     long cin = 1;
     for (int i = 0; i < c.n_conv; ++i) {
       conv_wf[i] = o;
+      if (i > 0) o += rup((long)c.conv_dim[i] * cin * c.conv_k[i] * es, 256);
+      conv_wt[i] = o;
       if (i > 0) o += rup((long)c.conv_dim[i] * cin * c.conv_k[i] * es, 256);
       cin = c.conv_dim[i];
     }
@@ -647,6 +650,10 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
   for (int i = 1; i < c.n_conv; ++i) {
     // [Cout][Cin][k] -> [Cout][k][Cin]
     RC(fh_permute3_cast_launch(dt, params + p.pl.conv_w[i], wc + p.wl.conv_wf[i], c.conv_dim[i], (int)cin, c.conv_k[i], 0, 2, 1, st));
+    // [Cout][Cin][k] -> [k][Cin][Cout]: dX = dZ . W reads W with Cout contiguous -- both operands of the data-gradient GEMMs R_CONTIG,
+    // which the 8-phase loops take (the R_STRIDED form went through transposing LDS reads in the ring loops: layer 2's data gradient
+    // 1.76 -> 1.63 ms at B = 128, tools/scratch/dgrad_probe.py)
+    RC(fh_permute3_cast_launch(dt, params + p.pl.conv_w[i], wc + p.wl.conv_wt[i], c.conv_dim[i], (int)cin, c.conv_k[i], 2, 1, 0, st));
     cin = c.conv_dim[i];
   }
   const int D = c.embed_dim;
@@ -1387,6 +1394,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     unsigned char* dst = x.W<unsigned char>(i - 1 >= 1 ? p.dz[i - 1] : p.dz[0]);
     const unsigned char* aux = i - 1 >= 1 ? x.W<unsigned char>(p.z[i - 1]) : nullptr;
     const void* wf = x.rel(p.wl.conv_wf[i]);
+    const void* wt = x.rel(p.wl.conv_wt[i]);   // [k Cin][Cout]
     if (i == 1 && p.c0_fused) {
       // layer 1's data gradient IS d loss / d y0: its tiles are consumed in the GEMM's epilogue by conv 0's weight-gradient sums (one
       // utterance per group, so that a 256-frame tile shares its GroupNorm statistics and waveform window); dz[0] is never written
@@ -1416,7 +1424,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     if (kk == sd || (kk == 1 && sd == 1)) {
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
-      g.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
+      g.Y = fh_operand(wt, FH_R_CONTIG, cout);
       g.C = dst;
       g.M = (int)Mi; g.N = kk * cin; g.Kseg = cout;
       g.ldc = (long)sd * cin; g.c_rpb = Ti; g.c_bstride = (long)Tin * cin;
@@ -1457,8 +1465,8 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       GemmParams e = fh_gemm_params();
       e.X = fh_operand(x.W(p.dz[i]), FH_R_CONTIG, cout);
       e.X.rpb = n_even; e.X.bstride = (long)Ti * cout; e.X.nseg = 2; e.X.tshift[0] = 0; e.X.tshift[1] = -1; e.X.tvalid = Ti;
-      e.Y = fh_operand(wf, FH_R_STRIDED, (long)kk * cin);
-      e.Y.nseg = 2; e.Y.segoff[0] = 0; e.Y.segoff[1] = 2L * cin; e.Y.seg1_limit = cin;
+      e.Y = fh_operand(wt, FH_R_CONTIG, cout);   // rows (tap, ci): segment 1 = the rows of tap 2
+      e.Y.nseg = 2; e.Y.segoff[0] = 0; e.Y.segoff[1] = 2L * cin * cout; e.Y.seg1_limit = cin;
       e.C = dst;
       e.M = B * n_even; e.N = 2 * cin; e.Kseg = cout;
       e.ldc = 2L * cin; e.c_rpb = n_even; e.c_bstride = (long)Tin * cin;
