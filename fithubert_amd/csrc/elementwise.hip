@@ -37,6 +37,33 @@ __global__ void permute3_kernel(const float* __restrict__ src, T* __restrict__ d
   dst[o] = from_f<T>(src[((long)idx[0] * d1 + idx[1]) * d2 + idx[2]]);
 }
 
+// ---- one launch for every "copy the fp32 master weights into a kernel layout" job of fh_student_prepare (round 5): the 16-bit cast
+// of the flat buffer, the conv / TR / head weight permutes and the transposed layer weights used to be ~22 separate 5 - 25 us launches at
+// the head of the student's stream, each of which could wait for a CU behind the teacher's persistent GEMM launches (rocprofv3 showed
+// averages of 0.8 - 4.9 ms for kernels that run in 20 - 170 us alone).  A job = a grouped 3-d permute with cast:
+//   dst[g][a][b][c] (dims d[p0], d[p1], d[p2]) = src[g][i0][i1][i2],  (a, b, c) = (i[p0], i[p1], i[p2])
+// Blocks of 256 outputs are dealt over the jobs through the prefix table `first_block`.
+template <typename T>
+__global__ void __launch_bounds__(256) weight_layout_kernel(const float* __restrict__ params, unsigned char* __restrict__ wc, fh_layout_jobs jobs) {
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+  const fh_layout_job& q = jobs.job[j];
+  const long per = (long)q.d[0] * q.d[1] * q.d[2];
+  const long o_all = (long)((int)blockIdx.x - jobs.first_block[j]) * 256 + threadIdx.x;
+  if (o_all >= per * q.groups) return;
+  const int g = (int)(o_all / per);
+  const long o = o_all - (long)g * per;
+  const float* src = params + q.src + (long)g * q.src_gstride;
+  T* dst = reinterpret_cast<T*>(wc + q.dst) + (long)g * q.dst_gstride;
+  const int e1 = q.d[q.p[1]], e2 = q.d[q.p[2]];
+  int idx[3];
+  idx[q.p[2]] = (int)(o % e2);
+  idx[q.p[1]] = (int)((o / e2) % e1);
+  idx[q.p[0]] = (int)(o / ((long)e1 * e2));
+  dst[o] = from_f<T>(src[((long)idx[0] * q.d[1] + idx[1]) * q.d[2] + idx[2]]);
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
                              float bc2, float gscale, const float* __restrict__ decay_mask) {
@@ -296,6 +323,27 @@ int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int 
     hipLaunchKernelGGL(permute3_kernel<f16>, grid, block, 0, st, src, (f16*)dst, d0, d1, d2, p0, p1, p2, src_gstride, dst_gstride);
   else
     hipLaunchKernelGGL(permute3_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, d0, d1, d2, p0, p1, p2, src_gstride, dst_gstride);
+  FH_CHECK_LAUNCH();
+  return 0;
+}
+
+int fh_layout_jobs_launch(int dtype, const float* params, void* wc, fh_layout_jobs& jobs, hipStream_t st) {
+  if (jobs.n <= 0) return 0;
+  if (jobs.n > FH_MAX_LAYOUT_JOBS) return -705;
+  int blocks = 0;
+  for (int j = 0; j < jobs.n; ++j) {
+    jobs.first_block[j] = blocks;
+    const long n = (long)jobs.job[j].d[0] * jobs.job[j].d[1] * jobs.job[j].d[2] * jobs.job[j].groups;
+    blocks += (int)((n + 255) / 256);
+  }
+  jobs.first_block[jobs.n] = blocks;
+  if (blocks <= 0) return 0;
+  if (dtype == 0)
+    hipLaunchKernelGGL(weight_layout_kernel<float>, dim3(blocks), dim3(256), 0, st, params, (unsigned char*)wc, jobs);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(weight_layout_kernel<f16>, dim3(blocks), dim3(256), 0, st, params, (unsigned char*)wc, jobs);
+  else
+    hipLaunchKernelGGL(weight_layout_kernel<bf16>, dim3(blocks), dim3(256), 0, st, params, (unsigned char*)wc, jobs);
   FH_CHECK_LAUNCH();
   return 0;
 }

@@ -645,26 +645,36 @@ inline int wgrad(const Ctx& x, const void* dC, long ld_dc, const GemmOperand& A,
 int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t st) {
   const fh_student_config& c = p.c;
   const int dt = c.dtype;
-  if (dt != 0) RC(fh_cast_launch(dt, params, wc + p.wl.cast_off, p.pl.total, st));
+  // every cast / permute of master weights into a kernel layout is ONE launch (weight_layout_kernel; round 5: they were ~22 tiny
+  // launches that queued one by one behind the teacher's persistent GEMMs)
+  fh_layout_jobs jobs;
+  jobs.n = 0;
+  if (dt != 0) jobs.add(0, p.wl.cast_off, 1, 1, (int)p.pl.total, 0, 1, 2);
   long cin = c.conv_dim[0];
   for (int i = 1; i < c.n_conv; ++i) {
     // [Cout][Cin][k] -> [Cout][k][Cin]
-    RC(fh_permute3_cast_launch(dt, params + p.pl.conv_w[i], wc + p.wl.conv_wf[i], c.conv_dim[i], (int)cin, c.conv_k[i], 0, 2, 1, st));
+    jobs.add(p.pl.conv_w[i], p.wl.conv_wf[i], c.conv_dim[i], (int)cin, c.conv_k[i], 0, 2, 1);
     // [Cout][Cin][k] -> [k][Cin][Cout]: dX = dZ . W reads W with Cout contiguous -- both operands of the data-gradient GEMMs R_CONTIG,
     // which the 8-phase loops take (the R_STRIDED form went through transposing LDS reads in the ring loops: layer 2's data gradient
     // 1.76 -> 1.63 ms at B = 128, tools/scratch/dgrad_probe.py)
-    RC(fh_permute3_cast_launch(dt, params + p.pl.conv_w[i], wc + p.wl.conv_wt[i], c.conv_dim[i], (int)cin, c.conv_k[i], 2, 1, 0, st));
+    jobs.add(p.pl.conv_w[i], p.wl.conv_wt[i], c.conv_dim[i], (int)cin, c.conv_k[i], 2, 1, 0);
     cin = c.conv_dim[i];
   }
   const int D = c.embed_dim;
   if (c.tr_factor > 0) {
-    RC(fh_permute3_cast_launch(dt, params + p.pl.tr_w, wc + p.wl.tr_wf, D, D, c.tr_factor, 0, 2, 1, st));
+    jobs.add(p.pl.tr_w, p.wl.tr_wf, D, D, c.tr_factor, 0, 2, 1);
+    // ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin]: all layer-wise heads as one grouped job (the bf16 mode's chain rule runs on
+    // these bf16 copies too; the fp32 mode's copy IS the fp32 one), or the shared upsampler in front of the DistilHuBERT-style head
+    // (model.py:341-348)
+    if (c.n_tasks == 0)
+      jobs.add(p.pl.head0 + p.pl.h_up_w, p.wl.head_wup, D, D, c.tr_factor, 2, 1, 0, c.layers, p.pl.head_stride, p.wl.head_wup_stride);
+    else
+      jobs.add(p.pl.ups_w, p.wl.head_wup, D, D, c.tr_factor, 2, 1, 0);
+  }
+  RC(fh_layout_jobs_launch(dt, params, wc, jobs, st));
+  if (c.tr_factor > 0) {
     const int es = dt == 0 ? 4 : 2;
     if (c.n_tasks == 0) {
-      // ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin], all heads in one launch (the bf16 mode's chain rule runs on these
-      // bf16 copies too; the fp32 mode's copy IS the fp32 one)
-      RC(fh_permute3_cast_launch(dt, params + p.pl.head0 + p.pl.h_up_w, wc + p.wl.head_wup, D, D, c.tr_factor, 2, 1, 0, st, c.layers,
-                                 p.pl.head_stride, p.wl.head_wup_stride));
       // merged weights Wm[l][j][p][ci] = sum_co Wlin[l][p][co] * Wup[l][ci][co][j]
       const int P = c.pred_dim, f = c.tr_factor;
       const unsigned char* nat = dt == 0 ? (const unsigned char*)params : wc + p.wl.cast_off;
@@ -683,9 +693,6 @@ int prepare(const Plan& p, const float* params, unsigned char* wc, hipStream_t s
       hipLaunchKernelGGL(head_bias_merge_kernel, dim3((c.layers * P + 3) / 4), dim3(256), 0, st, params, p.pl.head0,
                          p.pl.head_stride, p.pl.h_lin_w, p.pl.h_lin_b, p.pl.h_up_b, (float*)(wc + p.wl.head_bm), c.layers, P, D);
       FH_CHECK_LAUNCH();
-    } else {
-      // the shared upsampler in front of the DistilHuBERT-style head (model.py:341-348): ConvTranspose1d weight [Cin][Cout][k] -> [k][Cout][Cin]
-      RC(fh_permute3_cast_launch(dt, params + p.pl.ups_w, wc + p.wl.head_wup, D, D, c.tr_factor, 2, 1, 0, st));
     }
   }
   RC(fh_posconv_prep_launch(dt, params + p.pl.pos_g, params + p.pl.pos_v, wc + p.wl.pos_wf, wc + p.wl.pos_wb,
@@ -1191,7 +1198,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     GemmOperand A = fh_operand(x.at(p.hbuf, (long)l0 * Ms * Fd), FH_R_STRIDED, Fd);
     A.gstride = Ms * Fd;
     RC(wgrad(x, x.at(p.df2, (long)l0 * Ms * D), D, A, grads + lo + p.pl.l_fc2_w, D, Fd, M2, nl, Ms * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
-    RC(fh_colsum_launch(dt, x.at(p.df2, (long)l0 * Ms * D), grads + lo + p.pl.l_fc2_b, (int)M2, D, D, nl, Ms * D, ls, 0, 1.f, ws_));
+    // (fc2's and out-proj's bias gradients come out of the LayerNorm backward kernels that WRITE df2 / dao: no pass over them here)
     A = fh_operand(x.at(p.xa, (long)l0 * Ms * D), FH_R_STRIDED, D);
     A.gstride = Ms * D;
     RC(wgrad(x, x.at(p.dz1, (long)l0 * Ms * Fd), Fd, A, grads + lo + p.pl.l_fc1_w, Fd, D, M2, nl, Ms * Fd, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
@@ -1199,7 +1206,6 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     A = fh_operand(x.at(p.attn, (long)l0 * Ms * D), FH_R_STRIDED, D);
     A.gstride = Ms * D;
     RC(wgrad(x, x.at(p.dao, (long)l0 * Ms * D), D, A, grads + lo + p.pl.l_o_w, D, D, M2, nl, Ms * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
-    RC(fh_colsum_launch(dt, x.at(p.dao, (long)l0 * Ms * D), grads + lo + p.pl.l_o_b, (int)M2, D, D, nl, Ms * D, ls, 0, 1.f, ws_));
     A = fh_operand(x.at(p.xo, (long)s.slot_in(l0) * Ms * D), FH_R_STRIDED, D);  // layer inputs = consecutive slots
     A.gstride = Ms * D;
     RC(wgrad(x, x.at(p.dqkv, (long)l0 * Ms * 3 * D), 3 * D, A, grads + lo + p.pl.l_qkv_w, 3 * D, D, M2, nl, Ms * 3 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
@@ -1253,7 +1259,8 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     unsigned char* df2_l = x.at(p.df2, (long)l * Ms * D);
     RC(fh_layernorm_bwd_launch(dt, dy, dy2, x.at(p.s2, (long)l * Ms * D), x.W<float>(p.st2_mean) + l * Ms,
                                x.W<float>(p.st2_rstd) + l * Ms, lp + p.pl.l_ln2_w, x.W(p.ds2), df2_l, lg + p.pl.l_ln2_w,
-                               lg + p.pl.l_ln2_b, (int)M2, D, x.drop(0.f, 0), x.drop(drop3 ? c.dropout : 0.f, site + 3), x.st));
+                               lg + p.pl.l_ln2_b, (int)M2, D, x.drop(0.f, 0), x.drop(drop3 ? c.dropout : 0.f, site + 3), x.st,
+                               /*fc2's bias gradient = column sums of df2*/ lg + p.pl.l_fc2_b));
     {  // dz1 = (df2 . W2) * mask2 * gelu'(z1)
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(df2_l, FH_R_CONTIG, D);
@@ -1278,7 +1285,8 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     unsigned char* dao_l = x.at(p.dao, (long)l * Ms * D);
     RC(fh_layernorm_bwd_launch(dt, x.W(p.dx1b), nullptr, x.at(p.s1, (long)l * Ms * D), x.W<float>(p.st1_mean) + l * Ms,
                                x.W<float>(p.st1_rstd) + l * Ms, lp + p.pl.l_ln1_w, x.W(p.ds1), dao_l, lg + p.pl.l_ln1_w,
-                               lg + p.pl.l_ln1_b, (int)M2, D, x.drop(0.f, 0), x.drop(c.dropout, site + 1), x.st));
+                               lg + p.pl.l_ln1_b, (int)M2, D, x.drop(0.f, 0), x.drop(c.dropout, site + 1), x.st,
+                               /*out-proj's bias gradient = column sums of dao*/ lg + p.pl.l_o_b));
     {  // da = dao . Wo
       GemmParams g = fh_gemm_params();
       g.X = fh_operand(dao_l, FH_R_CONTIG, D);

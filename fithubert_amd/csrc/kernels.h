@@ -28,7 +28,9 @@ int fh_add_layernorm_fwd_launch(int dtype, const void* x, const void* res, const
                                 int M, int C, float eps, hipStream_t st, int gelu = 0);
 int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                             const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
-                            int M, int C, fh_drop out_drop, fh_drop in_drop, hipStream_t st);
+                            int M, int C, fh_drop out_drop, fh_drop in_drop, hipStream_t st, float* dxsum = nullptr);
+// (dxsum: optional [C] fp32, += the column sums of the last gradient written -- dx2 when given, else dx: the bias gradient of the
+// Linear in front of the LayerNorm)
 int fh_colsum_launch(int dtype, const void* X, float* out, int M, int N, long ldx, int groups, long x_gstride,
                      long out_gstride, int mod, float scale, hipStream_t st);
 int fh_zero_rows_launch(int dtype, void* x, int B, int Tn, int C, int from, hipStream_t st);
@@ -68,6 +70,25 @@ int fh_kd_loss_rows_launch(int dtype, int teacher_dtype, const void* pred, const
                            float sim_weight, hipStream_t st, float grad_scale = 1.0f);  // grad_scale: on dpred only (loss scaling)
 
 // ---- elementwise.hip
+// weight-layout jobs of fh_student_prepare, all in ONE launch (weight_layout_kernel): grouped 3-d permute + cast of fp32 master weights
+constexpr int FH_MAX_LAYOUT_JOBS = 40;
+struct fh_layout_job {
+  long src, dst;                 // element offset into the flat fp32 parameters, BYTE offset into the compute-dtype buffer
+  long src_gstride, dst_gstride; // elements
+  int d[3], p[3], groups;
+};
+struct fh_layout_jobs {
+  int n;
+  int first_block[FH_MAX_LAYOUT_JOBS + 1];
+  fh_layout_job job[FH_MAX_LAYOUT_JOBS];
+  void add(long src, long dst, int d0, int d1, int d2, int p0, int p1, int p2, int groups = 1, long sg = 0, long dg = 0) {
+    if (n >= FH_MAX_LAYOUT_JOBS) { n = FH_MAX_LAYOUT_JOBS + 1; return; }   // (reported by fh_layout_jobs_launch)
+    fh_layout_job& q = job[n++];
+    q.src = src; q.dst = dst; q.src_gstride = sg; q.dst_gstride = dg; q.groups = groups;
+    q.d[0] = d0; q.d[1] = d1; q.d[2] = d2; q.p[0] = p0; q.p[1] = p1; q.p[2] = p2;
+  }
+};
+int fh_layout_jobs_launch(int dtype, const float* params, void* wc, fh_layout_jobs& jobs, hipStream_t st);
 int fh_cast_launch(int dtype, const float* src, void* dst, long n, hipStream_t st);
 int fh_permute3_cast_launch(int dtype, const float* src, void* dst, int d0, int d1, int d2, int p0, int p1, int p2,
                             hipStream_t st, int groups = 1, long src_gstride = 0, long dst_gstride = 0);  // strides in elements

@@ -129,13 +129,16 @@ __global__ void __launch_bounds__(NCH == 1 ? 1024 : (NCH == 2 ? 512 : 256)) ln_b
                                                      const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, T* __restrict__ dx2, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int C, int rows_per_wave,
-                                                     DropCfg out_drop, DropCfg in_drop) {
+                                                     DropCfg out_drop, DropCfg in_drop, float* __restrict__ dxsum) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int lane = threadIdx.x & 63;
   const int nwav = blockDim.x >> 6;
   const int wave_global = blockIdx.x * nwav + (threadIdx.x >> 6);
   const int nchunk = C / VEC;
-  float dg[NCH][VEC], db[NCH][VEC], gm[NCH][VEC];
+  // dxsum (optional): column sums of the LAST gradient this kernel writes (dx2 when given, else dx) -- the bias gradient of the Linear
+  // whose output the LayerNorm consumed (out-proj / fc2: d bias = sum over rows of the dropout-scaled LayerNorm input gradient), which
+  // used to be a separate colsum pass over that tensor (round 5)
+  float dg[NCH][VEC], db[NCH][VEC], gm[NCH][VEC], dxs[NCH][VEC];
 #pragma unroll
   for (int u = 0; u < NCH; ++u) {
     const int ch = lane + 64 * u;
@@ -143,6 +146,7 @@ __global__ void __launch_bounds__(NCH == 1 ? 1024 : (NCH == 2 ? 512 : 256)) ln_b
     for (int e = 0; e < VEC; ++e) {
       dg[u][e] = 0.f;
       db[u][e] = 0.f;
+      dxs[u][e] = 0.f;
       gm[u][e] = ch < nchunk ? gamma[ch * VEC + e] : 0.f;
     }
   }
@@ -192,6 +196,10 @@ __global__ void __launch_bounds__(NCH == 1 ? 1024 : (NCH == 2 ? 512 : 256)) ln_b
           if (in_drop.p > 0.f) drop_scale_vec<VEC>(in_drop, (unsigned long long)row * C + ch * VEC, o);
           st16(dx2 + (long)row * C + ch * VEC, pack16<T>(o));
         }
+        if (dxsum) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) dxs[u][e] += o[e];
+        }
       }
     }
   }
@@ -214,6 +222,23 @@ __global__ void __launch_bounds__(NCH == 1 ? 1024 : (NCH == 2 ? 512 : 256)) ln_b
     float v = 0.f;
     for (int w = 0; w < nwav; ++w) v += red[w * 2 * C + i];
     atomicAdd((i < C ? dgamma : dbeta - C) + i, v);
+  }
+  if (dxsum) {   // a second round through the same LDS rows (a third [C] block per wave would halve the workgroups a CU holds)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) my[ch * VEC + e] = dxs[u][e];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+      float v = 0.f;
+      for (int w = 0; w < nwav; ++w) v += red[w * 2 * C + i];
+      atomicAdd(dxsum + i, v);
+    }
   }
 }
 
@@ -296,7 +321,7 @@ int ln_fwd_t(const T* x, const float* g, const float* b, T* y, float* mean, floa
 
 template <typename T>
 int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const float* rstd, const float* g, T* dx, T* dx2,
-             float* dgamma, float* dbeta, int M, int C, DropCfg out_drop, DropCfg in_drop, hipStream_t st) {
+             float* dgamma, float* dbeta, int M, int C, DropCfg out_drop, DropCfg in_drop, hipStream_t st, float* dxsum = nullptr) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (C % VEC) return -301;
   const int nch = (C / VEC + 63) / 64;
@@ -312,13 +337,13 @@ int ln_bwd_t(const T* dy, const T* dy2, const T* x, const float* mean, const flo
   const size_t smem = (size_t)2 * wpb * C * sizeof(float);
   if (nch == 1)
     hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, smem, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
-                       rpw, out_drop, in_drop);
+                       rpw, out_drop, in_drop, dxsum);
   else if (nch == 2)
     hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, smem, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
-                       rpw, out_drop, in_drop);
+                       rpw, out_drop, in_drop, dxsum);
   else if (nch <= 4)
     hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, smem, st, dy, dy2, x, mean, rstd, g, dx, dx2, dgamma, dbeta, M, C,
-                       rpw, out_drop, in_drop);
+                       rpw, out_drop, in_drop, dxsum);
   else
     return -302;
   FH_CHECK_LAUNCH();
@@ -346,14 +371,14 @@ int fh_add_layernorm_fwd_launch(int dtype, const void* x, const void* res, const
 
 int fh_layernorm_bwd_launch(int dtype, const void* dy, const void* dy2, const void* x, const float* mean,
                             const float* rstd, const float* gamma, void* dx, void* dx2, float* dgamma, float* dbeta,
-                            int M, int C, fh_drop out_drop, fh_drop in_drop, hipStream_t st) {
+                            int M, int C, fh_drop out_drop, fh_drop in_drop, hipStream_t st, float* dxsum) {
   if (M <= 0) return 0;
   return dtype == 0 ? ln_bwd_t<float>((const float*)dy, (const float*)dy2, (const float*)x, mean, rstd, gamma,
-                                      (float*)dx, (float*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st)
+                                      (float*)dx, (float*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st, dxsum)
                     : dtype == 2 ? ln_bwd_t<f16>((const f16*)dy, (const f16*)dy2, (const f16*)x, mean, rstd, gamma, (f16*)dx,
-                                     (f16*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st)
+                                     (f16*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st, dxsum)
                     : ln_bwd_t<bf16>((const bf16*)dy, (const bf16*)dy2, (const bf16*)x, mean, rstd, gamma, (bf16*)dx,
-                                     (bf16*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st);
+                                     (bf16*)dx2, dgamma, dbeta, M, C, out_drop, in_drop, st, dxsum);
 }
 
 int fh_colsum_launch(int dtype, const void* X, float* out, int M, int N, long ldx, int groups, long x_gstride,
