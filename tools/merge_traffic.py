@@ -16,5 +16,13 @@ if ent and pmc.get("batch") == d["config"]["per_gpu_batch"]:
     r["mfma_busy"] = ent.get("mfma_busy")
     r["mfma_busy_over_sq_busy"] = ent.get("mfma_busy_over_sq_busy")
     r["algorithmic_bytes"] = ent.get("algorithmic_bytes_per_launch")
+    # attribution: the counters' binary against the binary that printed the line (bench.py's `binary` field)
+    b = d.get("binary") or {}
+    same = pmc.get("source_sha256") is not None and pmc.get("source_sha256") == b.get("source_sha256")
+    r["traffic_binary"] = {"profiled_lib_sha256": pmc.get("lib_sha256"), "profiled_source_sha256": pmc.get("source_sha256"),
+                           "running_lib_sha256": b.get("lib_sha256"), "running_source_sha256": b.get("source_sha256"),
+                           "same_sources": bool(same), "same_library_file": pmc.get("lib_sha256") == b.get("lib_sha256")}
+    if same:
+        r.pop("traffic_warning", None)
 open(path, "w").write(json.dumps(d) + "\n")
 print("traffic", r.get("traffic"), "mfma_busy", r.get("mfma_busy"))
