@@ -81,15 +81,15 @@ CLASS_NOTE = {
 
 
 def classify(r, batch: int = 128) -> str:
-    if r["atomic"]:
+    if r["atomic"] & 1:
         return "weight_gradients"
     # conv-frontend launches have >= 999 rows per utterance, everything behind the frontend at most 499: the threshold scales with the batch
     # (conv layer 1's data gradient is launched per utterance -- groups = B, M = T0 rows each -- since it carries conv 0's weight-gradient sums)
     big = r["M"] >= 781 * batch or (r["groups"] > 1 and r["M"] * r["groups"] >= 7812 * batch)
     if r["tag"] == 1:
         return "teacher_conv" if big else "teacher_linear"
-    if big:
-        return "student_conv_dgrad" if r["yl"] == 1 else "student_conv_forward"
+    if big:   # a conv data gradient carries the saved GELU' as an epilogue operand (flag bit 1) or conv 0's weight-gradient epilogue (bit 2)
+        return "student_conv_dgrad" if (r["atomic"] & 6) else "student_conv_forward"
     return "student_layer_gemms"
 
 

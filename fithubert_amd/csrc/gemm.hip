@@ -318,7 +318,8 @@ extern "C" int fh_prof_tag(int tag) {
   g_prof_tag = tag;
   return old;
 }
-// per-launch form of fh_prof_collect: rows of {M, N, K (whole reduction), groups, X layout, Y layout, loop, atomic, tag} and the
+// per-launch form of fh_prof_collect: rows of {M, N, K (whole reduction), groups, X layout, Y layout, loop, flags (bit 0 atomic output,
+// bit 1 GELU' operand = a conv / fc1 data gradient, bit 2 conv-0 weight-gradient epilogue), tag} and the
 // launch's duration / algorithmic FLOPs; returns the number of launches recorded (rows beyond cap are dropped) and clears the log
 extern "C" int fh_prof_collect_launches(double* ms, double* flops, int* rows /*[cap][9]*/, int cap) {
   int n = 0;
@@ -414,7 +415,8 @@ int fh_gemm_launch(const GemmParams& p, int dtype, hipStream_t stream) {
   r.flops = 2.0 * p.M * ncols * (double)p.Kseg * p.groups;
   r.variant = (dtype ? 4 : 0) + p.X.layout * 2 + p.Y.layout;
   r.M = p.M; r.N = p.N; r.K = p.Kseg * p.X.nseg; r.groups = p.groups; r.splitk = p.splitk;
-  r.tag = g_prof_tag; r.atomic = p.ep.atomic; r.xl = p.X.layout; r.yl = p.Y.layout; r.loop = 0;
+  r.tag = g_prof_tag; r.atomic = (p.ep.atomic ? 1 : 0) | (p.ep.gelu_aux ? 2 : 0) | (p.ep.c0_wpart ? 4 : 0);  // bit 0 atomic output, bit 1 GELU' operand, bit 2 conv-0 epilogue
+  r.xl = p.X.layout; r.yl = p.Y.layout; r.loop = 0;
   hipEventRecord(r.a, stream);
   const int rc = dtype == 0 ? launch_t<float>(p, stream) : launch_16(p, dtype, stream);
   if (dtype != 0) {
