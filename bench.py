@@ -209,6 +209,59 @@ def kd_loss_delta(dev, fixture: str = "student_full_10s"):
     return out
 
 
+def kd_loss_delta_end_to_end(dev, fixture: str = "student_full_10s"):
+    """KD-loss delta WITH the frozen teacher in the loop (round 5): `kd_loss_delta` above feeds every mode the same stand-in teacher
+    tensors, so it says nothing about the teacher's own precision.  Here a seeded HuBERT-Base-shaped teacher runs on the HIP path in
+    the mode's dtype, its hidden states feed the HIP student's fused KD loss, and the total is compared with the CPU oracles end to
+    end (oracle.teacher_ref -> oracle.student_ref -> oracle.loss_ref, fp32: the restatements tests/test_oracle.py pins against the
+    reference / HuggingFace): utils/utils.py:80-99 + modules/model.py:420-552 + train.py:236-293 on 2 x 10 s, dropout off.  Modes
+    (student dtype, teacher dtype): fp32 / fp32, bf16 / bf16, fp16 / fp16 and the mixed fp16 student beside a bf16 teacher (what
+    recovering the fp16 mode's 4 % would take).  Checker leg: the oracle is the yardstick, never the thing measured."""
+    import numpy as np
+    from fithubert_amd.config import CustomStudentModelConfig
+    from fithubert_amd.engine import StudentEngine
+    from fithubert_amd.teacher import TeacherConfig, build_teacher
+    from oracle import loss_ref, student_ref
+    from oracle import teacher_ref as T
+
+    fx = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+    cfg = dict(yaml.safe_load(str(fx["cfg_yaml"])), dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    sd = student_ref.random_state_dict(cfg, seed=int(fx["weight_seed"]))
+    n = int(fx["samples"])
+    wav = float(fx["wav_rms"]) * torch.randn(2, n, generator=torch.Generator().manual_seed(int(fx["wav_seed"])))
+    rl = [int(v) for v in fx["rand_l"]]
+    ocfg = dict(T.BASE, model_type="hubert")
+    tsd = T.random_teacher_state_dict(ocfg, seed=17)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    try:
+        with torch.no_grad():
+            t_ref = T.teacher_extract_features(tsd, ocfg, wav, None)
+            s_ref = student_ref.student_forward(sd, cfg, wav, None)
+            ref, _ = loss_ref.calculate_loss(s_ref, t_ref, dict(rec_loss_weight=1.0, rec_loss_type="mse", distil_random_layer=len(rl),
+                                                                random_layer_weight=0.1), rand_l=rl, num_encoders=12)
+    finally:
+        torch.set_num_threads(prev)
+    ref = float(ref)
+    w = torch.zeros(12); w[rl] = 0.1; w[11] = 1.0
+    tdt = {"float32": torch.float32, "bf16": torch.bfloat16, "float16": torch.float16}
+    out = {"reference_loss_cpu_oracles": ref,
+           "what": "HIP teacher (its dtype) -> HIP student eval forward + fused KD loss (its dtype), total minus the CPU oracles' fp32 total "
+                   "(oracle teacher -> oracle student -> oracle loss) on the same seeded weights and waveform (2 x 10 s, dropout off)"}
+    for s_dt, t_dt in (("float32", "float32"), ("bf16", "bf16"), ("float16", "float16"), ("float16", "bf16")):
+        tw = build_teacher(TeacherConfig.base("hubert"), dtype=tdt[t_dt], device=dev, state_dict={k: v.clone() for k, v in tsd.items()},
+                           native_frontend=True)
+        hid = tw.hidden_stack(wav.to(dev), None).contiguous()
+        eng = StudentEngine(CustomStudentModelConfig(**cfg), dtype=s_dt, device=dev)
+        eng.load_state_dict(sd)
+        ws = eng.forward(wav.to(dev), None, training=False)
+        res, _ = eng.kd_loss(ws, hid, w.to(dev), torch.arange(12, dtype=torch.int32, device=dev), want_grad=False)
+        out[f"student_{s_dt}_teacher_{t_dt}"] = float(res.double().cpu().numpy()[12] - ref)
+        del eng, ws, tw, hid
+        torch.cuda.empty_cache()
+    return out
+
+
 def time_steps(task, batches, steps: int, warm: int):
     """-> (seconds, utterances, valid samples) for `steps` training steps cycling over `batches`, after `warm` untimed ones."""
     n = len(batches)
@@ -778,6 +831,11 @@ def main():
                 res["kd_loss_delta"] = kd_loss_delta(dev)
             except Exception as e:
                 res["kd_loss_delta"] = {"error": repr(e)}
+        if world == 1 and not args.no_kd_delta and not variant:
+            try:
+                res["kd_loss_delta_end_to_end"] = kd_loss_delta_end_to_end(dev)
+            except Exception as e:
+                res["kd_loss_delta_end_to_end"] = {"error": repr(e)}
         if world == 1 and not variant and not args.no_variants:
             try:
                 res["variants"] = run_variants(task, cfg, args, dev, args.variants_budget)
