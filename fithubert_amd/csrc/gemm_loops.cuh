@@ -1920,11 +1920,19 @@ template <> struct QuarterLoader<FH_R_STRIDED> {
 // phase building blocks of the 8-phase loops (they name acc, fa, fb, bx, by, xi0, yj0, lane of the enclosing function):
 // the DMA wait (this wave's own loads, RAW) goes BEFORE the barrier; the fragment reads are only waited for behind it, so
 // their latency overlaps the wait for the other wave group (the buffers they read are rewritten a whole K-tile later)
+// FH_PHASE_LGKM_WAIT: rounds 2 - 4 drained every fragment read (lgkmcnt(0)) behind the barrier before the cluster's first MFMA; the
+// compiler tracks these reads itself (they are plain LDS loads) and emits a counted lgkmcnt in front of each MFMA pair, so without the
+// drain the cluster starts as soon as its FIRST fragments have landed (-DFH_PHASE_DRAIN restores the drain for A/B runs)
+#ifdef FH_PHASE_DRAIN
+#define FH_PHASE_LGKM_WAIT asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define FH_PHASE_LGKM_WAIT
+#endif
 #define FH_PHASE_TAIL(WAITSTR)                                   \
   asm volatile(WAITSTR ::: "memory");                            \
   __builtin_amdgcn_sched_barrier(0);                             \
   __builtin_amdgcn_s_barrier();                                  \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+  FH_PHASE_LGKM_WAIT                                             \
   __builtin_amdgcn_sched_barrier(0);                             \
   __builtin_amdgcn_s_setprio(1);
 // Before a quarter that the previous phase read is handed to the LDS-DMA again: this wave's FIRST fragment read of the current
