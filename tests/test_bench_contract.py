@@ -70,3 +70,21 @@ def test_dp_projection_prefers_the_balanced_deal_on_the_librispeech_table():
     assert p["projected"] is True and p["fit_max_rel_error"] < 1e-6
     assert 0.7 < p["efficiency_plain_deal"] < 0.9 < p["efficiency_balanced_deal"] <= 1.0
     json.dumps(p)
+
+
+def test_gemm_launch_classes_follow_the_flag_bits():
+    """bench.classify: weight gradients by the atomic bit, the conv data gradients by their epilogue operand (bit 1: saved GELU', bit 2:
+    conv 0's weight-gradient epilogue) -- since round 5 their weight operand is R_CONTIG like the forward's, so the layouts no longer
+    tell them apart (fh_prof_collect_launches' `atomic` column is a bit field)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    B = 256
+    row = lambda **k: dict(dict(M=63744, N=480, K=480, groups=1, xl=0, yl=0, loop=8, atomic=0, tag=0), **k)
+    assert bench.classify(row(atomic=1, M=256, N=768, K=4095744, xl=1, yl=1), B) == "weight_gradients"
+    assert bench.classify(row(M=4095744, N=256, K=768), B) == "student_conv_forward"
+    assert bench.classify(row(M=4096000, N=512, K=512, atomic=2), B) == "student_conv_dgrad"
+    assert bench.classify(row(M=31999, N=128, K=256, groups=256, atomic=4, yl=1), B) == "student_conv_dgrad"
+    assert bench.classify(row(atomic=2), B) == "student_layer_gemms"          # fc1's data gradient carries GELU' too, but is no conv launch
+    assert bench.classify(row(M=127744, N=3072, K=768, tag=1), B) == "teacher_linear"
+    assert bench.classify(row(M=4095744, N=512, K=1536, tag=1), B) == "teacher_conv"
