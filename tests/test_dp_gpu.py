@@ -98,6 +98,7 @@ y["train"].update(distil_random_layer=1, accumulate_grad_batches=2)
 tc = TeacherConfig.base("hubert"); tc.encoder_layers = 2
 task = W2V2Distil(y, dtype="bf16", device="cuda:0", teacher_cfg=tc, seed=7 * rank, teacher_native_frontend=True)   # different inits:
 assert task.rank == rank and task.sync.world == 2                                                                   # rank 0's weights win
+assert (task.sync.wire is not None) == (os.environ.get("FH_DP_GRAD_WIRE") == "bf16")
 assert_replicas_equal(task.engine.params)
 task.configure_optimizers(num_training_steps=10)
 pool = [fixed_length_batch(2, 24000, seed=100 * rank + i, device="cuda:0") for i in range(5)]      # every rank its own shard
@@ -125,8 +126,10 @@ print("DP2_OK", rank, vals)
 ''' % (ROOT, ROOT)
 
 
-def test_two_ranks_train_on_one_gpu_over_gloo():
-    """Two real ranks (two processes, two native engines) sharing the one GPU of the test box, collectives staged through
+@pytest.mark.parametrize("wire", ["", "bf16"])
+def test_two_ranks_train_on_one_gpu_over_gloo(wire):
+    """(wire = "bf16": FH_DP_GRAD_WIRE, the gradient exchange staged through a bf16 buffer on the device -- dp.GradSync, round 5.)
+    Two real ranks (two processes, two native engines) sharing the one GPU of the test box, collectives staged through
     gloo: construction broadcast, gradient accumulation, the exchange launched segment by segment from inside the native
     backward on the communication stream, AdamW on the averaged gradients -- replicas stay bit-identical, every rank draws its
     own dropout masks.  (RCCL itself cannot put two ranks on one device; the RCCL leg is the 1-rank test above.)"""
@@ -135,7 +138,7 @@ def test_two_ranks_train_on_one_gpu_over_gloo():
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   FH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   FH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), FH_DP_GRAD_WIRE=wire)
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = [p.communicate(timeout=400) for p in procs]
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
