@@ -687,3 +687,45 @@ def test_kd_loss_in_the_heads_gemm_epilogue_equals_the_separate_loss_kernel(dtyp
     torch.cuda.synchronize()
     assert _rel_l2(eng.grads, g_a) < 1e-4                                       # same inputs; fp32 atomics in another order (1.1e-5 seen in fp16)
     assert torch.equal(ws_a.view("xo"), ws_b.view("xo"))
+
+
+@pytest.mark.parametrize("dtype,tol_l2,tol_g", [("float32", 1e-4, 3e-3), ("bf16", 2.5e-2, 6e-2)])
+def test_single_utterance_at_the_shortest_librispeech_length_against_the_oracle(dtype, tol_l2, tol_g):
+    """Edge of the size range (round 5): ONE utterance (the reference keeps a trailing bucket only with > 1 item, utils/dataset.py:52-53,
+    but `forward` itself takes any B) of train-clean-100's shortest length, 22,560 samples -> T' = 70 frames, T2 = 35: every GEMM has a
+    single ragged row tile, the attention one partial key tile.  3-layer student; forward, KD loss and gradients against the CPU oracle
+    (oracle/student_ref.py + loss_ref.py, the restatements tests/test_oracle.py pins to the reference)."""
+    from oracle import loss_ref
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=3, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    eng, sd = _engine(cfg, 11, dtype)
+    g = torch.Generator().manual_seed(3)
+    wav = 0.3 * torch.randn(1, 22560, generator=g)
+    sd_g = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = S.student_forward(sd_g, cfg, wav, None)
+    Tp = ref["projections"][0].shape[1]
+    assert ref["layer_results"][0][0].shape[0] == 35 and Tp == 70
+    teacher = torch.randn(3, 1, Tp + 1, 768, generator=g)
+    t_res = {"layer_results": [(teacher[i].transpose(0, 1), None) for i in range(3)]}
+    ref_loss, _ = loss_ref.calculate_loss(ref, t_res, dict(rec_loss_weight=1.0, rec_loss_type="mse", distil_random_layer=2,
+                                                           random_layer_weight=0.1), rand_l=[0, 1], num_encoders=3)
+    ref_loss.backward()
+    ws = eng.forward(wav.to(DEV), None, training=True, seed=1)
+    w = torch.tensor([0.1, 0.1, 1.0])
+    out, d_pred = eng.kd_loss(ws, teacher.to(DEV), w.to(DEV), torch.arange(3, dtype=torch.int32, device=DEV))
+    eng.grads.zero_()
+    eng.backward(ws, d_pred=d_pred)
+    torch.cuda.synchronize()
+    assert abs(out[3].item() - ref_loss.item()) < (1e-4 if dtype == "float32" else 4e-3 * ref_loss.item()), (out[3].item(), ref_loss.item())
+    for i in range(3):
+        assert _rel_l2(ws.view("pred")[i].float(), ref["projections"][i].detach()) < tol_l2, i
+    gv = eng.param_views(eng.grads)
+    bad = []
+    for k, v in sd_g.items():
+        if v.grad is None or k.startswith("upsampler.") or k.endswith("k_proj.bias"):
+            continue   # (the key bias shifts every logit of a row alike: its true gradient is zero, both sides hold rounding noise)
+        a, b = gv[k].double().cpu(), v.grad.double()
+        e = ((a - b).norm() / max(b.norm().item(), 5e-2 * (1 if dtype != "float32" else 0) + 1e-12)).item()
+        if e > tol_g:
+            bad.append((k, e))
+    assert not bad, bad
