@@ -729,3 +729,44 @@ def test_single_utterance_at_the_shortest_librispeech_length_against_the_oracle(
         if e > tol_g:
             bad.append((k, e))
     assert not bad, bad
+
+
+def test_ragged_pair_shortest_beside_a_ten_second_utterance_against_the_oracle():
+    """A strongly ragged batch (22,560 samples beside 160,000: 70 of 499 frames valid in the short row): padded frames zeroed behind
+    `post_extract_proj`, masked keys in every layer (T2 = 35 of 249), the conv frontend running over the padding as the reference does
+    (modules/model.py:449-472) -- fp32 engine, forward + loss + gradients against the CPU oracle."""
+    from oracle import loss_ref
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=2, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0)
+    eng, sd = _engine(cfg, 13, "float32")
+    g = torch.Generator().manual_seed(4)
+    lens = [160000, 22560]
+    wav = 0.3 * torch.randn(2, 160000, generator=g)
+    wav[1, lens[1]:] = 0
+    pm = torch.arange(160000)[None, :] >= torch.tensor(lens)[:, None]
+    sd_g = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = S.student_forward(sd_g, cfg, wav, pm)
+    Tp = ref["projections"][0].shape[1]
+    teacher = torch.randn(2, 2, Tp + 1, 768, generator=g)
+    t_res = {"layer_results": [(teacher[i].transpose(0, 1), None) for i in range(2)]}
+    ref_loss, _ = loss_ref.calculate_loss(ref, t_res, dict(rec_loss_weight=1.0, rec_loss_type="mse", distil_random_layer=1,
+                                                           random_layer_weight=0.1), rand_l=[0], num_encoders=2)
+    ref_loss.backward()
+    ws = eng.forward(wav.to(DEV), lens, training=True, seed=1)
+    out, d_pred = eng.kd_loss(ws, teacher.to(DEV), torch.tensor([0.1, 1.0]).to(DEV), torch.arange(2, dtype=torch.int32, device=DEV))
+    eng.grads.zero_()
+    eng.backward(ws, d_pred=d_pred)
+    torch.cuda.synchronize()
+    assert abs(out[2].item() - ref_loss.item()) < 1e-4, (out[2].item(), ref_loss.item())
+    for i in range(2):
+        assert _rel_l2(ws.view("pred")[i].float(), ref["projections"][i].detach()) < 1e-4, i
+    gv = eng.param_views(eng.grads)
+    bad = []
+    for k, v in sd_g.items():
+        if v.grad is None or k.startswith("upsampler.") or k.endswith("k_proj.bias"):
+            continue
+        a, b = gv[k].double().cpu(), v.grad.double()
+        e = ((a - b).norm() / max(b.norm().item(), 1e-12)).item()
+        if e > 3e-3:
+            bad.append((k, e))
+    assert not bad, bad
