@@ -12,11 +12,11 @@
 // GELU' on the staged operand; weight-gradient reduces over time with transposing LDS reads (ds_read_b64_tr_b16).
 #include "common.cuh"
 #include "kernels.h"
+#include "posconv_taps.cuh"
 
 namespace {
 
-constexpr int TT = 256;   // output frames per block (fwd / dgrad): 4 waves x 64 frames
-constexpr int NTT = TT / 64;  // 16-frame tiles per wave: each tap's weight fragments (streamed from L2) serve all of them
+// output frames per block (fwd / dgrad) = 4 waves x 16 NTT frames: each tap's weight fragments (streamed from L2) serve a wave's NTT tiles
 
 template <typename T, int CP> struct PC {
   static constexpr int RS = CP * (int)sizeof(T) + 16;  // LDS row stride in bytes
@@ -136,49 +136,134 @@ __device__ __forceinline__ void st2(bf16* p, const float* f) {
   *reinterpret_cast<uint32_t*>(p) = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
 }
 
+// Accesses at 4-byte alignment (the 30-channel groups start at multiples of 60 bytes; global memory takes the misaligned
+// dwordx2 / x3 / x4).  ld4u / st4u: four consecutive 16-bit channels = 8 bytes
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <typename T> __device__ __forceinline__ void st4u(T* p, const float* f) {
+  u32x2_a4 v = {pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3])};
+  *reinterpret_cast<u32x2_a4*>(p) = v;
+}
+template <typename T> __device__ __forceinline__ void ld4u(const T* p, float* f) {
+  const u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(p);
+  union { uint32_t u[2]; T h[4]; } c;
+  c.u[0] = v.x; c.u[1] = v.y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = (float)c.h[e];
+}
+// the first nch (0, 2, 4, 6 or >= 8) of 8 consecutive 16-bit channels, the rest zero: ONE access of 4 / 8 / 12 / 16 bytes
+__device__ __forceinline__ V16 ld_unit(const void* p, int nch) {
+  V16 v = v16_zero();
+  if (nch >= 8) {
+    const u32x4_a4 t = *reinterpret_cast<const u32x4_a4*>(p);
+    v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z; v.w[3] = t.w;
+  } else if (nch == 6) {
+    const u32x3_a4 t = *reinterpret_cast<const u32x3_a4*>(p);
+    v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z;
+  } else if (nch == 4) {
+    const u32x2_a4 t = *reinterpret_cast<const u32x2_a4*>(p);
+    v.w[0] = t.x; v.w[1] = t.y;
+  } else if (nch == 2) {
+    v.w[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+  return v;
+}
+__device__ __forceinline__ void st_unit(void* p, const V16& v, int nch) {
+  if (nch >= 8) {
+    *reinterpret_cast<u32x4_a4*>(p) = u32x4_a4{v.w[0], v.w[1], v.w[2], v.w[3]};
+  } else if (nch == 6) {
+    *reinterpret_cast<u32x3_a4*>(p) = u32x3_a4{v.w[0], v.w[1], v.w[2]};
+  } else if (nch == 4) {
+    *reinterpret_cast<u32x2_a4*>(p) = u32x2_a4{v.w[0], v.w[1]};
+  } else if (nch == 2) {
+    *reinterpret_cast<uint32_t*>(p) = v.w[0];
+  }
+}
 // stage `nrows` window rows (frame t_first + row, group g) of `src` into LDS as [row][CP] (zero outside [0,Tn)
 // and for padded channels).  GP: multiply by gelu'(zc) and, for rows in [own0, own1), also write the product to dz.
 template <typename T, int CP, bool GP>
 __device__ __forceinline__ void stage_rows(unsigned char* lds, const T* src, const T* zc, T* dz, int b, int Tn, int D,
                                            int cg, int g, int t_first, int nrows, int own0, int own1) {
-  if constexpr (!GP && sizeof(T) == 2) {
-    // group rows of a whole number of 16-byte vectors (cg % 8 == 0, e.g. 48 channels): one 16-byte load / LDS store per 8 channels
-    // instead of four 4-byte ones (the 30-channel groups of fithubert.yaml start at 60-byte offsets and cannot)
-    if (cg % 8 == 0) {
-      const int u8 = CP / 8, total8 = nrows * u8;
-      for (int idx = threadIdx.x; idx < total8; idx += blockDim.x) {
+  if constexpr (sizeof(T) == 2) {
+    // 8 channels per thread and access (16 bytes; 12 for the ragged last unit of a 30-channel group, whose rows start at multiples of
+    // 60 bytes: 4-byte aligned only).  As 4-byte pairs, 24 - 40 trips per thread with their index arithmetic, staging alone took
+    // 86 us (forward) / 200 us (data gradient) of 640 at B = 256.  BATCH units' loads are issued before the first is used.
+    constexpr int u8 = CP / 8, BATCH = 4;
+    const int total8 = nrows * u8;
+    for (int i0 = threadIdx.x; i0 < total8; i0 += blockDim.x * BATCH) {
+      V16 v[BATCH], zv[BATCH];
+      long off[BATCH];
+      int nch[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int idx = i0 + j * (int)blockDim.x;
         const int row = idx / u8, u = idx - row * u8;
         const int t = t_first + row;
-        V16 v = v16_zero();
-        if (t >= 0 && t < Tn && 8 * u < cg) v = ld16(src + ((long)b * Tn + t) * D + g * cg + 8 * u);
-        st16(lds + row * PC<T, CP>::RS + u * 16, v);
+        const int rem = cg - 8 * u;
+        nch[j] = (idx < total8 && t >= 0 && t < Tn && rem > 0) ? (rem < 8 ? rem : 8) : 0;
+        off[j] = ((long)b * Tn + t) * D + g * cg + 8 * u;
+        v[j] = ld_unit(src + off[j], nch[j]);
+        if (GP) zv[j] = ld_unit(zc + off[j], nch[j]);
       }
-      return;
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int idx = i0 + j * (int)blockDim.x;
+        if (idx >= total8) continue;
+        const int row = idx / u8, u = idx - row * u8;
+        if (GP) {
+          float f[8], z[8];
+          unpack16<T>(v[j], f);
+          unpack16<T>(zv[j], z);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= gelu_grad_t<T>(z[e]);
+          v[j] = pack16<T>(f);
+          if (row >= own0 && row < own1) st_unit(dz + off[j], v[j], nch[j]);
+        }
+        st16(lds + row * PC<T, CP>::RS + u * 16, v[j]);
+      }
     }
+    return;
   }
-  const int units = CP / 2;
+  // 4-byte units (the 30-channel groups of fithubert.yaml start at 60-byte offsets).  Every thread first issues the loads of BATCH
+  // units, then converts and stores them: one unit per trip left every trip's global-load round trip exposed (24 - 40 serial trips per
+  // workgroup: ~0.3 of the forward's time at B = 256)
+  constexpr int units = CP / 2, BATCH = 8;
   const int total = nrows * units;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const int row = idx / units, u = idx - row * units;
-    const int t = t_first + row;
-    float f[2] = {0.f, 0.f};
-    if (t >= 0 && t < Tn && 2 * u + 1 < cg) {
-      const long off = ((long)b * Tn + t) * D + g * cg + 2 * u;
-      ld2(src + off, f);
-      if (GP) {
-        float z[2];
-        ld2(zc + off, z);
-        f[0] *= gelu_grad_t<T>(z[0]);
-        f[1] *= gelu_grad_t<T>(z[1]);
-        if (row >= own0 && row < own1) st2(dz + off, f);
+  for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * BATCH) {
+    float f[BATCH][2], z[BATCH][2];
+    long off[BATCH];
+    bool ok[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int idx = i0 + j * (int)blockDim.x;
+      const int row = idx / units, u = idx - row * units;
+      const int t = t_first + row;
+      ok[j] = idx < total && t >= 0 && t < Tn && 2 * u + 1 < cg;
+      off[j] = ((long)b * Tn + t) * D + g * cg + 2 * u;
+      f[j][0] = f[j][1] = 0.f;
+      if (ok[j]) {
+        ld2(src + off[j], f[j]);
+        if (GP) ld2(zc + off[j], z[j]);
       }
     }
-    st2(reinterpret_cast<T*>(lds + row * PC<T, CP>::RS) + 2 * u, f);
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int idx = i0 + j * (int)blockDim.x;
+      if (idx >= total) continue;
+      const int row = idx / units, u = idx - row * units;
+      if (GP && ok[j]) {
+        f[j][0] *= gelu_grad_t<T>(z[j][0]);
+        f[j][1] *= gelu_grad_t<T>(z[j][1]);
+        if (row >= own0 && row < own1) st2(dz + off[j], f[j]);
+      }
+      st2(reinterpret_cast<T*>(lds + row * PC<T, CP>::RS) + 2 * u, f[j]);
+    }
   }
 }
 
 // ---------------------------------------------------------------- forward / data-gradient
-template <typename T, int CP, bool BWD>
+template <typename T, int CP, bool BWD, int NTT = 4>   // NTT: 16-frame tiles per wave (64 NTT output frames per block)
 __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, const T* __restrict__ zc_in,
                                                       const T* __restrict__ w, const float* __restrict__ bias,
                                                       T* __restrict__ out1, T* __restrict__ out2, int B, int Tn, int D,
@@ -187,6 +272,7 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
   typedef Frag<T, CP> F;
   constexpr int CB = PC<T, CP>::CB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int TT = 64 * NTT;
   const int t0 = blockIdx.x * TT, g = blockIdx.y, b = blockIdx.z;
   const int nrows = TT + K - 1;
   stage_rows<T, CP, BWD>(lds, in, zc_in, out1, b, Tn, D, cg, g, t0 - pad_left, nrows, pad_left, pad_left + TT);
@@ -199,6 +285,17 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
     for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * K * CP * CP;
   const int r = lane & 15;
+  bool taps_done = false;
+  if constexpr (sizeof(T) == 2 && CP == 32) {
+    if (K == 128) {
+      constexpr int RS = PC<T, CP>::RS;
+      const unsigned char* xrow = lds + (wave * (16 * NTT) + r) * RS + (lane >> 4) * 16;
+      toeplitz_taps<T, CB, NTT, 8>(16, [&](int c) { return xrow + c * RS; }, [&](int c) { return wg + (long)c * (CP * CP); }, 16L * CP * CP, 16 * RS,
+                                   lane, acc);
+      taps_done = true;
+    }
+  }
+  if (!taps_done) {
   // weights stream from L2 (identical for every workgroup of the group): keep the NEXT tap's fragments in flight
   typename F::type wn[F::NK][CB];
 #pragma unroll
@@ -228,8 +325,58 @@ __global__ void __launch_bounds__(256) posconv_kernel(const T* __restrict__ in, 
         for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = F::mma(wf[kr][cb], xf[tt], acc[cb][tt]);
     }
   }
+  }
 
   const int q = lane >> 4;
+  if constexpr (sizeof(T) == 2) {
+    // a lane holds four consecutive channels of one frame: one 8-byte access per tensor (pairs only for a group's ragged last quad).
+    // As 4-byte pairs the epilogue alone took 175 us of the forward's 640 at B = 256 (16 rows x 4 lanes x 4 bytes per store instruction)
+    float bq[CB][4];
+    if (!BWD) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = cb * 16 + q * 4 + e;
+          bq[cb][e] = co < cg ? bias[g * cg + co] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const int tl = wave * (16 * NTT) + tt * 16 + r;
+      const int t = t0 + tl;
+      if (t >= Tn) continue;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int co = cb * 16 + q * 4;
+        if (co >= cg) continue;
+        const bool quad = co + 3 < cg;   // else channels co, co + 1 only (cg is even)
+        const long off = ((long)b * Tn + t) * D + g * cg + co;
+        float v[4] = {acc[cb][tt][0], acc[cb][tt][1], acc[cb][tt][2], acc[cb][tt][3]};
+        if (!BWD) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bq[cb][e];
+          if (quad) st4u(out1 + off, v);
+          else st2(out1 + off, v);
+          float xv[4];
+          ld4u(reinterpret_cast<const T*>(lds + (tl + pad_left) * PC<T, CP>::RS) + co, xv);   // (padded channels are staged as zeros)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = xv[e] + gelu_t<T>(v[e]);
+          if (quad) st4u(out2 + off, v);
+          else st2(out2 + off, v);
+        } else {
+          float dv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (quad) ld4u(in + off, dv);
+          else ld2(in + off, dv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += dv[e];
+          if (quad) st4u(out2 + off, v);
+          else st2(out2 + off, v);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
     const int tl = wave * (16 * NTT) + tt * 16 + r;
@@ -287,7 +434,7 @@ template <int CP> struct WgFrag {
 // CB = 16-channel blocks that hold real channels (3 for the 48-channel groups: the fourth block of the 64-wide padding is all
 // zeros), JW = taps per wave (accumulators: JW * CB * CB tiles).  A workgroup re-stages the same dz / x tiles for its 4 * JW taps
 // only, so JW sets how often every tile is staged: 2 taps per wave made the 64-wide build 5x slower per FLOP than the 32-wide one.
-template <typename T, int CP, int CB, int JW>
+template <typename T, int CP, int CB, int JW, bool TOEP = false>
 __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict__ dzc, const T* __restrict__ x,
                                                             float* __restrict__ dws, int B, int Tn, int D, int cg, int K,
                                                             int pad_left, int nsplit) {
@@ -298,6 +445,13 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.y;
   const int jbase = blockIdx.x * (4 * JW) + wave * JW;
+  // Toeplitz tap assignment (16-bit, 8 taps per wave, K = 128): a wave owns the two tap classes cls0, cls0 + 1 (mod 32), i.e. taps
+  // cls + 32 i: at K-step ks tap (cls, i) needs the window frames [32 (ks + i) + cls, + 32), the fragment tap (cls, i + 1) read one
+  // K-step earlier.  With 8 CONSECUTIVE taps per wave every K-step reads 2 + 16 fragments for its 32 MFMAs -- 4 waves x 18 KB per 512
+  // MFMA cycles is more than the LDS port delivers (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.5 on top); this order reads 2 + 4.
+  static_assert(!TOEP || (sizeof(T) == 2 && JW == 8 && TS % 32 == 0), "Toeplitz taps: 16-bit, 8 taps per wave");
+  constexpr bool toep = TOEP;   // (the launcher picks it for K = 128)
+  const int cls0 = blockIdx.x * 8 + wave * 2;
   const int ntt = (Tn + TS - 1) / TS;
   f32x4 acc[JW][CB][CB];
 #pragma unroll
@@ -307,27 +461,25 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
 #pragma unroll
       for (int ib = 0; ib < CB; ++ib) acc[jj][cb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // bf16, channel groups that are no whole number of 16-byte vectors (fithubert.yaml: 30 channels): the (dzc | x window) rows of
-  // tile i + 1 are fetched into REGISTERS (40 four-byte pairs per thread at K = 128) before tile i is multiplied and stored to LDS
-  // behind it.  Staged synchronously, a tile cost 40 dependent load -> LDS-store round trips per thread against 2 us of MFMA work
-  // with one workgroup per CU: 608 us per launch, four fifths of it waiting.
-  constexpr int NPRE = 48, UN = CP / 2;
-  const int unitsA = TS * UN, total_units = unitsA + (TS + K - 1) * UN;
-  const bool prefetch = sizeof(T) == 2 && cg % 8 != 0 && total_units <= NPRE * 256;
-  uint32_t pre[NPRE];
+  // 16-bit, 32-channel groups: the (dzc | x window) rows of tile i + 1 are fetched into REGISTERS (10 sixteen-byte units per thread
+  // at K = 128; the ragged last unit of a 30-channel row is 12 bytes, rows start at multiples of 60 bytes) before tile i is multiplied,
+  // and stored to LDS behind it.  Staged synchronously, a tile cost 40 dependent load -> LDS-store round trips per thread against
+  // 2 us of MFMA work with one workgroup per CU: 608 us per launch, four fifths of it waiting.
+  constexpr int NPRE = 12, U8 = CP / 8;
+  const int unitsA = TS * U8, total_units = unitsA + (TS + K - 1) * U8;
+  const bool prefetch = sizeof(T) == 2 && total_units <= NPRE * 256;
+  V16 pre[NPRE];
   auto fetch = [&](int tile) {
     const int b = tile / ntt, t0 = (tile - b * ntt) * TS;
 #pragma unroll
     for (int j = 0; j < NPRE; ++j) {
       const int idx = (int)threadIdx.x + j * 256;
-      pre[j] = 0u;
-      if (idx < total_units) {
-        const bool isb = idx >= unitsA;
-        const int loc = isb ? idx - unitsA : idx, row = loc / UN, u = loc - row * UN;
-        const int t = (isb ? t0 - pad_left : t0) + row;
-        if (t >= 0 && t < Tn && 2 * u + 1 < cg)
-          pre[j] = *reinterpret_cast<const uint32_t*>((isb ? x : dzc) + ((long)b * Tn + t) * D + g * cg + 2 * u);
-      }
+      const bool isb = idx >= unitsA;
+      const int loc = isb ? idx - unitsA : idx, row = loc / U8, u = loc - row * U8;
+      const int t = (isb ? t0 - pad_left : t0) + row;
+      const int rem = cg - 8 * u;
+      const int nch = (idx < total_units && t >= 0 && t < Tn && rem > 0) ? (rem < 8 ? rem : 8) : 0;
+      pre[j] = ld_unit((isb ? x : dzc) + ((long)b * Tn + t) * D + g * cg + 8 * u, nch);
     }
   };
   auto deposit = [&]() {
@@ -336,8 +488,8 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
       const int idx = (int)threadIdx.x + j * 256;
       if (idx < total_units) {
         const bool isb = idx >= unitsA;
-        const int loc = isb ? idx - unitsA : idx, row = loc / UN, u = loc - row * UN;
-        *reinterpret_cast<uint32_t*>((isb ? ldsB : ldsA) + row * RS + u * 4) = pre[j];
+        const int loc = isb ? idx - unitsA : idx, row = loc / U8, u = loc - row * U8;
+        st16((isb ? ldsB : ldsA) + row * RS + u * 16, pre[j]);
       }
     }
   };
@@ -353,7 +505,40 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
     }
     __syncthreads();
     if (prefetch && tile + nsplit < B * ntt) fetch(tile + nsplit);
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (TOEP) {
+      {
+        // tap (class c, i) at K-step ks reads the window fragment that starts at frame 32 (ks + i) + c: a sliding window of four
+        // fragments per class, ONE new per K-step
+        bf16x8 bw[2][4][CB];
+#pragma unroll
+        for (int cls = 0; cls < 2; ++cls)
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int ib = 0; ib < CB; ++ib) bw[cls][n][ib] = WgFrag<CP>::load(ldsB, 32 * n + cls0 + cls, ib * 16, lane);
+#pragma unroll
+        for (int ks = 0; ks < TS / 32; ++ks) {
+          bf16x8 fa[CB];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) fa[cb] = WgFrag<CP>::load(ldsA, ks * 32, cb * 16, lane);
+#pragma unroll
+          for (int cls = 0; cls < 2; ++cls)
+#pragma unroll
+            for (int ib = 0; ib < CB; ++ib) bw[cls][(ks + 3) & 3][ib] = WgFrag<CP>::load(ldsB, 32 * (ks + 3) + cls0 + cls, ib * 16, lane);
+#pragma unroll
+          for (int cls = 0; cls < 2; ++cls)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < CB; ++ib)
+                  acc[cls * 4 + i][cb][ib] = mfma16<T>(fa[cb], bw[cls][(ks + i) & 3][ib], acc[cls * 4 + i][cb][ib]);
+        }
+        continue;
+      }
+    }
+    if constexpr (sizeof(T) == 2 && !TOEP) {
 #pragma unroll 1
       for (int ks = 0; ks < TS / 32; ++ks) {
         bf16x8 fa[CB];
@@ -371,7 +556,7 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
               acc[jj][cb][ib] = mfma16<T>(fa[cb], fb[ib], acc[jj][cb][ib]);
         }
       }
-    } else {
+    } else if constexpr (sizeof(T) == 4) {
       const int r = lane & 15, q = lane >> 4;
 #pragma unroll 1
       for (int kk = 0; kk < TS / 4; ++kk) {  // 4 frames per MFMA: frame = 4*kk + q
@@ -397,7 +582,7 @@ __global__ void __launch_bounds__(256) posconv_wgrad_kernel(const T* __restrict_
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int jj = 0; jj < JW; ++jj) {
-    const int j = jbase + jj;
+    const int j = toep ? cls0 + (jj >> 2) + 32 * (jj & 3) : jbase + jj;
     if (j >= K) continue;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -443,7 +628,7 @@ __global__ void wn_apply_kernel(const float* __restrict__ gsc, const float* __re
   if (oc == 0 && ci == 0) dg[j] += dj / nj;
 }
 
-template <typename T, int CP> size_t fwd_lds(int K) { return (size_t)(TT + K - 1) * PC<T, CP>::RS; }
+template <typename T, int CP> size_t fwd_lds(int K, int tt) { return (size_t)(tt + K - 1) * PC<T, CP>::RS; }
 template <typename T, int CP> size_t wg_lds(int K) { return (size_t)(2 * PC<T, CP>::TS + K - 1) * PC<T, CP>::RS; }
 template <typename Kern> void set_lds(Kern k, size_t bytes) {
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -458,19 +643,30 @@ int prep_t(const float* g, const float* v, const float* norm2, void* w_fwd, void
   FH_CHECK_LAUNCH();
   return 0;
 }
-template <typename T, int CP, bool BWD>
-int conv_t(const void* in, const void* zc, const void* w, const float* bias, void* o1, void* o2, int B, int Tn, int D, int groups,
-           int K, int pad_left, hipStream_t st) {
+template <typename T, int CP, bool BWD, int NTT>
+int conv_launch(const void* in, const void* zc, const void* w, const float* bias, void* o1, void* o2, int B, int Tn, int D, int groups,
+                int K, int pad_left, hipStream_t st) {
+  constexpr int TT = 64 * NTT;
   dim3 grid((Tn + TT - 1) / TT, groups, B), block(256);
-  const size_t smem = fwd_lds<T, CP>(K);
-  set_lds(posconv_kernel<T, CP, BWD>, smem);
-  hipLaunchKernelGGL((posconv_kernel<T, CP, BWD>), grid, block, smem, st, (const T*)in, (const T*)zc, (const T*)w, bias, (T*)o1,
+  const size_t smem = fwd_lds<T, CP>(K, TT);
+  set_lds(posconv_kernel<T, CP, BWD, NTT>, smem);
+  hipLaunchKernelGGL((posconv_kernel<T, CP, BWD, NTT>), grid, block, smem, st, (const T*)in, (const T*)zc, (const T*)w, bias, (T*)o1,
                      (T*)o2, B, Tn, D, D / groups, K, pad_left);
   FH_CHECK_LAUNCH();
   return 0;
 }
-template <typename T, int CP, int CB, int JW>
-int wgrad_t(const void* dzc, const void* x, float* dws, int B, int Tn, int D, int groups, int K, hipStream_t st) {
+template <typename T, int CP, bool BWD>
+int conv_t(const void* in, const void* zc, const void* w, const float* bias, void* o1, void* o2, int B, int Tn, int D, int groups,
+           int K, int pad_left, hipStream_t st) {
+  // the Toeplitz tap loop (16-bit, 32-channel groups, K = 128) with 8 tiles per wave: half the weight-fragment traffic per MFMA
+  if constexpr (sizeof(T) == 2 && CP == 32) {
+    static const int wide = [] { const char* e = getenv("FH_POSCONV_NTT"); return e ? atoi(e) : 8; }();
+    if (K == 128 && wide == 8 && Tn > 256) return conv_launch<T, CP, BWD, 8>(in, zc, w, bias, o1, o2, B, Tn, D, groups, K, pad_left, st);
+  }
+  return conv_launch<T, CP, BWD, 4>(in, zc, w, bias, o1, o2, B, Tn, D, groups, K, pad_left, st);
+}
+template <typename T, int CP, int CB, int JW, bool TOEP>
+int wgrad_launch(const void* dzc, const void* x, float* dws, int B, int Tn, int D, int groups, int K, hipStream_t st) {
   constexpr int TS = PC<T, CP>::TS;
   if (K % (4 * JW)) return -502;
   const int ntt = (Tn + TS - 1) / TS;
@@ -478,11 +674,19 @@ int wgrad_t(const void* dzc, const void* x, float* dws, int B, int Tn, int D, in
   if (nsplit > 8) nsplit = 8;
   dim3 grid(K / (4 * JW), groups, nsplit), block(256);
   const size_t smem = wg_lds<T, CP>(K);
-  set_lds(posconv_wgrad_kernel<T, CP, CB, JW>, smem);
-  hipLaunchKernelGGL((posconv_wgrad_kernel<T, CP, CB, JW>), grid, block, smem, st, (const T*)dzc, (const T*)x, dws, B, Tn, D, D / groups, K,
+  set_lds(posconv_wgrad_kernel<T, CP, CB, JW, TOEP>, smem);
+  hipLaunchKernelGGL((posconv_wgrad_kernel<T, CP, CB, JW, TOEP>), grid, block, smem, st, (const T*)dzc, (const T*)x, dws, B, Tn, D, D / groups, K,
                      K / 2, nsplit);
   FH_CHECK_LAUNCH();
   return 0;
+}
+template <typename T, int CP, int CB, int JW>
+int wgrad_t(const void* dzc, const void* x, float* dws, int B, int Tn, int D, int groups, int K, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && JW == 8) {
+    static const bool toep = [] { const char* e = getenv("FH_POSCONV_WGRAD_TOEPLITZ"); return !e || atoi(e) != 0; }();
+    if (K == 128 && toep) return wgrad_launch<T, CP, CB, JW, true>(dzc, x, dws, B, Tn, D, groups, K, st);
+  }
+  return wgrad_launch<T, CP, CB, JW, false>(dzc, x, dws, B, Tn, D, groups, K, st);
 }
 
 }  // namespace

@@ -6,6 +6,7 @@
 
 #include "common.cuh"
 #include "kernels.h"
+#include "posconv_taps.cuh"
 
 namespace {
 
@@ -13,7 +14,9 @@ constexpr int CPW = 64;
 // frames per workgroup = 4 waves x 16 NTT frames: each tap's weight fragments (streamed from L2 by every wave) serve NTT frame
 // tiles, so NTT sets the L2 traffic per MFMA
 
-template <typename T> struct PW { static constexpr int RS = CPW * (int)sizeof(T) + 16; };
+// LDS row strides (bytes), both = 32 (mod 64): the 16 rows x 4 sixteen-byte columns of one fragment read then cover the 64 banks
+// exactly once (see PC<>::RS in posconv.hip).  The 48-channel form keeps only its 96 real bytes per row.
+template <typename T> struct PW { static constexpr int RS = CPW * (int)sizeof(T) + 32, RS48 = 48 * (int)sizeof(T); };
 
 __global__ void __launch_bounds__(256) wnw_norm2_kernel(const float* __restrict__ v, float* __restrict__ norm2, int rows, int K) {
   __shared__ float red[256];
@@ -202,23 +205,36 @@ __global__ void wnw_layout48_kernel(const float* __restrict__ gsc, const float* 
   w_fwd[o] = from_f<T>(gsc[j] * v[((long)(g * 48 + co) * 48 + ci) * K + j] * rsqrtf(norm2[j]));
 }
 
-template <typename T, int NTT>
+template <typename T, int NTT, bool TOEP>   // TOEP: K = 128 (64 tap pairs) in Toeplitz order
 __global__ void __launch_bounds__(256) posconv_wide48_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                              const float* __restrict__ bias, T* __restrict__ y, int B, int Tn,
                                                              int D, int K, int pad_left) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int RS = PW<T>::RS, cg = 48;
+  constexpr int RS = PW<T>::RS48, cg = 48;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
   constexpr int TTW = 64 * NTT;
   const int t0 = blockIdx.x * TTW, g = blockIdx.y, b = blockIdx.z;
   const int nrows = TTW + K - 1;
-  const int units = CPW / 2;
-  for (int idx = threadIdx.x; idx < nrows * units; idx += blockDim.x) {
-    const int row = idx / units, u = idx - row * units;
-    const int t = t0 - pad_left + row;
-    float f[2] = {0.f, 0.f};
-    if (t >= 0 && t < Tn && 2 * u + 1 < cg) ld2w(x + ((long)b * Tn + t) * D + g * cg + 2 * u, f);
-    st2w(reinterpret_cast<T*>(lds + row * RS) + 2 * u, f);
+  // a row holds exactly its 48 channels = 6 sixteen-byte units (D and the group offset are multiples of 8 elements here: 768 / 48);
+  // BATCH units' loads are issued before the first is stored (as 4-byte pairs, one per trip, staging cost as much as a third of the taps)
+  constexpr int units = cg / 8, BATCH = 4;
+  for (int i0 = threadIdx.x; i0 < nrows * units; i0 += blockDim.x * BATCH) {
+    V16 v[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int idx = i0 + j * (int)blockDim.x;
+      const int row = idx / units, u = idx - row * units;
+      const int t = t0 - pad_left + row;
+      v[j] = v16_zero();
+      if (idx < nrows * units && t >= 0 && t < Tn) v[j] = ld16(x + ((long)b * Tn + t) * D + g * cg + 8 * u);
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int idx = i0 + j * (int)blockDim.x;
+      if (idx >= nrows * units) continue;
+      const int row = idx / units, u = idx - row * units;
+      st16(lds + row * RS + u * 16, v[j]);
+    }
   }
   __syncthreads();
   f32x4 acc[3][NTT];
@@ -227,13 +243,21 @@ __global__ void __launch_bounds__(256) posconv_wide48_kernel(const T* __restrict
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) acc[cb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const T* wg = w + (long)g * (K / 2) * 9 * 512;
+  const int np = K / 2;
+  if constexpr (TOEP) {
+    // Toeplitz order over the tap pairs (posconv_taps.cuh): pair p = rho + 8 i of tile tt reads the window rows 16 (tt + i) + 2 rho + r,
+    // so the 8 pair classes rho x 3 reduction slabs are walked as 24 classes of NI = 8 taps; a class's window fragment of step m
+    // serves tap i = m - tt of every tile (12 MFMAs per 1 KB LDS read), its 24 weight fragments are requested one class ahead
+    const unsigned char* xbase = lds + (wave * (16 * NTT) + r) * RS + q * 16;
+    toeplitz_taps<T, 3, NTT, 8>(24, [&](int c) { return xbase + (c / 3) * (2 * RS) + (c % 3) * 64; },
+                                [&](int c) { return wg + (long)(c / 3) * (9 * 512) + (c % 3) * (3 * 512); }, 8L * 9 * 512, 16 * RS, lane, acc);
+  } else {
   int xoff[3];   // byte offset of this lane's 8 reduction elements of slab sl inside the window rows of a tap pair
 #pragma unroll
   for (int sl = 0; sl < 3; ++sl) {
     const int kk = 32 * sl + 8 * q;
     xoff[sl] = (kk / 48) * RS + (kk % 48) * 2;
   }
-  const int np = K / 2;
   // weight fragments of tap pair p + 3 are requested (from L2) while pair p's 36 MFMAs per frame tile run; ring of four register sets
   bf16x8 wr[4][3][3];
   auto load_pair = [&](int slot, int p) {
@@ -263,6 +287,13 @@ __global__ void __launch_bounds__(256) posconv_wide48_kernel(const T* __restrict
       }
     }
   }
+  }
+  // a lane holds four consecutive channels of one frame: one 8-byte store (and one 8-byte LDS read of the residual) per tile
+  float bq[3][4];
+#pragma unroll
+  for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bq[cb][e] = bias[g * cg + cb * 16 + q * 4 + e];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
     const int tl = wave * (16 * NTT) + tt * 16 + r;
@@ -270,17 +301,13 @@ __global__ void __launch_bounds__(256) posconv_wide48_kernel(const T* __restrict
     if (t >= Tn) continue;
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb) {
+      const int co = cb * 16 + q * 4;
+      const long off = ((long)b * Tn + t) * D + g * cg + co;
+      float xv[4], v[4];
+      ld4(reinterpret_cast<const T*>(lds + (tl + pad_left) * RS) + co, xv);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int co = cb * 16 + q * 4 + 2 * h;
-        const long off = ((long)b * Tn + t) * D + g * cg + co;
-        float v[2] = {acc[cb][tt][2 * h] + bias[g * cg + co], acc[cb][tt][2 * h + 1] + bias[g * cg + co + 1]};
-        float xv[2];
-        ld2w(reinterpret_cast<const T*>(lds + (tl + pad_left) * RS) + co, xv);
-        v[0] = xv[0] + gelu_t<T>(v[0]);
-        v[1] = xv[1] + gelu_t<T>(v[1]);
-        st2w(y + off, v);
-      }
+      for (int e = 0; e < 4; ++e) v[e] = xv[e] + gelu_t<T>(acc[cb][tt][e] + bq[cb][e]);
+      st4(y + off, v);
     }
   }
 }
@@ -331,17 +358,21 @@ extern "C" int fh_posconv_wide_forward(int dtype, const void* x, const void* w_f
   const int TTW = 64 * ntt;
   dim3 grid((T + TTW - 1) / TTW, groups, B), block(256);
   if (flat48(dtype, cg, K)) {
-#define FH_PW48(TY, NT)                                                                                                        \
+#define FH_PW48(TY, NT, TP)                                                                                                    \
   do {                                                                                                                       \
-    const size_t smem = (size_t)(64 * NT + K - 1) * PW<TY>::RS;                                                              \
-    hipFuncSetAttribute((const void*)posconv_wide48_kernel<TY, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
-    hipLaunchKernelGGL((posconv_wide48_kernel<TY, NT>), grid, block, smem, st, (const TY*)x, (const TY*)w_fwd, bias, (TY*)y, B, T, D, \
-                       K, K / 2);                                                                                            \
+    const size_t smem = (size_t)(64 * NT + K - 1) * PW<TY>::RS48;                                                            \
+    hipFuncSetAttribute((const void*)posconv_wide48_kernel<TY, NT, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((posconv_wide48_kernel<TY, NT, TP>), grid, block, smem, st, (const TY*)x, (const TY*)w_fwd, bias, (TY*)y, B, T, \
+                       D, K, K / 2);                                                                                         \
   } while (0)
-    if (dtype == 2 && ntt == 8) FH_PW48(f16, 8);
-    else if (dtype == 2) FH_PW48(f16, 4);
-    else if (ntt == 8) FH_PW48(bf16, 8);
-    else FH_PW48(bf16, 4);
+    static const bool toep_on = [] { const char* e = getenv("FH_POSCONV_WIDE_TOEPLITZ"); return !e || atoi(e) != 0; }();
+    const bool toep = toep_on && K == 128 && ntt == 4;
+    if (dtype == 2 && toep) FH_PW48(f16, 4, true);
+    else if (toep) FH_PW48(bf16, 4, true);
+    else if (dtype == 2 && ntt == 8) FH_PW48(f16, 8, false);
+    else if (dtype == 2) FH_PW48(f16, 4, false);
+    else if (ntt == 8) FH_PW48(bf16, 8, false);
+    else FH_PW48(bf16, 4, false);
 #undef FH_PW48
     FH_CHECK_LAUNCH();
     return 0;
