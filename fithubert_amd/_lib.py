@@ -174,6 +174,7 @@ SIGNATURES = {
     "fh_attention_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, Drop, _P]),
     "fh_attention_backward_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
     "fh_attention_backward_ws": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, Drop, _P, _P]),
+    "fh_attention_backward_bias": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, Drop, _P, _P]),
     "fh_kd_loss_nblk": (_I, [_I, _I, _I, _I]),
     "fh_kd_loss": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _P]),
     "fh_kd_loss_rows_nblk": (_I, [_I, _I]),

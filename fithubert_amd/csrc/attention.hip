@@ -624,6 +624,64 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const T* __restri
   }
 }
 
+// q | k | v bias gradient out of the fused backward kernels: column sums of a workgroup's dQ / dK / dV contributions (fp32, before the
+// rounding of the stored gradient), reduced over the 16 rows of a tile in the wave, over the waves through LDS (`red`: a region no
+// wave reads any more), then one atomicAdd per column and workgroup into dbias [3][D].  Replaces a pass over the 3 D-wide gradient
+// (2.2 GB per student step at B = 256).  Every thread of the workgroup calls it (one barrier).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+template <int NDT>
+__device__ __forceinline__ void qkv_bias_sums(float* red, float* __restrict__ dbias, const f32x4 (&dk)[2][NDT], const f32x4 (&dv)[2][NDT],
+                                              const bool (&kvalid)[2], const f32x4& qsum, int h, int dh, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  constexpr int NC = 16 * NDT;
+  float* redk = red;                   // [8 waves][NC]
+  float* redv = red + 8 * NC;          // [8 waves][NC]
+  float* redq = red + 16 * NC;         // [2 query halves][NC]
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = 0.f, c = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        if (kvalid[kt]) {
+          a += dk[kt][dt][e];
+          c += dv[kt][dt][e];
+        }
+      a = row16_sum(a);
+      c = row16_sum(c);
+      if (r == 0) {
+        redk[wave * NC + 16 * dt + 4 * q + e] = a;
+        redv[wave * NC + 16 * dt + 4 * q + e] = c;
+      }
+    }
+  if (wave < 2 * NDT) {
+    const int qb2 = wave / NDT, dt = wave - qb2 * NDT;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = row16_sum(qsum[e]);
+      if (r == 0) redq[qb2 * NC + 16 * dt + 4 * q + e] = a;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * NC) {
+    const int which = threadIdx.x / NC, c = threadIdx.x - which * NC;
+    if (c < dh) {
+      float s = 0.f;
+      if (which == 0) s = redq[c] + redq[NC + c];
+      else
+        for (int w = 0; w < 8; ++w) s += (which == 1 ? redk : redv)[w * NC + c];
+      atomicAdd(dbias + (long)which * D + h * dh + c, s);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: fused dQ / dK / dV
 // One workgroup = one (batch, head), Tn <= 256, bf16; 8 waves, wave w owns keys [32w, 32w + 32) exactly like the dK/dV pass above
 // (its K / V fragments and dK / dV accumulators stay in registers while it walks the resident Q / dO tiles).  What the two-pass
@@ -639,7 +697,7 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
                                                              const T* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta, T* __restrict__ dqkv,
                                                              const int* __restrict__ key_len, int B, int Tn, int H, int dh,
-                                                             float scale, float scale_log2e, DropCfg drop) {
+                                                             float scale, float scale_log2e, DropCfg drop, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int RS = AT<T>::RS;
   constexpr int PAIR = 2 * 64 * RS + 512;  // Q tile | dO tile | 64 x LSE | 64 x delta
@@ -708,6 +766,7 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
   __syncthreads();
 
   const int nstep = (Tn + 31) / 32;  // 32-query steps
+  f32x4 qsum = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of this wave's dQ tiles (q bias gradient)
   const int qq = r >> 2, pp = r & 3;
   for (int st = 0; st < nstep; ++st) {
     const int m2 = st & 1;
@@ -768,7 +827,10 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
       if (query < Tn && d < dh) {
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc0[e] + acc1[e];
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc0[e] + acc1[e];
+          qsum[e] += v[e];
+        }
         st4(dqkv + ((long)b * Tn + query) * ld + h * dh + d, v);
       }
     }
@@ -790,6 +852,10 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
         st4(dqkv + ((long)b * Tn + key) * ld + 2 * D + h * dh + d, v);
       }
     }
+  }
+  if (dbias) {   // (uniform) -- the Q / dO tiles at the head of LDS are dead behind the loop's last barrier
+    const bool kvalid[2] = {k0 + r < Tn, k0 + 16 + r < Tn};
+    qkv_bias_sums<NDT>(reinterpret_cast<float*>(lds), dbias, dk, dv, kvalid, qsum, h, dh, D);
   }
 }
 
@@ -850,7 +916,8 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_stream_kernel(const T* __r
                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
                                                                     T* __restrict__ dqkv, float* __restrict__ dq_part,
                                                                     const int* __restrict__ key_len, int B, int Tn, int H, int dh,
-                                                                    int kpb, float scale, float scale_log2e, DropCfg drop) {
+                                                                    int kpb, float scale, float scale_log2e, DropCfg drop,
+                                                                    float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int RS = AT<T>::RS;
   constexpr int PAIR = 2 * 64 * RS + 512;  // Q tile | dO tile | 64 x LSE | 64 x delta
@@ -942,6 +1009,7 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_stream_kernel(const T* __r
   };
   fetch(0);
   const int qq = r >> 2, pp = r & 3;
+  f32x4 qsum = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of this wave's dQ tiles (q bias gradient)
   for (int tile = 0; tile < ntile; ++tile) {
     unsigned char* sb = lds + (tile & 1) * PAIR;
     // the buffer's readers (the score steps of tile - 2) finished before the barriers this wave has passed since
@@ -1010,7 +1078,10 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_stream_kernel(const T* __r
         if (query < Tn && d < dh) {
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc0[e] + acc1[e];
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc0[e] + acc1[e];
+            qsum[e] += v[e];
+          }
           if (nkb == 1) st4(dqkv + ((long)b * Tn + query) * ld + h * dh + d, v);
           else st4(dq_part + (((long)kb * B + b) * Tn + query) * D + h * dh + d, v);
         }
@@ -1034,6 +1105,10 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_stream_kernel(const T* __r
         st4(dqkv + ((long)b * Tn + key) * ld + 2 * D + h * dh + d, v);
       }
     }
+  }
+  if (dbias) {   // (uniform) -- both Q / dO buffers are dead behind the loop's last barrier
+    const bool kvalid[2] = {k0 + r < kend, k0 + 16 + r < kend};
+    qkv_bias_sums<NDT>(reinterpret_cast<float*>(lds), dbias, dk, dv, kvalid, qsum, h, dh, D);
   }
 }
 
@@ -1092,16 +1167,16 @@ int bwd_launch_t(const T* qkv, const T* out, const T* dout, const float* lse, fl
 }
 template <typename T, int NDT>
 int bwd_fused_launch(const T* qkv, const T* out, const T* dout, const float* lse, float* delta, T* dqkv,
-                     const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
+                     const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st, float* dbias) {
   const size_t smem = 4 * (2 * 64 * AT<bf16>::RS + 512) + 256 * AT<bf16>::RS + 2 * 256 * FUSED_SRS;
   if (drop.p > 0.f) {
     set_lds(attn_bwd_fused_kernel<T, NDT, true>, smem);
     hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, true>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
-                       B, Tn, H, dh, scale, sl2, drop);
+                       B, Tn, H, dh, scale, sl2, drop, dbias);
   } else {
     set_lds(attn_bwd_fused_kernel<T, NDT, false>, smem);
     hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, false>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
-                       B, Tn, H, dh, scale, sl2, drop);
+                       B, Tn, H, dh, scale, sl2, drop, dbias);
   }
   FH_CHECK_LAUNCH();
   return 0;
@@ -1110,7 +1185,8 @@ int bwd_fused_launch(const T* qkv, const T* out, const T* dout, const float* lse
 int fused_stream_blocks(int Tn) { return (Tn + 255) / 256; }
 template <typename T, int NDT>
 int bwd_fused_stream_launch(const T* qkv, const T* out, const T* dout, const float* lse, float* delta, T* dqkv, float* dq_part,
-                            const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st) {
+                            const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st,
+                            float* dbias) {
   const int nkb = fused_stream_blocks(Tn);
   const int kpb = (((Tn + nkb - 1) / nkb) + 31) / 32 * 32;
   const size_t smem = 2 * (2 * 64 * AT<T>::RS + 512) + 256 * AT<T>::RS + 2 * 256 * FUSED_SRS;
@@ -1120,11 +1196,11 @@ int bwd_fused_stream_launch(const T* qkv, const T* out, const T* dout, const flo
   if (drop.p > 0.f) {
     set_lds(attn_bwd_fused_stream_kernel<T, NDT, true>, smem);
     hipLaunchKernelGGL((attn_bwd_fused_stream_kernel<T, NDT, true>), dim3(nkb, H, B), dim3(512), smem, st, qkv, dout, lse, delta, dqkv, dq_part,
-                       key_len, B, Tn, H, dh, kpb, scale, sl2, drop);
+                       key_len, B, Tn, H, dh, kpb, scale, sl2, drop, dbias);
   } else {
     set_lds(attn_bwd_fused_stream_kernel<T, NDT, false>, smem);
     hipLaunchKernelGGL((attn_bwd_fused_stream_kernel<T, NDT, false>), dim3(nkb, H, B), dim3(512), smem, st, qkv, dout, lse, delta, dqkv, dq_part,
-                       key_len, B, Tn, H, dh, kpb, scale, sl2, drop);
+                       key_len, B, Tn, H, dh, kpb, scale, sl2, drop, dbias);
   }
   FH_CHECK_LAUNCH();
   if (nkb > 1) {
@@ -1189,17 +1265,19 @@ int fwd16(const void* qkv, void* out, float* lse, const int* key_len, int B, int
 }
 template <typename T>
 int bwd16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, const int* key_len, int B, int Tn,
-          int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st, float* dq_scratch) {
+          int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st, float* dq_scratch, float* dbias, bool* bias_done) {
   const int res = resident_tiles<T>(Tn);
   const int nw = wide_waves(res, Tn, 8);  // the 16-wave backward builds spill under the 128-VGPR cap
   const T *q = (const T*)qkv, *o = (const T*)out, *d = (const T*)dout;
   if (res && Tn <= 256 && Tn > 64 && fused_bwd_enabled()) {
-    if (dh > 48) return bwd_fused_launch<T, 4>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
-    return bwd_fused_launch<T, 3>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+    *bias_done = dbias != nullptr;
+    if (dh > 48) return bwd_fused_launch<T, 4>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dbias);
+    return bwd_fused_launch<T, 3>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dbias);
   }
   if (Tn > 256 && dq_scratch && (H * dh) % 8 == 0 && fused_bwd_enabled()) {   // longer utterances: the streamed fused form
-    if (dh > 48) return bwd_fused_stream_launch<T, 4>(q, o, d, lse, delta, (T*)dqkv, dq_scratch, key_len, B, Tn, H, dh, scale, sl2, drop, st);
-    return bwd_fused_stream_launch<T, 3>(q, o, d, lse, delta, (T*)dqkv, dq_scratch, key_len, B, Tn, H, dh, scale, sl2, drop, st);
+    *bias_done = dbias != nullptr;
+    if (dh > 48) return bwd_fused_stream_launch<T, 4>(q, o, d, lse, delta, (T*)dqkv, dq_scratch, key_len, B, Tn, H, dh, scale, sl2, drop, st, dbias);
+    return bwd_fused_stream_launch<T, 3>(q, o, d, lse, delta, (T*)dqkv, dq_scratch, key_len, B, Tn, H, dh, scale, sl2, drop, st, dbias);
   }
   if (dh > 48) {
     if (nw == 8) return bwd_launch_t<T, 4, 8>(q, o, d, lse, delta, (T*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
@@ -1229,15 +1307,22 @@ long fh_attention_bwd_scratch_floats(int dtype, int B, int Tn, int H, int dh) {
 }
 int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                             float* delta, void* dqkv, const int* key_len, int B, int Tn, int H, int dh, float scale,
-                            fh_drop drop, hipStream_t st, float* dq_scratch) {
+                            fh_drop drop, hipStream_t st, float* dq_scratch, float* dbias) {
   if (int rc = check_dims(dtype, H, dh, 64)) return rc;
   const float sl2 = scale * 1.4426950408889634f;
+  bool bias_done = false;
+  int rc;
   if (dtype == 0) {
     const int res = resident_tiles<float>(Tn);
     if (dh > 48)
-      return bwd_launch_t<float, 4, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
-    return bwd_launch_t<float, 3, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+      rc = bwd_launch_t<float, 4, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+    else
+      rc = bwd_launch_t<float, 3, 4>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, res, st);
+  } else {
+    rc = dtype == 2 ? bwd16<f16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dq_scratch, dbias, &bias_done)
+                    : bwd16<bf16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dq_scratch, dbias, &bias_done);
   }
-  return dtype == 2 ? bwd16<f16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dq_scratch)
-                    : bwd16<bf16>(qkv, out, dout, lse, delta, dqkv, key_len, B, Tn, H, dh, scale, sl2, drop, st, dq_scratch);
+  // dbias [3 H dh] += column sums of dqkv: out of the fused kernels' accumulators, else by a pass over the stored gradient
+  if (!rc && dbias && !bias_done) rc = fh_colsum_launch(dtype, dqkv, dbias, B * Tn, 3 * H * dh, 3L * H * dh, 1, 0, 0, 0, 1.f, st);
+  return rc;
 }

@@ -94,6 +94,11 @@ int fh_attention_backward_ws(int dtype, const void* qkv, const void* out, const 
                              fh_stream_t stream) {
   return fh_attention_bwd_launch(dtype, qkv, out, dout, lse, delta, dqkv, key_len, B, T, H, dh, scale, drop, ST(stream), scratch);
 }
+int fh_attention_backward_bias(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                               void* dqkv, float* dbias, const int* key_len, int B, int T, int H, int dh, float scale, fh_drop drop,
+                               float* scratch, fh_stream_t stream) {
+  return fh_attention_bwd_launch(dtype, qkv, out, dout, lse, delta, dqkv, key_len, B, T, H, dh, scale, drop, ST(stream), scratch, dbias);
+}
 
 int fh_kd_loss(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred, const float* layer_w,
                const int* teacher_layer, float* partials, double* out_losses, int L, int B, int Tp, int Tt, int P,

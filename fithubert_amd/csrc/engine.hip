@@ -1209,7 +1209,10 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     A = fh_operand(x.at(p.xo, (long)s.slot_in(l0) * Ms * D), FH_R_STRIDED, D);  // layer inputs = consecutive slots
     A.gstride = Ms * D;
     RC(wgrad(x, x.at(p.dqkv, (long)l0 * Ms * 3 * D), 3 * D, A, grads + lo + p.pl.l_qkv_w, 3 * D, D, M2, nl, Ms * 3 * D, ls, 0, 0, 0, 0, 0, 0, -1, ws_));
-    RC(fh_colsum_launch(dt, x.at(p.dqkv, (long)l0 * Ms * 3 * D), grads + lo + p.pl.l_qkv_b, (int)M2, 3 * D, 3 * D, nl, Ms * 3 * D, ls, 0, 1.f, ws_));
+    // (the q|k|v bias gradients come with the attention backward; only a last layer that took transfer gradients into dqkv is summed here)
+    if (d_qkv_last && l0 + nl == L)
+      RC(fh_colsum_launch(dt, x.at(p.dqkv, (long)(L - 1) * Ms * 3 * D), grads + p.pl.layer0 + (long)(L - 1) * ls + p.pl.l_qkv_b, (int)M2, 3 * D,
+                          3 * D, 1, 0, 0, 0, 1.f, ws_));
     return 0;
   };
   // ---------------- time-reduction conv backward: gradient w.r.t. its output (reduced frames) -> dx1tr (T' frames; the frames past
@@ -1299,7 +1302,10 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
     RC(fh_attention_bwd_launch(dt, x.at(p.qkv, (long)l * Ms * 3 * D), x.at(p.attn, (long)l * Ms * D), x.W(p.da),
                                x.W<float>(p.lse) + (long)l * B * H * s.Ts, x.W<float>(p.delta),
                                x.at(p.dqkv, (long)l * Ms * 3 * D), len_l, B, Tl, H, D / H, scale,
-                               x.drop(c.attention_dropout, site + 0), x.st, p.attn_scr >= 0 ? x.W<float>(p.attn_scr) : nullptr));
+                               x.drop(c.attention_dropout, site + 0), x.st, p.attn_scr >= 0 ? x.W<float>(p.attn_scr) : nullptr,
+                               // the q|k|v bias gradient = column sums of dqkv, out of the fused kernels' accumulators -- except where the
+                               // transfer gradients below still join dqkv (layer_wgrads sums that layer's stored gradient)
+                               (l == L - 1 && d_qkv_last) ? nullptr : lg + p.pl.l_qkv_b));
     if (l == L - 1 && d_qkv_last)  // attention-logit / value-relation transfer gradients enter at the last layer's q|k|v
       RC(fh_unary_launch(dt, d_qkv_last, x.at(p.dqkv, (long)l * Ms * 3 * D), M2 * 3 * D, 1, x.st));
     {  // dxin = dqkv . Wqkv + ds1

@@ -56,7 +56,9 @@ int fh_attention_fwd_launch(int dtype, const void* qkv, void* out, float* lse, c
 long fh_attention_bwd_scratch_floats(int dtype, int B, int Tn, int H, int dh);
 int fh_attention_bwd_launch(int dtype, const void* qkv, const void* out, const void* dout, const float* lse,
                             float* delta, void* dqkv, const int* key_len, int B, int Tn, int H, int dh, float scale,
-                            fh_drop drop, hipStream_t st, float* dq_scratch = nullptr);
+                            fh_drop drop, hipStream_t st, float* dq_scratch = nullptr, float* dbias = nullptr);
+// dbias (optional): [3 H dh] fp32, += the column sums of dqkv = the gradient of the q | k | v projection bias (out of the fused kernels'
+// accumulators in the 16-bit modes; a pass over dqkv otherwise)
 
 // ---- loss.hip : layer-wise KD loss (MSE / L1) fused with its gradient
 int fh_kd_loss_launch(int dtype, int teacher_dtype, const void* pred, const void* teacher, void* dpred,

@@ -251,6 +251,13 @@ long fh_attention_backward_scratch_floats(int dtype, int B, int T, int H, int dh
 int fh_attention_backward_ws(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                              void* dqkv, const int* key_len, int B, int T, int H, int dh, float scale, fh_drop drop, float* scratch,
                              fh_stream_t stream);
+/* ... and the gradient of the q | k | v projection bias (modules/module.py:558-564: fairseq's in-projection biases) with it:
+ * dbias [3 * H * dh] fp32 += column sums of dqkv over the B * T rows.  The 16-bit fused kernels take them from their fp32 dQ / dK / dV
+ * accumulators (no pass over the stored gradient); the other paths add a column-sum pass.  dbias must hold the running sum (zeros for
+ * a fresh gradient); the order of the atomic adds is not fixed. */
+int fh_attention_backward_bias(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                               void* dqkv, float* dbias, const int* key_len, int B, int T, int H, int dh, float scale, fh_drop drop,
+                               float* scratch, fh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layer-wise KD loss + gradient (train.py:250-293,372-378):  out[l] = mean_{b,t,d} f(pred_l - teacher_{tl[l]}),

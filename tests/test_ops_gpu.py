@@ -288,6 +288,49 @@ def test_attention_fwd_bwd(dt, ws, B, T, masked, dh):
         assert _rel(dqkv[..., sl], qr.grad[..., sl]) < tol, name
 
 
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16, L.DT_F16])
+@pytest.mark.parametrize("dh", [40, 64])
+@pytest.mark.parametrize("B,T,masked", [(3, 249, True),    # the fused backward (fithubert.yaml at 10 s)
+                                        (2, 64, False),    # too short for it: two passes + a column-sum pass
+                                        (3, 349, True),    # two key blocks of the streamed fused form: dQ is a sum over workgroups
+                                        (2, 613, True)])   # three
+def test_attention_backward_bias_gradient_is_the_column_sum_of_dqkv(dt, B, T, masked, dh):
+    """fh_attention_backward_bias: dbias += column sums of dqkv = the gradient of fairseq's q | k | v in-projection biases
+    (modules/module.py:558-564).  The 16-bit fused kernels sum their fp32 accumulators, so the comparison is against autograd's bias
+    gradient; the running-sum contract is checked by starting from a non-zero buffer."""
+    torch.manual_seed(B * 11 + T)
+    H = 12
+    D = H * dh
+    lib = L.lib()
+    x = (torch.randn(B, T, 3 * D, device=DEV) * 1.2)
+    bias = (torch.randn(3 * D, device=DEV) * 0.3).double().requires_grad_(True)
+    qkv64 = x.double() + bias
+    qkv = qkv64.detach().to(_tdt(dt)).contiguous()
+    key_len = torch.tensor([T, max(1, T * 3 // 4), max(1, T // 2)][:B], device=DEV, dtype=torch.int32) if masked else None
+    out = torch.empty(B, T, D, device=DEV, dtype=_tdt(dt))
+    lse = torch.empty(B, H, T, device=DEV)
+    L.check(lib.fh_attention_forward(dt, _p(qkv), _p(out), _p(lse), _p(key_len), B, T, H, dh, dh ** -0.5, L.drop(), _st()), "attn")
+    ref, _ = _attn_ref(qkv.double() + (bias - bias.detach()), H, dh, key_len)   # (value of the rounded qkv, gradient flows to the bias)
+    dout = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+    ref.backward(dout.double())
+    n = lib.fh_attention_backward_scratch_floats(dt, B, T, H, dh)
+    scratch = torch.empty(max(n, 1), device=DEV) if n > 0 else None
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(B, H, T, device=DEV)
+    start = torch.randn(3 * D, device=DEV)
+    dbias = start.clone()
+    L.check(lib.fh_attention_backward_bias(dt, _p(qkv), _p(ref.detach().to(_tdt(dt)).contiguous()), _p(dout), _p(lse), _p(delta), _p(dqkv),
+                                           _p(dbias), _p(key_len), B, T, H, dh, dh ** -0.5, L.drop(), _p(scratch), _st()), "attn bwd + bias")
+    got = (dbias - start).double()
+    want = bias.grad
+    # per third: the k bias gradient is zero in exact arithmetic (softmax is shift invariant), so it is compared on the scale of the others
+    scale = want.abs().max().item()
+    tol = {L.DT_F32: 2e-4, L.DT_BF16: 2e-2, L.DT_F16: 4e-3}[dt]
+    assert (got - want).abs().max().item() < tol * scale, (got - want).abs().max().item() / scale
+    # and it is the column sum of the gradient the call stored (up to that tensor's rounding)
+    assert (got - dqkv.double().sum(dim=(0, 1))).abs().max().item() < 3 * tol * scale
+
+
 @pytest.mark.parametrize("B,T,masked", [(2, 499, True), (1, 96, False), (2, 200, True), (2, 699, True), (2, 1226, True)])
 def test_attention_forward_64_wide_heads(B, T, masked):
     """bf16 forward-only build for the frozen teacher's 64-wide heads (HuBERT Base / Large)."""
