@@ -186,9 +186,12 @@ def _posconv_ref(x, g, v, bias, groups, K):
     return zc, x + F.gelu(zc)
 
 
-@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16, L.DT_F16])
 @pytest.mark.parametrize("D", [480, 768])  # 30 channels per group (fithubert.yaml) / 48 (ex.yaml): padded to 32 / 64
-@pytest.mark.parametrize("B,T", [(2, 99), (1, 499), (3, 19)])
+@pytest.mark.parametrize("B,T", [(2, 99), (1, 499), (3, 19),
+                                 # the 16-bit 32-channel kernels switch from 256 to 512 output frames per workgroup past T = 256: both sides of
+                                 # that switch, a full 512-frame block and one frame more (a second, almost empty block)
+                                 (2, 256), (1, 257), (1, 512), (2, 513)])
 def test_posconv_fwd_bwd(dt, B, T, D):
     torch.manual_seed(B * 1000 + T)
     G, K = 16, 128
@@ -232,6 +235,29 @@ def test_posconv_fwd_bwd(dt, B, T, D):
     L.check(lib.fh_posconv_weightnorm_backward(_p(g), _p(v), _p(norm), _p(dws), _p(dg), _p(dv), D, G, K, _st()), "wn bwd")
     assert _rel(dv, vr.grad) < _tol(dt) * 3
     assert _rel(dg, gr.grad) < _tol(dt) * 3
+
+
+@pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16, L.DT_F16])
+@pytest.mark.parametrize("B,T", [(2, 99), (1, 499), (2, 256), (1, 257), (3, 19)])
+def test_posconv_wide_forward_48_channel_groups(dt, B, T):
+    """The frozen teacher's positional conv (utils/utils.py:84-88 loads fairseq's HuBERT: Conv1d(768, 768, 128, groups=16) under weight
+    norm, GELU, residual): fh_posconv_wide_forward.  The 16-bit modes run the flattened tap-pair kernel in Toeplitz order."""
+    torch.manual_seed(B * 100 + T)
+    D, G, K = 768, 16, 128
+    cg = D // G
+    lib = L.lib()
+    x = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+    g = 0.5 + torch.rand(1, 1, K, device=DEV)
+    v = torch.randn(D, cg, K, device=DEV) * (4.0 / (K * D)) ** 0.5 * 3
+    bias = 0.1 * torch.randn(D, device=DEV)
+    w = torch.empty(G * K * 64 * 64, device=DEV, dtype=_tdt(dt))
+    norm2 = torch.empty(K, device=DEV)
+    L.check(lib.fh_posconv_wide_prepare(dt, _p(g), _p(v), _p(w), _p(norm2), D, G, K, _st()), "prep")
+    y = torch.full_like(x, float("nan"))
+    L.check(lib.fh_posconv_wide_forward(dt, _p(x), _p(w), _p(bias), _p(y), B, T, D, G, K, _st()), "fwd")
+    _, y_ref = _posconv_ref(x.double(), g.double(), v.double(), bias.double(), G, K)
+    assert not torch.isnan(y.float()).any()
+    assert _rel(y, y_ref) < _tol(dt)
 
 
 # ------------------------------------------------------------------------------------------ attention
