@@ -81,3 +81,20 @@ def test_gemm_kernels_keep_their_accumulators_in_registers():
         sc = _kernel_scratch_bytes(obj) or {}
         bad = {k: v for k, v in sc.items() if v > 160}
         assert not bad, (os.path.basename(obj), bad)
+
+
+def test_positional_conv_tap_loops_own_no_scratch():
+    """The 16-bit positional-conv kernels request their weight fragments through inline asm and wait for them with COUNTED
+    `s_waitcnt vmcnt(n)` (csrc/posconv_taps.cuh): a spill slot is a vector-memory access the counts do not know about, i.e. a
+    fragment would be multiplied before it has landed -- wrong results without any error.  No scratch at all in those kernels."""
+    import pytest
+    found = 0
+    for unit, pat in (("posconv.hip.o", r"posconv_kernelIDF16[b_]Li32E"), ("posconv_wide.hip.o", r"posconv_wide48_kernelIDF16[b_]Li4ELb1E")):
+        sc = _kernel_scratch_bytes(os.path.join(ROOT, "fithubert_amd", "csrc", "_obj", unit))
+        if sc is None:
+            pytest.skip("no built object file / LLVM tools")
+        hot = {k: v for k, v in sc.items() if re.search(pat, k)}
+        assert hot, (unit, sorted(sc))
+        assert max(hot.values()) == 0, (unit, hot)
+        found += len(hot)
+    assert found >= 10   # forward / data gradient x bf16 / half x 4 / 8 tiles per wave, the teacher's kernel x 2 types
