@@ -39,6 +39,10 @@ __device__ __forceinline__ void toeplitz_taps(int ncls, XOf&& xof, WOf&& wof, lo
                                               f32x4 (&acc)[CB][NT]) {
   const uint32_t voff = lane * 16;
   bf16x8 W[NI][CB];
+  // Compiler fences at both ends of the tap loop: a vector-memory access the compiler moved in between the requests and their waits
+  // (an epilogue load hoisted above the loop) would be younger than a request without being counted.  Inside, the only memory
+  // accesses are the LDS fragment reads (lgkmcnt) and the asm requests.
+  asm volatile("" ::: "memory");
   {
     const T* w0 = wof(0);
 #pragma unroll
@@ -76,6 +80,7 @@ __device__ __forceinline__ void toeplitz_taps(int ncls, XOf&& xof, WOf&& wof, lo
   };
   for (int c = 0; c + 1 < ncls; ++c) tap_class(std::true_type{}, xof(c), wof(c + 1));
   tap_class(std::false_type{}, xof(ncls - 1), (const T*)nullptr);
+  asm volatile("" ::: "memory");
 }
 
 }  // namespace
