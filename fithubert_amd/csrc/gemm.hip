@@ -194,7 +194,10 @@ int launch_16(const GemmParams& p, int dtype, hipStream_t stream) {
   if (it == g_tune.end()) {
     if (!g_tune_mode) {
       const TuneChoice* nb = tune_neighbour(p, dtype, stream_mask(stream));
-      if (!nb) return launch_path(p, 2, dtype, stream);
+      // no measurement for this class or a neighbouring one (a caller that never switched the tuner on): launches with many rows
+      // take the 256-tile 8-phase loops -- streaming where the epilogue allows it (launch_path_h falls back from 8 to 7 to the
+      // 128-tile loop by itself); at M = 63,744, N = K = 480 they run 40 us against the 128-tile loop's 59 -- the rest loop 2
+      if (!nb) return launch_path(p, (!p.ep.atomic && p.M >= 4096 && p.N >= 128) ? 8 : 2, dtype, stream);
       TuneChoice c = *nb;
       if (p.ep.atomic) {   // a split count measured on a longer reduction: keep every split at least 512 deep, as the candidates are
         const long red = (long)p.Kseg * p.X.nseg;

@@ -670,7 +670,7 @@ def test_untuned_shape_class_takes_the_nearest_measured_one(tmp_path):
         return lib.fh_gemm_last_loop()
 
     try:
-        assert fwd(64 * 768, tune=False) == 2                 # empty table: the fallback loop
+        assert fwd(64 * 768, tune=False) in (7, 8)            # empty table: many rows -> the 256-tile 8-phase loops (streaming: no operand here)
         lib.fh_gemm_tune(-1)
         tuned = fwd(64 * 731, tune=True)
         assert tuned != 2
