@@ -2139,7 +2139,7 @@ __device__ __forceinline__ void glds4(const float* gsrc, unsigned dst) {  // 64 
 __device__ __forceinline__ void wait_vm_upto(int n) {
   switch (__builtin_amdgcn_readfirstlane(n)) {
 #define FH_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    FH_W(6) FH_W(8) FH_W(14) FH_W(16) FH_W(22) FH_W(24)
+    FH_W(6) FH_W(8) FH_W(14) FH_W(16) FH_W(17) FH_W(22) FH_W(24)
 #undef FH_W
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
@@ -2149,9 +2149,26 @@ __device__ __forceinline__ void wait_vm_upto(int n) {
 // the wave's 64 columns lie beyond N, 2 -- 4 with a pre-activation copy -- per m-tile for a block whose rows are all inside M:
 // every instruction then has an active lane), -1 for a block cut by M (rows past M are masked out, and an instruction without
 // active lanes may be branched over).
-template <typename H, int M0, int M1, bool PRE, bool GELU, bool DROP, bool BOTH, typename AccT>
+// OP = 1 (the conv data gradients): the product is multiplied by a per-element operand (the saved GELU', ep.gelu_aux with ep.aux_factor)
+// that stream_opnd_issue() brought into the dead tile buffers by LDS-DMA -- read here in the ACCUMULATOR layout, so the output is rounded
+// once as in the other loops --, and the output rows follow the batch wrap of an odd frame count (c_rpb / c_bstride, ep.tail_cols).
+struct StreamOpnd {
+  const unsigned char* opl;  // this wave's operand pieces of the half being written: [m-tile][row half][64 lanes x 16 B]
+  long off0;                 // element offset of (group, batch entry of the wave's first row, row 0, column 0) in C / the operand
+  long wrap;                 // c_bstride - c_rpb * ldc: added once a row index runs past the batch entry
+  int t0, rpb, tail;         // the wave's first row inside its batch entry; rows per entry (0: no wrap); valid columns of an entry's last row (0: all)
+};
+// global element offset and store predicate of local row d (0 .. 127) of the wave's block, column jr
+__device__ __forceinline__ long stream_row_off(const StreamOpnd& o, int d, long ldc, int jr, bool& keep) {
+  const int t = o.t0 + d;
+  const bool crossed = o.rpb > 0 && t >= o.rpb;
+  const int tt = crossed ? t - o.rpb : t;
+  keep = !(o.tail > 0 && tt == o.rpb - 1 && jr >= o.tail);
+  return o.off0 + (long)t * ldc + (crossed ? o.wrap : 0L) + jr;
+}
+template <typename H, int M0, int M1, bool PRE, bool GELU, bool DROP, bool BOTH, int OP = 0, typename AccT>
 __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const AccT& acc, const float (&b4)[4][4], unsigned char* my, int i0,
-                                                   int j0, int xi0, int yj0, int lane, int g) {
+                                                   int j0, int xi0, int yj0, int lane, int g, const StreamOpnd* so = nullptr) {
   const GemmEpilogue& ep = p.ep;
   const int r = lane & 15, q = lane >> 4;
   const int jr = j0 + yj0 + 8 * (lane & 7);
@@ -2164,13 +2181,31 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
 #pragma unroll
   for (int m = M0; m < M1; ++m) {
     const int row = i0 + xi0 + 16 * m + (lane >> 3);
-    const long base = (long)g * p.c_gstride + (long)row * p.ldc + jr;
-    const bool sv0 = jrv && (full || row < p.M), sv1 = jrv && (full || row + 8 < p.M);
+    long base = (long)g * p.c_gstride + (long)row * p.ldc + jr, base1 = base + rstep;
+    bool sv0 = jrv && (full || row < p.M), sv1 = jrv && (full || row + 8 < p.M);
+    if constexpr (OP != 0) {
+      bool k0, k1;
+      base = stream_row_off(*so, 16 * m + (lane >> 3), p.ldc, jr, k0);
+      base1 = stream_row_off(*so, 16 * m + (lane >> 3) + 8, p.ldc, jr, k1);
+      sv0 = sv0 && k0;
+      sv1 = sv1 && k1;
+    }
     float v[4][4];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[n][e] = fmaf(acc[n][m][e], ep.alpha, b4[n][e]);
+    if constexpr (OP != 0) {
+      // operand of (row 16 m + r, columns 16 n + 4 q ..): piece (m, r >> 3), slot (r & 7) * 8 + (chunk ^ (r & 7)), half q & 1
+      const unsigned char* ob = so->opl + ((m - M0) * 2 + (r >> 3)) * 1024 + (r & 7) * 128 + (q & 1) * 8;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float x[4];
+        ld4(reinterpret_cast<const H*>(ob + (((2 * n + (q >> 1)) ^ (r & 7)) << 4)), x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[n][e] *= x[e];
+      }
+    }
     if (PRE) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
@@ -2187,7 +2222,7 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
       }
       const V16 t0 = ld16(lp), t1 = ld16(lp + 8 * EPB_ROW);
       if (sv0) st16(reinterpret_cast<bf16*>(ep.preact) + base, t0);
-      if (sv1) st16(reinterpret_cast<bf16*>(ep.preact) + base + rstep, t1);
+      if (sv1) st16(reinterpret_cast<bf16*>(ep.preact) + base1, t1);
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -2207,14 +2242,15 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
     }
     const V16 t0 = ld16(lp), t1 = ld16(lp + 8 * EPB_ROW);
     if (sv0) st16(reinterpret_cast<bf16*>(p.C) + base, t0);
-    if (sv1) st16(reinterpret_cast<bf16*>(p.C) + base + rstep, t1);
+    if (sv1) st16(reinterpret_cast<bf16*>(p.C) + base1, t1);
   }
   return full ? (M1 - M0) * (PRE ? 4 : 2) : -1;
 }
 // the option tests hoisted out of the unrolled passes: each instance is straight-line code the scheduler can overlap across passes
-template <typename H, int M0, int M1, typename AccT>
+template <typename H, int M0, int M1, int OP = 0, typename AccT>
 __device__ __forceinline__ int epilogue_stream16(const GemmParams& p, const AccT& acc, const float (&b4)[4][4], unsigned char* my, int i0,
-                                                 int j0, int xi0, int yj0, int lane, int g) {
+                                                 int j0, int xi0, int yj0, int lane, int g, const StreamOpnd* so = nullptr) {
+  if constexpr (OP != 0) return epilogue_stream16_t<H, M0, M1, false, false, false, false, OP>(p, acc, b4, my, i0, j0, xi0, yj0, lane, g, so);
   int opt = (p.ep.preact ? 4 : 0) | (p.ep.act == FH_ACT_GELU ? 2 : 0) | (p.ep.drop.p > 0.f ? 1 : 0);
   if ((opt & 6) == 6 && p.ep.aux_factor) opt |= 8;  // the saved tensor is GELU'(pre-activation)
   switch (__builtin_amdgcn_readfirstlane(opt)) {
@@ -2225,7 +2261,7 @@ __device__ __forceinline__ int epilogue_stream16(const GemmParams& p, const AccT
   }
 }
 
-template <typename H, int XL, int YL>
+template <typename H, int XL, int YL, int OP = 0>
 __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p, int tiles, int total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BK_ = 64, XT = 256 * 64 * 2, STAGE = 2 * XT;
@@ -2268,7 +2304,8 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
   };
   // tile f becomes the current tile: loaders set up, its bias row and its first two K-tiles issued (1 + 8 + 8 pieces at most,
   // oldest first; the quarters of a K-tile in the order the phases need them)
-  auto start_tile = [&](int f) {
+  // (OP: only K-tile 0 goes out between the epilogue halves -- the second half's operand pieces still sit in K-tile 1's buffer)
+  auto start_tile = [&](int f, int nk) {
     g = f / tiles;
     const int lb = xcd_remap(f - g * tiles, tiles);
     int ti, tj;
@@ -2288,8 +2325,18 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
     is_k0 = 0;
     issued = 0;
     need_slow = true;
-    for (int k = 0; k < (nt > 1 ? 2 : 1); ++k) {
+    for (int k = 0; k < (nt > 1 ? nk : 1); ++k) {
       const unsigned b = lds0 + k * STAGE;
+      advance();
+      lx.issue_half(b, 0);
+      ly.issue_half(b + XT, 0);
+      ly.issue_half(b + XT, 1);
+      lx.issue_half(b, 1);
+    }
+  };
+  auto issue_ktile1 = [&]() {   // (OP) K-tile 1 of the current tile, behind the second epilogue half
+    if (nt > 1) {
+      const unsigned b = lds0 + STAGE;
       advance();
       lx.issue_half(b, 0);
       ly.issue_half(b + XT, 0);
@@ -2300,7 +2347,8 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
 
   int f = blockIdx.x;
   if (f >= total) return;
-  start_tile(f);
+  start_tile(f, 2);
+  int young1 = 0;   // (OP) operations younger than K-tile 1's last piece: none, it is issued behind the stores
   int younger = 0;  // vector-memory operations this wave issued AFTER the last prefetch piece (stores of the previous tile's second half); < 0: drain
   f32x4 acc[4][8];  // [n][m]
   bf16x8 fa[2][4], fb[2][2];
@@ -2346,7 +2394,7 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
         FH_REFILL_GUARD(RB - 1)
         lx.issue_half(lds0, 1);
       }
-      wait_vm_upto(younger < 0 ? 0 : younger + (more ? 6 : 0));
+      wait_vm_upto(younger < 0 ? 0 : (OP != 0 ? young1 : younger) + (more ? 6 : 0));
       FH_PHASE_TAIL("")
       FH_PHASE_MMA(1, 0)
     }
@@ -2412,13 +2460,62 @@ __global__ void __launch_bounds__(512) gemm_8ph_stream_kernel(const GemmParams p
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stash is rewritten by the next tile's bias piece
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (OP != 0) {
+      // The operand tile of this wave's 128 x 64 block comes into the dead tile buffers by LDS-DMA: 16 pieces (m-tile, row half) of
+      // 64 lanes x 16 B -- the first half's eight into stage 0, the second half's into stage 1, 8 KiB per wave each --, all of them
+      // OLDER than any store of the tile, so waiting for them never waits for a store acknowledgement.  Lane i fetches row i >> 3,
+      // column chunk (i & 7) ^ (i >> 3): the accumulator-layout reads of the epilogue then spread over the banks.
+      StreamOpnd so;
+      {
+        const RowMap rm = map_row(ci0 + xi0, p.c_rpb);
+        so.off0 = (long)cg * p.c_gstride + (long)rm.b * (p.c_rpb > 0 ? p.c_bstride : 0L);
+        so.wrap = p.c_rpb > 0 ? p.c_bstride - (long)p.c_rpb * p.ldc : 0L;
+        so.t0 = rm.t; so.rpb = p.c_rpb; so.tail = p.ep.tail_cols;
+      }
+      const bool live_wave = __builtin_amdgcn_readfirstlane(cj0 + yj0 < p.N && ci0 + xi0 < p.M);
+      if (live_wave) {
+        const int rho = lane >> 3, jr = cj0 + yj0 + 8 * ((lane & 7) ^ rho);
+        const H* aux = reinterpret_cast<const H*>(p.ep.gelu_aux);
+        const bool jv = jr < p.N;
+        const int mrows = p.M - (ci0 + xi0);          // rows of the block inside M (>= 1)
+        unsigned dst = lds0 + wave * 8192;
+#pragma unroll 1
+        for (int mh = 0; mh < 16; ++mh) {             // (rolled: sixteen unrolled 64-bit address chains cost the kernel its last registers)
+          const int d = 8 * mh + rho;                 // local row of piece mh = 2 m + half
+          bool keep;
+          const long off = stream_row_off(so, d, p.ldc, jr, keep);
+          const bool v = keep && jv && d < mrows;
+          glds16(v ? reinterpret_cast<const unsigned char*>(aux + off) : reinterpret_cast<const unsigned char*>(g_zero_chunk), dst);
+          dst += mh == 7 ? (unsigned)(STAGE - 7 * 1024) : 1024u;
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the first half's pieces
+      }
+      so.opl = lds + wave * 8192;
+      const int n1 = epilogue_stream16<H, 0, 4, OP>(p, acc, b4, my, ci0, cj0, xi0, yj0, lane, cg, &so);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has read its stage-0 pieces: K-tile 0 may land there
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) start_tile(fn, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // the second half's pieces are older than the first half's stores and the K-tile-0 pieces issued since
+      if (live_wave) wait_vm_upto(n1 < 0 ? 0 : n1 + (has_next ? 8 + (has_bias ? 1 : 0) : 0));
+      so.opl = lds + STAGE + wave * 8192;
+      const int n2 = epilogue_stream16<H, 4, 8, OP>(p, acc, b4, my, ci0, cj0, xi0, yj0, lane, cg, &so);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and its stage-1 pieces: K-tile 1 may land
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) issue_ktile1();
+      __builtin_amdgcn_sched_barrier(0);
+      // K-tile 0 is older than the second half's stores and K-tile 1's pieces; K-tile 1 is younger than every store (young1 = 0): the
+      // first iteration's counted wait for it also waits for those stores' acknowledgements
+      younger = (n1 < 0 || n2 < 0) ? -1 : n2;
+    } else {
     const int n1 = epilogue_stream16<H, 0, 4>(p, acc, b4, my, ci0, cj0, xi0, yj0, lane, cg);
     __builtin_amdgcn_sched_barrier(0);
-    if (has_next) start_tile(fn);
+    if (has_next) start_tile(fn, 2);
     __builtin_amdgcn_sched_barrier(0);
     const int n2 = epilogue_stream16<H, 4, 8>(p, acc, b4, my, ci0, cj0, xi0, yj0, lane, cg);
     __builtin_amdgcn_sched_barrier(0);
     younger = (n1 < 0 || n2 < 0) ? -1 : n2;
+    }
     if (!has_next) break;
     f = fn;
   }
@@ -2460,6 +2557,16 @@ template <typename H> int launch_8ph(const GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
+// ... and its operand instance (OP = 1): the conv data gradients -- product x saved GELU' (ep.gelu_aux with ep.aux_factor), nothing else in
+// the epilogue, both operands R_CONTIG; the output rows may wrap per batch entry (c_rpb / c_bstride) and an entry's last row may be
+// narrower (ep.tail_cols), in whole 16-byte chunks; a wave's 128 rows cross one entry boundary at most
+bool stream_opnd_ok(const GemmParams& p) {
+  static const bool on = [] { const char* e = getenv("FH_GEMM_STREAM_OPND"); return !e || e[0] != '0'; }();
+  const GemmEpilogue& e = p.ep;
+  return on && e.gelu_aux && e.aux_factor && !e.residual && !e.preact && e.act == FH_ACT_NONE && e.drop.p <= 0.f && !e.bias && !e.atomic && !e.row_len &&
+         !e.out_f32 && !e.kd_teacher && !e.c0_wpart && (p.splitk & 0xffff) <= 1 && p.X.layout == FH_R_CONTIG && p.Y.layout == FH_R_CONTIG &&
+         (p.c_rpb <= 0 || p.c_rpb >= 128) && p.N % 8 == 0 && e.tail_cols % 8 == 0 && p.ldc % 8 == 0 && (p.c_rpb <= 0 || p.c_bstride % 8 == 0);
+}
 // launches loop 8 can take: the bf16-staged epilogue without per-row operands, one reduction split
 bool stream_ok(const GemmParams& p) {
   // TIMING-ONLY debug switch (wrong results; compiled only with -DFH_DEBUG_BUILD): offer loop 8 to launches with a GELU' operand / row wrap / tail columns, ignoring them --
@@ -2468,6 +2575,7 @@ bool stream_ok(const GemmParams& p) {
   static const int force = [] { const char* e = getenv("FH_DEBUG_L8_FORCE"); return (e && e[0] == '1') ? 1 : 0; }();
   if (force) return !p.ep.atomic && !p.ep.out_f32 && !p.ep.kd_teacher && !p.ep.c0_wpart && !p.ep.residual && !p.ep.row_len && (p.splitk & 0xffff) <= 1;
 #endif
+  if (stream_opnd_ok(p)) return true;
   const long wrap0 = p.c_bstride - (long)p.c_rpb * p.ldc;
   return !p.ep.atomic && !p.ep.gelu_aux && !p.ep.residual && !p.ep.row_len && !p.ep.out_f32 && !p.ep.tail_cols && !p.ep.kd_teacher && !p.ep.c0_wpart &&
          (p.c_rpb <= 0 || wrap0 == 0) && (p.splitk & 0xffff) <= 1;
@@ -2498,6 +2606,16 @@ template <typename H> int launch_8ph_stream(const GemmParams& p, hipStream_t str
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) hipFuncSetAttribute((const void*)kerns[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
+  }
+  if (stream_opnd_ok(p)) {
+    static bool op_attr = false;
+    if (!op_attr) {
+      hipFuncSetAttribute((const void*)gemm_8ph_stream_kernel<H, FH_R_CONTIG, FH_R_CONTIG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      op_attr = true;
+    }
+    hipLaunchKernelGGL((gemm_8ph_stream_kernel<H, FH_R_CONTIG, FH_R_CONTIG, 1>), grid, block, smem, stream, p, tiles, (int)total);
+    FH_CHECK_LAUNCH();
+    return 0;
   }
   hipLaunchKernelGGL(kerns[p.X.layout == FH_R_STRIDED][p.Y.layout == FH_R_STRIDED], grid, block, smem, stream, p, tiles, (int)total);
   FH_CHECK_LAUNCH();

@@ -70,8 +70,9 @@ def test_gemm_kernels_keep_their_accumulators_in_registers():
         # re-read in the epilogue -- none inside the K loop; a moved accumulator block would be 528 bytes)
         bad = {k: v for k, v in big.items() if v > 160}
         assert not bad, (unit, bad)
-        hot = [v for k, v in big.items() if re.search(r"gemm_8ph_stream_kernelI\w+?Li0ELi0E", k)]
-        assert len(hot) >= 1 and max(hot) == 0, (unit, hot)  # the streaming forward loop: no scratch at all (a scratch access drains its counted vmcnt queue)
+        # both operands R_CONTIG: the plain instance (...Li0E) and the one with a per-element operand (...Li1E: the conv data gradients)
+        hot = [v for k, v in big.items() if re.search(r"gemm_8ph_stream_kernelIDF16[b_]Li0ELi0ELi[01]E", k)]
+        assert len(hot) == 2 and max(hot) == 0, (unit, hot)  # the streaming loops: no scratch at all (a scratch access is a vector-memory operation their counted vmcnt waits do not know)
         warm = [v for k, v in big.items() if re.search(r"gemm_8ph_kernelI\w+?Li0ELi0ELb0E", k)]   # (the KD-loss instance, ...Lb1E, parks up to 100 bytes)
         assert len(warm) >= 1 and max(warm) <= 32, (unit, warm)   # loop 7: a few slots outside the K loop at most (the IEEE-half build parks 24 bytes around its epilogue)
     # every other kernel of the library: a handful of spill slots at most (the 4-wave attention forward once carried 404 bytes
