@@ -620,6 +620,121 @@ def test_saved_gelu_derivative_forward_and_backward(loop):
     assert (dz.double() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("dt", [L.DT_BF16, L.DT_F16])
+@pytest.mark.parametrize("B,T,cin,cout", [(3, 999, 512, 512),    # 1,500 rows: a cut last row tile; every batch entry wraps (odd frame count)
+                                          (2, 1999, 256, 256),   # the student's width
+                                          (5, 499, 64, 128),     # 128 output columns: the upper two wave columns of a tile lie beyond N
+                                          (2, 1998, 256, 256),   # even frame count: no wrap, no tail columns
+                                          (300, 257, 64, 64)])   # 129 rows per entry: most 128-row blocks cross an entry boundary
+def test_conv_data_gradient_on_the_streaming_loop_with_its_operand(dt, B, T, cin, cout):
+    """The k = 3, s = 2 conv data gradient as engine.hip launches it (one product over two shifted reduction segments, output row =
+    frame pair, x saved GELU' as a per-element operand, batch entries of an odd frame count wrap and end in a half row): the streaming
+    loop's operand instance (gemm_8ph_stream_kernel<.., 1>) against torch's conv1d input gradient in fp64, and bit for bit against the
+    non-streaming 8-phase loop in bf16 (both round the product once)."""
+    torch.manual_seed(B + T)
+    dev, k, s = "cuda", 3, 2
+    lib = L.lib()
+    tdt = torch.float16 if dt == L.DT_F16 else torch.bfloat16
+    Tout = (T - k) // s + 1
+    w = (torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5).to(tdt)
+    wt = w.permute(2, 1, 0).contiguous().view(k * cin, cout)
+    dy = torch.randn(B, Tout, cout, device=dev).to(tdt)
+    aux = torch.randn(B, T, cin, device=dev).to(tdt)
+    n_even = Tout + 1 if 2 * Tout <= T - 1 else Tout
+    outs = {}
+    try:
+        for path in (7, 8):
+            dx = torch.full((B, T, cin), float("nan"), device=dev, dtype=tdt)
+            d = L.GemmDesc()
+            d.X = L.operand(dy.data_ptr(), 0, cout, rpb=n_even, bstride=Tout * cout, nseg=2, tshift=(0, -1), tvalid=Tout)
+            d.Y = L.operand(wt.data_ptr(), 0, cout, nseg=2, segoff=(0, 2 * cin * cout), seg1_limit=cin)
+            d.C = dx.data_ptr()
+            d.M, d.N, d.Kseg, d.groups, d.splitk = B * n_even, 2 * cin, cout, 1, 1
+            d.ldc, d.c_rpb, d.c_bstride = 2 * cin, n_even, T * cin
+            d.ep = L.epilogue(gelu_aux=aux.data_ptr(), tail_cols=cin if 2 * n_even > T else 0, aux_factor=1)
+            lib.fh_gemm_set_path(path)
+            _run(d, dt)
+            assert lib.fh_gemm_last_loop() == path
+            if 2 * n_even < T:
+                dx[:, 2 * n_even:] = 0       # (engine.hip zeroes the frames the conv never reached with fh_zero_rows)
+            outs[path] = dx
+    finally:
+        lib.fh_gemm_set_path(9)
+    ref = torch.nn.grad.conv1d_input((B, cin, T), w.double(), dy.double().transpose(1, 2), stride=s).transpose(1, 2) * aux.double()
+    assert not torch.isnan(outs[8].float()).any()
+    assert (outs[8].double() - ref).abs().max().item() <= {L.DT_BF16: 8e-3, L.DT_F16: 1.2e-3}[dt] * ref.abs().max().item()
+    if dt == L.DT_BF16 and T % 2 == 1:   # (with an even frame count loop 7 takes its 16-bit staged epilogue, which rounds twice)
+        assert torch.equal(outs[8].view(torch.int16), outs[7].view(torch.int16))
+
+
+def test_streaming_operand_instance_under_load():
+    """The operand instance orders three kinds of LDS-DMA traffic through the two tile buffers with counted vmcnt waits and two extra
+    barriers per tile (operand pieces -> K-tile 0 behind the first epilogue half -> K-tile 1 behind the second): 2,000 launches of a conv
+    data gradient with many tiles per workgroup beside a second stream that keeps the device busy (a conv-shaped product on loop 7 and a
+    streaming fill), every one compared on the device, bit for bit, with the result of the non-streaming 8-phase loop on a quiet device."""
+    dev, k, s = "cuda", 3, 2
+    torch.manual_seed(5)
+    lib = L.lib()
+    B, T, cin, cout = 24, 7999, 256, 256           # 96,000 rows = 375 row tiles x 2 column tiles: ~3 tiles per workgroup
+    Tout = (T - k) // s + 1
+    n_even = Tout + 1 if 2 * Tout <= T - 1 else Tout
+    w = (torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5).to(torch.bfloat16)
+    wt = w.permute(2, 1, 0).contiguous().view(k * cin, cout)
+    dy = torch.randn(B, Tout, cout, device=dev).to(torch.bfloat16)
+    aux = torch.randn(B, T, cin, device=dev).to(torch.bfloat16)
+
+    def desc(out):
+        d = L.GemmDesc()
+        d.X = L.operand(dy.data_ptr(), 0, cout, rpb=n_even, bstride=Tout * cout, nseg=2, tshift=(0, -1), tvalid=Tout)
+        d.Y = L.operand(wt.data_ptr(), 0, cout, nseg=2, segoff=(0, 2 * cin * cout), seg1_limit=cin)
+        d.C = out.data_ptr()
+        d.M, d.N, d.Kseg, d.groups, d.splitk = B * n_even, 2 * cin, cout, 1, 1
+        d.ldc, d.c_rpb, d.c_bstride = 2 * cin, n_even, T * cin
+        d.ep = L.epilogue(gelu_aux=aux.data_ptr(), tail_cols=cin if 2 * n_even > T else 0, aux_factor=1)
+        return d
+
+    Tc = 40000
+    cx = torch.randn(4, Tc, 512, device=dev).to(torch.bfloat16)
+    cw = (torch.randn(512, 1536, device=dev) / 40).to(torch.bfloat16)
+    cy = torch.empty(4, (Tc - 3) // 2 + 1, 512, device=dev, dtype=torch.bfloat16)
+    fill = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+    cd = L.GemmDesc()
+    cd.X = L.operand(cx.data_ptr(), 0, 2 * 512, rpb=cy.shape[1], bstride=Tc * 512)
+    cd.Y = L.operand(cw.data_ptr(), 0, 1536)
+    cd.C = cy.data_ptr()
+    cd.M, cd.N, cd.Kseg, cd.ldc, cd.groups, cd.splitk = 4 * cy.shape[1], 512, 1536, 512, 1, 1
+    cd.ep = L.epilogue(act=L.ACT_GELU)
+    try:
+        outs = [torch.zeros(B, T, cin, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+        lib.fh_gemm_set_path(7)
+        _run(desc(outs[0]), L.DT_BF16)
+        quiet = outs[0].clone()
+        lib.fh_gemm_set_path(8)
+        _run(desc(outs[1]), L.DT_BF16)
+        assert lib.fh_gemm_last_loop() == 8
+        assert torch.equal(outs[1], quiet)
+        bad = torch.zeros((), device=dev, dtype=torch.int64)
+        side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        n_launch = 2000
+        for i in range(n_launch):
+            if i % 6 == 0:
+                with torch.cuda.stream(side):
+                    lib.fh_gemm_set_path(7)
+                    L.check(lib.fh_gemm(cd, L.DT_BF16, side.cuda_stream), "fh_gemm (side stream)")
+                    lib.fh_gemm_set_path(8)
+                    fill.fill_(float(i))
+            out = outs[i % 3]
+            L.check(lib.fh_gemm(desc(out), L.DT_BF16, main.cuda_stream), "fh_gemm")
+            bad += (out != quiet).any()
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0, f"{int(bad.item())} of {n_launch} launches differ from the quiet-device result"
+    finally:
+        lib.fh_gemm_set_path(9)
+
+
 def test_untuned_shape_class_takes_the_nearest_measured_one(tmp_path):
     """A launch whose quarter-octave class (tune_key, gemm.hip) was never measured takes the choice of the nearest measured class that
     differs only in the long dimension -- not the 128-tile fallback: M = 64 x 731 rows measured, M = 64 x 768 (the next class) launched
