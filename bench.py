@@ -45,6 +45,8 @@ def kernel_name(slot: int, dtype: str = "bf16") -> str:
     tools/pmc_summary.py reduces rocprofv3's kernel names to)."""
     loop, var = slot // 8, slot % 8
     t = ELEM_NAME[dtype]
+    if slot >= 64:   # the streaming loop's operand instance (the conv data gradients): slot_sums keeps it apart from the plain kernel
+        return "gemm_8ph_stream_kernel<%s, %s, 1>" % (t, LAYOUTS[var])
     if loop == 1 and var < 4:
         return "gemm_8ph_stream_kernel<%s, %s>" % (t, LAYOUTS[var])
     if var < 4:
@@ -62,10 +64,12 @@ def collect_launches(lib, cap: int = 20000):
 
 def slot_sums(launches, dtype_is_16: bool):
     """per-slot sums in fh_prof_collect's numbering (loop * 8 + 4 + layouts; loop 8 -> 8 + layouts; fp32 -> layouts)."""
-    ms, fl, ln = [0.0] * 64, [0.0] * 64, [0] * 64
+    ms, fl, ln = [0.0] * 72, [0.0] * 72, [0] * 72
     for r in launches:
         lay = r["xl"] * 2 + r["yl"]
         v = lay if not dtype_is_16 else (8 + lay if r["loop"] == 8 else 8 * (r["loop"] & 7) + 4 + lay)
+        if dtype_is_16 and r["loop"] == 8 and (r["atomic"] & 2):   # flag bit 1 = GELU' operand: gemm_8ph_stream_kernel<.., 1>, a kernel of its own
+            v = 64 + lay
         ms[v] += r["ms"]; fl[v] += r["flops"]; ln[v] += 1
     return ms, fl, ln
 
@@ -727,7 +731,7 @@ def main():
     roof = None
     tot_ms = sum(ms)
     if tot_ms > 0:
-        v = max(range(64), key=lambda i: ms[i])
+        v = max(range(72), key=lambda i: ms[i])
         ach = fl[v] / (ms[v] * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype != "float32" else 157.3   # the f16 MFMA forms run at the bf16 rate (MI355X_MICROARCH.md)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak,

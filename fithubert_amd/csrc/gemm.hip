@@ -331,7 +331,7 @@ extern "C" int fh_prof_collect_launches(double* ms, double* flops, int* rows /*[
   for (auto& r : g_prof) {
     float t = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && n < cap) {
-      if (tf) fprintf(tf, "%d %d %d %d %d %d %d %d %.4f\n", r.M, r.N, r.K, r.groups, r.xl, r.yl, r.loop, r.splitk, t);
+      if (tf) fprintf(tf, "%d %d %d %d %d %d %d %d %.4f %d\n", r.M, r.N, r.K, r.groups, r.xl, r.yl, r.loop, r.splitk, t, r.atomic);   // (last: the flag bits)
       ms[n] = t;
       flops[n] = r.flops;
       int* q = rows + 9 * n;
@@ -361,8 +361,8 @@ extern "C" int fh_prof_collect(double* ms /*[64]*/, double* flops /*[64]*/, long
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     if (tf)
-      fprintf(tf, "%d %d %d %d %d %d %d %d %.4f\n", r.M, r.N, r.K, r.groups, (r.variant >> 1) & 1, r.variant & 1,
-              (r.variant >= 8 && r.variant < 12) ? 8 : r.variant >> 3, r.splitk, t);
+      fprintf(tf, "%d %d %d %d %d %d %d %d %.4f %d\n", r.M, r.N, r.K, r.groups, (r.variant >> 1) & 1, r.variant & 1,
+              (r.variant >= 8 && r.variant < 12) ? 8 : r.variant >> 3, r.splitk, t, r.atomic);
     ms[r.variant] += t;
     flops[r.variant] += r.flops;
     launches[r.variant] += 1;

@@ -3,7 +3,7 @@ import sys
 from collections import OrderedDict
 rows = OrderedDict()
 for line in open(sys.argv[1]):
-    M, N, K, G, xl, yl, loop, sk, ms = line.split()
+    M, N, K, G, xl, yl, loop, sk, ms = line.split()[:9]   # (a tenth column holds the launch's flag bits)
     key = (int(M), int(N), int(K), int(G), int(xl), int(yl), int(loop), int(sk) & 0xffff, int(sk) >> 16)
     r = rows.setdefault(key, [0, 0.0])
     r[0] += 1; r[1] += float(ms)

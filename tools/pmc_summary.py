@@ -34,6 +34,10 @@ def canon_kernel_name(raw):
     m = _MAN.search(raw)
     if m:
         ints = re.findall(r"L[ij](\d+)E", m.group(3))
+        # the streaming loop's third integer is its operand instance: 0 = the plain kernel (named without it, as before round 5), 1 = the
+        # instance that multiplies by a per-element operand (the conv data gradients)
+        if m.group(1) == "gemm_8ph_stream_kernel" and len(ints) == 3 and ints[2] == "0":
+            ints = ints[:2]
         return "%s<%s>" % (m.group(1), ", ".join([_TAGS[m.group(2)]] + ints))
     # rocprofv3's demangler does not know DF16b (std::bfloat16_t): names whose first integer argument is 0 stay mangled (handled above),
     # those with a leading 1 come out as '<bool _Accum, int, E, ...>' -- the 'int, E' IS that 1
@@ -93,6 +97,8 @@ if trace and os.path.exists(trace):
             continue
         M, N, K, G, xl, yl, loop, sk = (int(v) for v in p[:8])
         name = LOOPS.get(loop, "gemm_kernel<float, {l}>").format(t=ELEM, l=LAYOUTS[(xl, yl)])
+        if loop == 8 and len(p) > 9 and int(p[9]) & 2:   # flag bit 1: the GELU' operand -> the streaming loop's operand instance
+            name = name[:-1] + ", 1>"
         a = alg[name]
         a[0] += 1
         a[1] += 2.0 * M * N * K * G
