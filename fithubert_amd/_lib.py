@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfithubert_hip.so")
+# FH_LIB_PATH: another build of the SAME interface (same-box A/B of kernel changes, tools/scratch/ab.sh); the loader still checks
+# every symbol of include/fithubert_hip.h, and bench.py's `binary` field names the file that was loaded
+LIB_PATH = os.environ.get("FH_LIB_PATH") or os.path.join(HERE, "libfithubert_hip.so")
 
 R_CONTIG, R_STRIDED = 0, 1
 ACT_NONE, ACT_GELU = 0, 1

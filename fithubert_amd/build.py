@@ -48,14 +48,14 @@ def _deps_hash(src: str) -> str:
     return h.hexdigest()
 
 
-def _compile(src: str) -> str:
+def _compile(src: str, extra: tuple = (), tag: str = "") -> str:
     os.makedirs(OBJ, exist_ok=True)
-    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    obj = os.path.join(OBJ, os.path.basename(src) + tag + ".o")
     stamp = obj + ".sha1"
-    want = _deps_hash(src)
+    want = _deps_hash(src) + " ".join(extra)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -79,12 +79,13 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def lib_hash() -> str:
-    """sha256 (16 hex digits) of the built shared library itself, or '' when it does not exist."""
-    if not os.path.exists(LIB):
+def lib_hash(path: str = "") -> str:
+    """sha256 (16 hex digits) of the shared library the binding loads (FH_LIB_PATH, else the in-tree build), or '' when it does not exist."""
+    path = path or os.environ.get("FH_LIB_PATH") or LIB
+    if not os.path.exists(path):
         return ""
     h = hashlib.sha256()
-    with open(LIB, "rb") as fh:
+    with open(path, "rb") as fh:
         for chunk in iter(lambda: fh.read(1 << 20), b""):
             h.update(chunk)
     return h.hexdigest()[:16]
@@ -104,7 +105,28 @@ def build(verbose: bool = True, jobs: int = 6) -> str:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
         print(f"[fithubert_amd.build] {LIB} ({os.path.getsize(LIB) >> 10} KiB) from {len(srcs)} sources")
+    _build_plainloads(srcs, objs, jobs)
     return LIB
+
+
+# Test-only twin of the library: the positional-conv tap loops on ordinary loads instead of the asm-requested, hand-counted ones
+# (csrc/posconv_taps.cuh, -DFH_POSCONV_PLAIN_LOADS); every other object is shared.  The GPU suite compares the two bit for bit.
+LIB_PLAINLOADS = os.path.join(HERE, "libfithubert_hip_plainloads.so")
+_PLAIN_UNITS = ("posconv.hip", "posconv_wide.hip")
+
+
+def _build_plainloads(srcs, objs, jobs: int) -> str:
+    twin = []
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        futs = {s: ex.submit(_compile, s, ("-DFH_POSCONV_PLAIN_LOADS",), ".plainloads") for s in srcs if os.path.basename(s) in _PLAIN_UNITS}
+        for s, o in zip(srcs, objs):
+            twin.append(futs[s].result() if s in futs else o)
+    newest = max(os.path.getmtime(o) for o in twin)
+    if not os.path.exists(LIB_PLAINLOADS) or os.path.getmtime(LIB_PLAINLOADS) < newest:
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PLAINLOADS] + twin, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PLAINLOADS
 
 
 if __name__ == "__main__":

@@ -197,7 +197,11 @@ int launch_16(const GemmParams& p, int dtype, hipStream_t stream) {
       // no measurement for this class or a neighbouring one (a caller that never switched the tuner on): launches with many rows
       // take the 256-tile 8-phase loops -- streaming where the epilogue allows it (launch_path_h falls back from 8 to 7 to the
       // 128-tile loop by itself); at M = 63,744, N = K = 480 they run 40 us against the 128-tile loop's 59 -- the rest loop 2
-      if (!nb) return launch_path(p, (!p.ep.atomic && p.M >= 4096 && p.N >= 128) ? 8 : 2, dtype, stream);
+      // (the tuner's own gate on the reduction depth applies here too: it never offers loops 3 - 8 below 128, i.e. a single K-tile)
+      if (!nb) {
+        const bool deep = (long)p.Kseg * p.X.nseg >= 128;
+        return launch_path(p, (!p.ep.atomic && p.M >= 4096 && p.N >= 128 && deep) ? 8 : 2, dtype, stream);
+      }
       TuneChoice c = *nb;
       if (p.ep.atomic) {   // a split count measured on a longer reduction: keep every split at least 512 deep, as the candidates are
         const long red = (long)p.Kseg * p.X.nseg;

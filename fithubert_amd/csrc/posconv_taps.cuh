@@ -16,6 +16,19 @@ template <int N, typename F, int M = 0> __device__ __forceinline__ void static_s
     static_steps<N, F, M + 1>(static_cast<F&&>(f));
   }
 }
+// The hand-counted protocol trusts the compiler in one respect it is not told about: it treats a fragment as defined at the REQUEST, so
+// a copy, rematerialisation or spill it inserted between a request and its wait would read registers the load has not written yet
+// (tests/test_abi.py checks the spill side: no scratch in these kernels).  -DFH_POSCONV_PLAIN_LOADS builds the same tap loop on
+// ordinary loads the compiler tracks itself (slower: it sinks them to their first use) -- the reference build of
+// tests/test_ops_gpu.py::test_positional_conv_asm_requests_against_the_plain_load_build, which compares the two bit for bit
+// over many launches under load (fithubert_amd/build.py links it as libfithubert_hip_plainloads.so).
+#ifdef FH_POSCONV_PLAIN_LOADS
+template <int OFF> __device__ __forceinline__ void wfrag_request(bf16x8& d, const void* sbase, uint32_t voff) {
+  d = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(sbase) + voff + OFF);
+}
+template <int N> __device__ __forceinline__ void wfrag_wait(bf16x8 (&)[2]) {}
+template <int N> __device__ __forceinline__ void wfrag_wait(bf16x8 (&)[3]) {}
+#else
 template <int OFF> __device__ __forceinline__ void wfrag_request(bf16x8& d, const void* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
 }
@@ -25,6 +38,7 @@ template <int N> __device__ __forceinline__ void wfrag_wait(bf16x8 (&w)[2]) {
 template <int N> __device__ __forceinline__ void wfrag_wait(bf16x8 (&w)[3]) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : "n"(N));
 }
+#endif
 // Toeplitz order.  Output tile tt of a wave multiplies tap j with the window rows [16 tt + j, 16 tt + j + 16): taps j and j + 16 of
 // neighbouring tiles read the SAME rows.  So the taps are walked in 16 classes rho = j mod 16; inside a class, step m reads the
 // fragment at row 16 m + rho ONCE and feeds it to tap i = m - tt (j = rho + 16 i) of every tile tt -- NT * CB MFMAs per 1 KB LDS read

@@ -111,6 +111,7 @@ class W2V2Distil:
         self.v_rel_loss_weight = t["v_rel_loss_weight"]
         self.random_layer_weight = t["random_layer_weight"]
         self._attn_transfer = t["attn_loss_weight"] > 0 or t["v_rel_loss_weight"] > 0
+        self._tr_select = None    # layer-wise heads behind a TR conv in the middle of the stack: the pred_layer_id the loss stacks
         if self._attn_transfer:   # train.py:64-78: both models return the last layer's (attn_logits, v_rel)
             if self.model_cfg.get("enable_tr_layer"):
                 raise NotImplementedError("attention / value-relation transfer needs equal frame counts in student and teacher: "
@@ -125,11 +126,11 @@ class W2V2Distil:
                 raise NotImplementedError("layer-wise distillation with tr_layer_index > 0: the reference's loss stacks projections of "
                                           "different lengths (train.py:260-282); use tr_layer_index = 0 or layerwise_proj = False")
             # distil_random_layer == 0 with every pred_layer_id behind the TR conv stacks equal-length projections and RUNS in the
-            # reference (train.py:269-282); the engine computes those heads (tests/test_tr_variants_gpu.py), but the fused KD loss walks
-            # ONE [layers][B][T][P] block and is not wired to the second head group alone: a limitation of this package, said as such
-            raise NotImplementedError("layer-wise distillation with tr_layer_index > 0 and distil_random_layer == 0 (pred_layer_id all "
-                                      "behind the TR conv) runs in the reference but is not wired into this package's fused KD loss; "
-                                      "use tr_layer_index = 0 or layerwise_proj = False")
+            # reference (train.py:269-282).  The fused loss kernels walk ONE contiguous [tasks][B][T][P] block, while those heads fill
+            # the first rows of their [slot] of the engine's `pred` array: the selected heads are gathered into such a block, the loss
+            # runs on it with the DistilHuBERT-style tables (task k <-> teacher layer pred_layer_id[k], weight 1 / N) and its gradient
+            # is scattered back into the slots (every other head's gradient is zero, as in the reference) -- _selected_heads_loss
+            self._tr_select = list(self.student_model.pred_layer_id)
         if t["sim_loss_weight"] > 0 and t["distil_random_layer"] > 0:
             # the reference itself cannot run this: sim_loss is 3-D and train.py:305 takes mean((0, 2, 3))
             raise NotImplementedError("sim_loss_weight > 0 needs distil_random_layer == 0 (train.py:302-306 fails otherwise)")
@@ -237,8 +238,9 @@ class W2V2Distil:
             w[Lr - 1] = 1.0
             tl[Lr - 1] = n_teacher - 1  # teacher_results["layer_results"][-1] (train.py:255-257)
             self._mean_over_layers = 1.0
-        elif not self.student_model.layerwise_proj:
-            # DistilHuBERT-style head: task k predicts teacher layer pred_layer_id[k] (train.py:268-281)
+        elif not self.student_model.layerwise_proj or self._tr_select is not None:
+            # DistilHuBERT-style head: task k predicts teacher layer pred_layer_id[k] (train.py:268-281); the same tables serve the
+            # layer-wise heads gathered behind a TR conv (self._tr_select: block k = head pred_layer_id[k])
             ids = self.student_model.pred_layer_id
             w = torch.full((len(ids),), 1.0 / len(ids))
             tl = torch.tensor(ids, dtype=torch.int32)
@@ -266,6 +268,8 @@ class W2V2Distil:
         """train.py:236-405 for the built branch (rec_loss mse / l1, random-layer or pred_layer_id selection).
         Differentiable w.r.t. the student through the fused loss kernel's gradient."""
         proj = student_results["projections"]
+        if self._tr_select is not None:   # train.py:277-281: only the pred_layer_id heads are stacked (equal lengths behind the TR conv)
+            proj = [proj[i] for i in self._tr_select]
         pred = torch.stack(proj, dim=0) if isinstance(proj, (list, tuple)) else proj.permute(1, 0, 2, 3)  # -> [tasks][B][T][P]
         teacher = torch.stack([lr[0].transpose(0, 1) for lr in teacher_results["layer_results"]], dim=0).contiguous()
         out = _KDLossFn.apply(pred, teacher, self)
@@ -293,7 +297,7 @@ class W2V2Distil:
             for i, l in enumerate(self.rand_l):
                 losses[f"rand_l{i}"] = out[l] * self.random_layer_weight
             losses[f"l{Lr - 1}"] = out[Lr - 1]
-        elif not self.student_model.layerwise_proj:
+        elif not self.student_model.layerwise_proj or self._tr_select is not None:
             for k, pid in enumerate(self.student_model.pred_layer_id):
                 losses[f"layer{pid}"] = out[k]
         else:
@@ -412,7 +416,7 @@ class W2V2Distil:
             ((self.opt_step * 7919 + self._micro * 104729 + batch_idx + 1 + self.rank * 0x9E3779B1) & 0xFFFFFFFF)
         # FH_KD_FUSED=1: the layer-wise loss rides in the projection heads' GEMM epilogue (`pred` is never written, the loss vector and
         # d loss / d pred come out of the forward); default: the separate fused loss kernel, which is faster
-        fused_kd = (not self._rows_loss) and self._kd_fused and getattr(self.engine, "kd_fusable", lambda h=True: False)(self.student_model._heads_on)
+        fused_kd = (not self._rows_loss) and self._tr_select is None and self._kd_fused and getattr(self.engine, "kd_fusable", lambda h=True: False)(self.student_model._heads_on)
         if fused_kd:
             if ev is not None:      # the teacher's hidden states are an operand of the forward now (one batch ahead: ready long before)
                 torch.cuda.current_stream(self.device).wait_event(ev)
@@ -427,6 +431,8 @@ class W2V2Distil:
                 torch.cuda.current_stream(self.device).wait_event(ev)
         if fused_kd:
             pass
+        elif self._tr_select is not None:
+            out, d_pred = self._selected_heads_loss(ws, hid, want_grad=True)
         elif self._rows_loss:
             out, d_pred = self.engine.kd_loss_rows(ws, hid, self.layer_w, self.teacher_layer,
                                                    loss_type=0 if self.rec_loss_type == "mse" else 1,
@@ -474,6 +480,39 @@ class W2V2Distil:
             self.sync.wait()                        # the student stream (not the host) waits for the reduced gradients
             self.optimizer_step()
         return out
+
+    def _selected_heads_loss(self, ws, hid, want_grad: bool):
+        """Layer-wise heads with the TR conv in the middle of the stack (self._tr_select; train.py:269-282 with distil_random_layer == 0
+        and every pred_layer_id behind the conv): gather the selected heads' predictions -- the first B x (T2 f) rows of their slots --
+        into one [N][B][T2 f][P] block, run the fused loss kernel on it, scatter d loss / d pred back into the slot layout the
+        backward reads (zero for the heads the loss does not see)."""
+        ids = self._tr_select
+        block = torch.stack([ws.head_pred(i) for i in ids]).contiguous()
+        lt = 0 if self.rec_loss_type == "mse" else 1
+        if self._rows_loss:
+            nblk = self.engine.lib.fh_kd_loss_rows_nblk(block.shape[1], block.shape[2])
+            partials = torch.empty(2 * len(ids) * nblk, device=self.device, dtype=torch.float32)
+            out = torch.empty(len(ids) + 1, device=self.device, dtype=torch.float64)
+            d_blk = torch.empty_like(block) if want_grad else None
+            from .engine import tensor_dtype_code
+            L.check(self.engine.lib.fh_kd_loss_rows_scaled(self.engine.c.dtype, tensor_dtype_code(hid), block.data_ptr(), hid.data_ptr(),
+                                                           d_blk.data_ptr() if want_grad else None, self.layer_w.data_ptr(),
+                                                           self.teacher_layer.data_ptr(), partials.data_ptr(), out.data_ptr(), len(ids),
+                                                           block.shape[1], block.shape[2], hid.shape[2], block.shape[3],
+                                                           hid.shape[1] * hid.shape[2] * hid.shape[3], lt, float(self.rec_loss_weight),
+                                                           float(self.sim_loss_weight), float(self.loss_scale), self.engine.stream()),
+                    "fh_kd_loss_rows")
+        else:
+            out, d_blk = self.engine.kd_loss(ws, hid, self.layer_w, self.teacher_layer, loss_type=lt,
+                                             grad_scale=float(self.rec_loss_weight) * self.loss_scale, want_grad=want_grad, pred=block)
+        if not want_grad:
+            return out, None
+        d_pred = torch.zeros_like(ws.view("pred"))
+        B, frames = block.shape[1], block.shape[2]
+        for k, i in enumerate(ids):
+            slot = d_pred[i].reshape(-1, d_pred.shape[-1])
+            slot[: B * frames].view(B, frames, -1).copy_(d_blk[k])
+        return out, d_pred
 
     def fuse_window(self, batches):
         """The micro-batches of ONE accumulation window as one batch, or None when that would not be exact.  Gradient accumulation
@@ -588,7 +627,10 @@ class W2V2Distil:
         self._next_teacher = None
         hid = self.teacher_hiddens(batch)
         ws = self.engine.forward(x, lengths, training=False, heads_on=self.student_model._heads_on)
-        if self._rows_loss:
+        if self._tr_select is not None:
+            out, _ = self._selected_heads_loss(ws, hid, want_grad=False)
+            total = out[-1] if self._rows_loss else float(self.rec_loss_weight) * out[-1]
+        elif self._rows_loss:
             out, _ = self.engine.kd_loss_rows(ws, hid, self.layer_w, self.teacher_layer, loss_type=0 if self.rec_loss_type == "mse" else 1,
                                               rec_weight=float(self.rec_loss_weight), sim_weight=float(self.sim_loss_weight), want_grad=False)
             total = out[-1]

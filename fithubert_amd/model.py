@@ -94,16 +94,21 @@ class _UpsampleFn(torch.autograd.Function):
         dy2 = dy.reshape(B * T, f * cout).to(eng.elem).contiguous()    # row t: the f up-sampled frames (j, co)
         wp = w.detach().permute(2, 1, 0).reshape(f * cout, cin)
         dx = model._native_linear(dy2, wp.t().contiguous(), torch.zeros(cin, device=dev)).view(B, T, cin).to(x.dtype)
-        # the weight gradient contracts over the B T rows: both operands transposed once (a layout move), rows padded to the 16-byte vector
-        K = (B * T + 7) // 8 * 8
-        xt = torch.zeros(cin, K, device=dev, dtype=eng.elem)
-        xt[:, : B * T] = x.reshape(B * T, cin).t()
-        dyt = torch.zeros(f * cout, K, device=dev, dtype=eng.elem)
-        dyt[:, : B * T] = dy2.t()
-        dwp = model._native_linear(xt, dyt, torch.zeros(f * cout, device=dev)).float()          # [cin, (j, co)]
+        # the weight gradient contracts over the B T rows: dwp[(j, co)][ci] = sum_t dy2[t][(j, co)] x[t][ci] as ONE fp32-accumulating GEMM
+        # whose operands are read where they lie (both with the reduction index as the memory row: FH_R_STRIDED) -- no transposed copies,
+        # and the sum never passes through the 16-bit compute type
+        xr = x.reshape(B * T, cin).to(eng.elem).contiguous()
+        if (f * cout) % 8 or cin % 8:
+            raise NotImplementedError("upsampler weight gradient: channel counts must be multiples of 8")
+        dwp = torch.zeros(f * cout, cin, device=dev, dtype=torch.float32)
+        d = L.GemmDesc()
+        d.X, d.Y, d.C = L.operand(dy2.data_ptr(), 1, f * cout), L.operand(xr.data_ptr(), 1, cin), dwp.data_ptr()
+        d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = f * cout, cin, B * T, cin, 1, max(1, min(64, (B * T) // 512))
+        d.ep = L.epilogue(atomic=1)
+        L.check(eng.lib.fh_gemm(d, eng.c.dtype, eng.stream()), "fh_gemm (upsampler weight gradient)")
         g = torch.zeros_like(eng.params)
         gv = eng.param_views(g)
-        gv["upsampler.weight"].copy_(dwp.view(cin, f, cout).permute(0, 2, 1))
+        gv["upsampler.weight"].copy_(dwp.view(f, cout, cin).permute(2, 1, 0))
         db = gv["upsampler.bias"]                                      # out[n % cout] += sum_m dy2[m][n]
         L.check(eng.lib.fh_colsum(eng.c.dtype, dy2.data_ptr(), db.data_ptr(), B * T, f * cout, f * cout, 1, 0, 0, cout, 1.0, eng.stream()),
                 "fh_colsum")
@@ -440,7 +445,9 @@ class CustomStudentModel(nn.Module):
         if not self.layerwise_proj:  # model.py:503-516: x is the encoder output (up-sampled behind a TR layer), projections B x N x T x D
             # behind a TR layer x = upsampler(x) stays differentiable, as in the reference (model.py:505-506): a native node of its own
             # when autograd is recording (its gradient re-enters the engine through layer_results), the plain native op otherwise
-            if tr and torch.is_grad_enabled() and self.training:
+            # (whatever the module's mode: with model.eval() under autograd the reference's upsampler is differentiable too; the engine's
+            # own node then says loudly that it keeps no activations in eval mode instead of x being silently detached -- ADVICE r5)
+            if tr and torch.is_grad_enabled() and (self.flat.requires_grad or enc_x.requires_grad):
                 x = _UpsampleFn.apply(self.flat, self, enc_x)
             else:
                 x = self._upsample(enc_x) if tr else enc_x

@@ -623,3 +623,67 @@ def test_merged_accumulation_window_has_the_gradient_of_the_micro_batch_loop():
     # a padded micro-batch keeps the loop
     padded = dict(micro[1], _any_pad=True)
     assert task.fuse_window([micro[0], padded, micro[2], micro[3]]) is None
+
+
+@pytest.mark.parametrize("rec_type,sim_w", [("l1", 0.0), ("mse", 0.0), ("l1", 1.0)])
+def test_layerwise_distillation_behind_a_tr_conv_in_the_middle_of_the_stack(rec_type, sim_w):
+    """layerwise_proj with tr_layer_index > 0, distil_random_layer == 0 and every pred_layer_id behind the TR conv: the reference
+    stacks those heads' equal-length projections and runs (train.py:269-282); round 5 raised NotImplementedError here.
+    Module-API loss and gradients, then the hot path's first step and its gradient, against the oracle's autograd (fp32); the
+    configurations the reference itself cannot run (a head in front of the conv selected, random layers) still fail loudly."""
+    import copy
+    from fithubert_amd.dataset import SyntheticLibriDataset
+    from fithubert_amd.distill import W2V2Distil
+    from fithubert_amd.teacher import TeacherConfig
+    from oracle import loss_ref as LR
+
+    y = yaml.safe_load(open(os.path.join(ROOT, "conf", "fithubert.yaml")))
+    y["distiller"].update(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0, encoder_layers=4,
+                          init_conv_layers=False, init_encoder_layers=0, tr_layer_index=2, pred_layer_id="[2, 3]")
+    y["train"].update(distil_random_layer=0, accumulate_grad_batches=1, rec_loss_type=rec_type, sim_loss_weight=sim_w)
+    tc = TeacherConfig.base("hubert")
+    tc.encoder_layers = 4
+    bad_cfg = copy.deepcopy(y)
+    bad_cfg["distiller"]["pred_layer_id"] = "[1, 3]"
+    with pytest.raises(NotImplementedError, match="stacks projections of different lengths"):
+        W2V2Distil(bad_cfg, dtype="float32", device=DEV, teacher_cfg=tc, seed=0, teacher_dtype=torch.float32)
+    task = W2V2Distil(y, dtype="float32", device=DEV, teacher_cfg=tc, seed=0, teacher_dtype=torch.float32)
+    sm = task.student_model
+    ds = SyntheticLibriDataset([12000, 10400], batch_size=2, seed=4)
+    b = to_device(ds[0], DEV)
+    sm.train()
+    sres, tres = task(b["x"], b["padding_mask"])
+    assert sres["projections"][0].shape[1] != sres["projections"][3].shape[1]      # two lengths: heads in front of / behind the conv
+    total, losses = task.calculate_loss(sres, tres)
+    total.backward()
+    grads = {k: v.clone() for k, v in sm.engine.param_views(sm.flat.grad).items()}
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in sm.state_dict().items()}
+    ref = S.student_forward(sd, y["distiller"], b["x"].cpu(), b["padding_mask"].cpu(), training=True)
+    t_res = {"layer_results": [(lr[0].float().cpu(), (None, None)) for lr in tres["layer_results"]],
+             "features": [tres["features"][0].float().cpu()]}
+    lo, ld = LR.calculate_loss(ref, t_res, y["train"], pred_layer_id=[2, 3], layerwise_proj=True, num_encoders=4)
+    lo.backward()
+    assert abs(total.item() - lo.item()) < 2e-4 * abs(lo.item()), (total.item(), lo.item())
+    assert set(losses) >= {"layer2", "layer3"}
+
+    def check(gv_map, what):
+        bad = []
+        for k, gv in gv_map.items():
+            rg = sd[k].grad
+            if rg is None or rg.norm().item() < 1e-7:
+                assert gv.abs().max().item() < 1e-6 or not k.startswith("proj_head."), (what, k)   # heads 0 / 1 see no gradient
+                continue
+            e = _rel_l2(gv.float(), rg)
+            if e > 3e-3:
+                bad.append((k, e))
+        assert not bad, (what, bad)
+    check(grads, "module API")
+    assert sd["proj_head.0.lin_proj.weight"].grad is None or sd["proj_head.0.lin_proj.weight"].grad.abs().max().item() == 0.0
+    # hot path: the first training step's loss and its gradient (read before AdamW consumed it: accumulate over two micro-batches)
+    task.accumulate = 2
+    task.configure_optimizers(num_training_steps=10)
+    out = task.training_step(b, batch_idx=0)
+    assert abs(out[-1].item() * (1.0 if sim_w > 0 else float(y["train"]["rec_loss_weight"])) - lo.item()) < 2e-4 * abs(lo.item()), (out[-1].item(), lo.item())
+    check(sm.engine.param_views(sm.engine.grads), "training_step")
+    v = task.validation_step(b)["v_loss"]
+    assert v == v and abs(v.item() - lo.item()) < 5e-2 * abs(lo.item())             # eval forward = the training forward at dropout 0

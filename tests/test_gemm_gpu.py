@@ -735,6 +735,34 @@ def test_streaming_operand_instance_under_load():
         lib.fh_gemm_set_path(9)
 
 
+@pytest.mark.parametrize("path", [7, 8])
+@pytest.mark.parametrize("K", [24, 40, 64, 72])
+def test_8_phase_loops_with_a_single_or_ragged_k_tile(path, K):
+    """Loops 7 / 8 forced onto reductions the tuner never offers them (one K-tile, a K-tile that is mostly tail, one tile + a tail of 8):
+    whichever loop launch_path_h ends up on, the result is the fp64 product -- the untuned fallback (gemm.hip launch_16) no longer sends
+    such launches there, callers that force a path still may."""
+    dev = "cuda"
+    torch.manual_seed(K)
+    M, N = 40000 + 13, 480
+    X = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    d = L.GemmDesc()
+    d.X, d.Y, d.C = L.operand(X.data_ptr(), 0, K), L.operand(W.data_ptr(), 0, K), out.data_ptr()
+    d.M, d.N, d.Kseg, d.ldc, d.groups, d.splitk = M, N, K, N, 1, 1
+    d.ep = L.epilogue(bias=bias.data_ptr())
+    L.lib().fh_gemm_set_path(path)
+    try:
+        for _ in range(3):
+            _run(d, L.DT_BF16)
+    finally:
+        L.lib().fh_gemm_set_path(9)
+    ref = X.double() @ W.double().t() + bias.double()
+    assert not torch.isnan(out.float()).any()
+    assert (out.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 def test_untuned_shape_class_takes_the_nearest_measured_one(tmp_path):
     """A launch whose quarter-octave class (tune_key, gemm.hip) was never measured takes the choice of the nearest measured class that
     differs only in the long dimension -- not the 128-tile fallback: M = 64 x 731 rows measured, M = 64 x 768 (the next class) launched
@@ -747,7 +775,7 @@ def test_untuned_shape_class_takes_the_nearest_measured_one(tmp_path):
     torch.manual_seed(0)
     N, K = 480, 480
 
-    def fwd(M, tune):
+    def fwd(M, tune, K=K):
         X = torch.randn(M, K, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
@@ -786,6 +814,9 @@ def test_untuned_shape_class_takes_the_nearest_measured_one(tmp_path):
 
     try:
         assert fwd(64 * 768, tune=False) in (7, 8)            # empty table: many rows -> the 256-tile 8-phase loops (streaming: no operand here)
+        lib.fh_gemm_tune(-1)
+        assert fwd(64 * 768, tune=False, K=64) == 2           # ... but never with a single K-tile: the tuner's own gate (reduction >= 128)
+        assert fwd(64 * 768, tune=False, K=40) == 2
         lib.fh_gemm_tune(-1)
         tuned = fwd(64 * 731, tune=True)
         assert tuned != 2

@@ -260,6 +260,98 @@ def test_posconv_wide_forward_48_channel_groups(dt, B, T):
     assert _rel(y, y_ref) < _tol(dt)
 
 
+
+@pytest.mark.parametrize("dt", [L.DT_BF16, L.DT_F16])
+def test_positional_conv_asm_requests_against_the_plain_load_build(dt):
+    """csrc/posconv_taps.cuh requests its weight fragments through inline asm and orders every use with a hand-counted
+    `s_waitcnt vmcnt(n)`; what the counts cannot see is a copy / rematerialisation of a requested register that the compiler inserted
+    in front of the wait.  The twin library built with -DFH_POSCONV_PLAIN_LOADS (fithubert_amd/build.py) runs the same
+    tap loops on ordinary loads the compiler tracks by itself: forward, data gradient and weight gradient of the student's kernel (at
+    4 and 8 tiles per wave: T on both sides of the 256-frame switch) and the teacher's 48-channel kernel must agree BIT FOR BIT
+    between the two builds, launch after launch, while a second stream keeps the memory system busy (a fragment multiplied before
+    it landed depends on cache timing)."""
+    import ctypes as C
+    import os
+    from fithubert_amd.build import LIB_PLAINLOADS
+    assert os.path.exists(LIB_PLAINLOADS), "the plain-load twin was not built (python -m fithubert_amd.build)"
+    lib = L.lib()
+    twin = C.CDLL(LIB_PLAINLOADS)
+    for name in ("fh_posconv_prepare", "fh_posconv_forward", "fh_posconv_backward_data", "fh_posconv_backward_weight",
+                 "fh_posconv_wide_prepare", "fh_posconv_wide_forward"):
+        getattr(twin, name).argtypes = getattr(lib, name).argtypes
+        getattr(twin, name).restype = getattr(lib, name).restype
+    torch.manual_seed(11)
+    G, K = 16, 128
+    side = torch.cuda.Stream()
+    noise_a = torch.randn(64 << 20, device=DEV)
+    noise_b = torch.empty_like(noise_a)
+    stop = 24
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for _ in range(stop):
+            noise_b.copy_(noise_a)
+            noise_a.mul_(1.0001)
+    bad = torch.zeros((), device=DEV, dtype=torch.int64)
+    for (B, T) in [(6, 249), (3, 499)]:
+        # student: 30-channel groups
+        D = 480
+        x = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+        g = 0.5 + torch.rand(1, 1, K, device=DEV)
+        v = torch.randn(D, D // G, K, device=DEV) * (4.0 / (K * D)) ** 0.5 * 3
+        bias = 0.1 * torch.randn(D, device=DEV)
+        dsum = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+        res = []
+        for lb in (lib, twin):
+            wf = torch.empty(G, K, 32, 32, device=DEV, dtype=_tdt(dt))
+            wb = torch.empty_like(wf)
+            norm = torch.empty(3 * K, device=DEV)
+            L.check(lb.fh_posconv_prepare(dt, _p(g), _p(v), _p(wf), _p(wb), _p(norm), D, G, K, _st()), "prep")
+            outs = []
+            for rep in range(40 if lb is lib else 1):
+                zc, y, dzc, dx = (torch.empty_like(x) for _ in range(4))
+                dws = torch.zeros(G, K, 32, 32, device=DEV)
+                dbias = torch.zeros(D, device=DEV)
+                L.check(lb.fh_posconv_forward(dt, _p(x), _p(wf), _p(bias), _p(zc), _p(y), B, T, D, G, K, _st()), "fwd")
+                L.check(lb.fh_posconv_backward_data(dt, _p(dsum), _p(zc), _p(wb), _p(dzc), _p(dx), B, T, D, G, K, _st()), "dgrad")
+                L.check(lb.fh_posconv_backward_weight(dt, _p(dzc), _p(x), _p(dws), _p(dbias), B, T, D, G, K, _st()), "wgrad")
+                cur = (zc, y, dzc, dx)
+                if outs:
+                    for a, b in zip(outs, cur):
+                        bad += (a != b).any()
+                else:
+                    outs = cur
+                    wg0 = dws
+            res.append((outs, wg0))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert torch.equal(a, b), (B, T, "student kernel: asm-requested build differs from the plain-load build")
+        # (the weight gradient adds fp32 atomics in an order that changes from launch to launch: equal up to that)
+        assert _rel(res[0][1], res[1][1]) < 1e-5
+        # teacher: 48-channel groups
+        D = 768
+        x = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
+        v = torch.randn(D, D // G, K, device=DEV) * (4.0 / (K * D)) ** 0.5 * 3
+        bias = 0.1 * torch.randn(D, device=DEV)
+        ys = []
+        for lb in (lib, twin):
+            w = torch.empty(G * K * 64 * 64, device=DEV, dtype=_tdt(dt))
+            norm2 = torch.empty(K, device=DEV)
+            L.check(lb.fh_posconv_wide_prepare(dt, _p(g), _p(v), _p(w), _p(norm2), D, G, K, _st()), "prep")
+            first = None
+            for rep in range(40 if lb is lib else 1):
+                y = torch.empty_like(x)
+                L.check(lb.fh_posconv_wide_forward(dt, _p(x), _p(w), _p(bias), _p(y), B, T, D, G, K, _st()), "fwd")
+                if first is None:
+                    first = y
+                else:
+                    bad += (first != y).any()
+            ys.append(first)
+        assert torch.equal(ys[0], ys[1]), (B, T, "teacher kernel: asm-requested build differs from the plain-load build")
+    main.wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f"{int(bad.item())} launches of the asm-requested build differ from its own first launch"
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _attn_ref(qkv, H, dh, key_len):
     B, T, _ = qkv.shape

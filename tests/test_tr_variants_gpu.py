@@ -284,6 +284,26 @@ def test_upsampled_x_is_differentiable_as_in_the_reference(golden_dir):
         assert ((a - b).norm() / b.norm()).item() < 3e-3, k
     # the head's parameters saw no gradient from x
     assert float(gv["proj_head.0.weight"].abs().max()) == 0.0
+    # model.eval() under autograd: x is NOT silently detached -- it still carries the upsampler's node, and the engine's own
+    # node says loudly that it keeps no activations in eval mode
+    m.eval()
+    m.flat.grad = None
+    r_eval = m(wav.to(DEV))
+    assert r_eval["x"].requires_grad
+    with pytest.raises(RuntimeError, match="requires model.train"):
+        (r_eval["x"].float() * tgt.to(DEV)).sum().backward()
+    with torch.no_grad():
+        assert not m(wav.to(DEV))["x"].requires_grad
+    # bf16 engine: the upsampler's weight gradient is accumulated in fp32 (never rounded to the compute type)
+    mb = CustomStudentModel(CustomStudentModelConfig(**cfg), dtype="bfloat16", device=DEV)
+    mb.load_state_dict(sd)
+    mb.train()
+    rb = mb(wav.to(DEV))
+    (rb["x"].float() * tgt.to(DEV)).sum().backward()
+    gb = mb.engine.param_views(mb.flat.grad)
+    for k in ("upsampler.weight", "upsampler.bias"):
+        a, b = gb[k].double().cpu(), sd_g[k].grad.double()
+        assert ((a - b).norm() / b.norm()).item() < 3e-2, k
     # layer = 0 with the TR conv first and the head on: projections = proj_head(upsampler(x)) (model.py:505-516)
     cfg0 = dict(cfg, tr_layer_index=0)
     m0 = CustomStudentModel(CustomStudentModelConfig(**cfg0), dtype="float32", device=DEV)
