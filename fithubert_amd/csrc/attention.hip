@@ -706,9 +706,37 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
   unsigned char* Kt = lds + 4 * PAIR;
   unsigned char* Sc = Kt + 256 * RS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, k0 = wave * 32;
+  // Which (batch, head) pairs.  The workgroup owns its CU (149.5 KB of LDS), so nothing of its own hides the load round trips of its
+  // prologue or the drain of its last stores (measured, B = 256, T = 249: prologue 78 + key loop 240 + epilogue 46 us per launch).
+  //  * grid (1, H, B): one pair per workgroup.  The heads of one utterance read and write neighbouring 80-byte (2 dh) pieces of the
+  //    same memory rows: dealt round-robin over the XCDs in dispatch order they would pull every 128-byte line through up to eight
+  //    L2s; XCD k takes a contiguous range of (b, h) instead (attn_block; 394 -> 364 us).
+  //  * grid (G, 1, 1), round 6: PERSISTENT -- one workgroup per CU walks pairs; the stores of pair i drain while the loads of pair
+  //    i + 1 are already in flight.
+  const int npair = B * H;
+  int pair, pair_end, pair_step = 1;
+  if (gridDim.y == 1 && gridDim.z == 1 && (int)gridDim.x != npair) {
+    // XCD x (workgroups w = x mod 8, dealt round-robin) takes the contiguous eighth [x0, x1) of the pairs, and ITS workgroups walk it
+    // interleaved (j, j + G8, ...): at any time the XCD works on ~G8 consecutive pairs -- neighbouring heads of the same utterances,
+    // whose shared lines are then in its L2 (a contiguous range PER WORKGROUP measured no better than no remap at all: head i + 1
+    // came 30 us after head i, when the line had long left the L2)
+    const int G = gridDim.x, w = blockIdx.x, x = w & 7, j = w >> 3;
+    const int per = npair >> 3, rem = npair & 7;
+    const int x0 = x * per + min(x, rem);
+    pair_step = (G - x + 7) >> 3;                 // workgroups of this XCD
+    pair = x0 + j;
+    pair_end = x0 + per + (x < rem ? 1 : 0);
+  } else {
+    int b_, h_, blk_;
+    attn_block(b_, h_, blk_);
+    pair = b_ * H + h_;
+    pair_end = pair + 1;
+  }
+  const int k0 = wave * 32;
   const int D = H * dh;
   const long ld = 3L * D;
+  for (; pair < pair_end; pair += pair_step) {
+  const int b = pair / H, h = pair - b * H;
   const T* base = qkv + (long)b * Tn * ld + h * dh;
   const T* dobase = dout + (long)b * Tn * D + h * dh;
   const T* obase = out + (long)b * Tn * D + h * dh;
@@ -765,7 +793,11 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
   ks_.init(drop, b, h, H, Tn, klen, k0, lane, scale, scale_log2e);
   __syncthreads();
 
+#ifdef FH_ATTN_DBG_NOLOOP   // timing aid (tools/scratch/mkvariant.py): prologue + epilogue of the fused backward alone
+  const int nstep = 0;
+#else
   const int nstep = (Tn + 31) / 32;  // 32-query steps
+#endif
   f32x4 qsum = f32x4{0.f, 0.f, 0.f, 0.f};   // column sums of this wave's dQ tiles (q bias gradient)
   const int qq = r >> 2, pp = r & 3;
   for (int st = 0; st < nstep; ++st) {
@@ -835,6 +867,9 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
       }
     }
   }
+#ifdef FH_ATTN_DBG_NOEPI
+  if (scale == 12345.f)
+#endif
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
     const int key = k0 + 16 * kt + r;
@@ -853,9 +888,14 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_kernel(const T* __restrict
       }
     }
   }
+#ifdef FH_ATTN_DBG_NOEPI
+  if (scale == 12345.f)
+#endif
   if (dbias) {   // (uniform) -- the Q / dO tiles at the head of LDS are dead behind the loop's last barrier
     const bool kvalid[2] = {k0 + r < Tn, k0 + 16 + r < Tn};
     qkv_bias_sums<NDT>(reinterpret_cast<float*>(lds), dbias, dk, dv, kvalid, qsum, h, dh, D);
+  }
+  __syncthreads();   // (persistent walk: the next pair's prologue rewrites every LDS tile)
   }
 }
 
@@ -926,7 +966,10 @@ __global__ void __launch_bounds__(512) attn_bwd_fused_stream_kernel(const T* __r
   unsigned char* Kt = lds + 2 * PAIR;
   unsigned char* Sc = Kt + 256 * RS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nkb = gridDim.x;
+  // (b, h, key block) under the XCD-contiguous remap, as the resident form: neighbouring heads' workgroups share memory rows
+  int b, h, kb;
+  attn_block(b, h, kb);
+  const int nkb = gridDim.x;
   const int kbase = kb * kpb;
   const int D = H * dh;
   const long ld = 3L * D;
@@ -1169,13 +1212,24 @@ template <typename T, int NDT>
 int bwd_fused_launch(const T* qkv, const T* out, const T* dout, const float* lse, float* delta, T* dqkv,
                      const int* key_len, int B, int Tn, int H, int dh, float scale, float sl2, fh_drop drop, hipStream_t st, float* dbias) {
   const size_t smem = 4 * (2 * 64 * AT<bf16>::RS + 512) + 256 * AT<bf16>::RS + 2 * 256 * FUSED_SRS;
+  // persistent walk (one workgroup per CU, each over a contiguous range of (batch, head) pairs) once there are at least two pairs per
+  // CU; FH_ATTN_PERSIST=0 keeps one pair per workgroup (A/B comparisons)
+  static int persist = -1, ncu = 0;
+  if (persist < 0) {
+    const char* e = getenv("FH_ATTN_PERSIST");
+    persist = (e && e[0] == '0') ? 0 : 1;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const dim3 grid = (persist && (long)B * H >= 2L * ncu) ? dim3(ncu, 1, 1) : dim3(1, H, B);
   if (drop.p > 0.f) {
     set_lds(attn_bwd_fused_kernel<T, NDT, true>, smem);
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, true>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, true>), grid, dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
                        B, Tn, H, dh, scale, sl2, drop, dbias);
   } else {
     set_lds(attn_bwd_fused_kernel<T, NDT, false>, smem);
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, false>), dim3(1, H, B), dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, false>), grid, dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,
                        B, Tn, H, dh, scale, sl2, drop, dbias);
   }
   FH_CHECK_LAUNCH();

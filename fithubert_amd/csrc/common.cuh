@@ -56,6 +56,15 @@ __device__ __forceinline__ V16 v16_zero() {
   v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u;
   return v;
 }
+// Logical block index under the XCD-contiguous remap.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so
+// neighbours in the grid -- readers of neighbouring pieces of the same memory rows -- land on as many L2s as there are XCDs; here XCD k
+// takes a contiguous range of the logical order instead (bijective for any grid size; speed only, never correctness).
+__device__ __forceinline__ int fh_xcd_logical_block() {
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * (int)gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int per = nwg >> 3, rem = nwg & 7, xcd = lin & 7;
+  return (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (lin >> 3);
+}
 __device__ __forceinline__ V16 ld16(const void* p) { return *reinterpret_cast<const V16*>(p); }
 __device__ __forceinline__ void st16(void* p, const V16& v) { *reinterpret_cast<V16*>(p) = v; }
 

@@ -167,6 +167,9 @@ class CustomStudentModel(nn.Module):
         """Same distributions as the reference initialisers (module.py:47 kaiming_normal for convs, :195-197 pos_conv,
         init_bert_params N(0, 0.02) for Linear / q,k,v, default torch init for the TR conv / ConvTranspose heads)."""
         g = torch.Generator().manual_seed(seed)
+        # the time-reduction conv sits at encoder.layers.<tr_layer_index> (modules/module.py:247-248); round 6: with an index > 0 it used
+        # to fall under the GroupNorm rule below (".2.weight" -> ones) or the N(0, 0.02) default
+        tr_name = f"encoder.layers.{int(getattr(self.cfg, 'tr_layer_index', 0) or 0)}" if self.cfg.enable_tr_layer else "<none>"
         for name, p in self.engine.param_views().items():
             shape = tuple(p.shape)
             if "feature_extractor" in name and name.endswith("0.weight"):
@@ -180,14 +183,14 @@ class CustomStudentModel(nn.Module):
             elif name in ("proj_head.2.weight", "proj_head.2.bias", "proj_head.2.layer.weight", "proj_head.2.layer.bias"):  # module.py:596-605
                 bound = float(self.engine.c.inter_dim) ** -0.5
                 t = (torch.rand(shape, generator=g) * 2 - 1) * bound
-            elif "layer_norm.weight" in name or name.endswith(".2.weight"):
+            elif "layer_norm.weight" in name or (name.endswith(".2.weight") and len(shape) == 1):   # LayerNorm / GroupNorm scales
                 t = torch.ones(shape)
-            elif name.endswith("bias") and ("upsampler" in name or name == "encoder.layers.0.bias" and self.cfg.enable_tr_layer):
+            elif name.endswith("bias") and ("upsampler" in name or name == tr_name + ".bias"):
                 fan_in = shape[0] * 1
                 t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(self.cfg.encoder_embed_dim * self.cfg.tr_reduce_factor)
             elif name.endswith("bias"):
                 t = torch.zeros(shape)
-            elif "upsampler.weight" in name or (name == "encoder.layers.0.weight" and self.cfg.enable_tr_layer):
+            elif "upsampler.weight" in name or name == tr_name + ".weight":
                 fan_in = shape[1] * shape[2] if "upsampler" in name else shape[1] * shape[2]
                 bound = 1.0 / math.sqrt(fan_in)
                 t = (torch.rand(shape, generator=g) * 2 - 1) * bound

@@ -640,7 +640,7 @@ def test_layerwise_distillation_behind_a_tr_conv_in_the_middle_of_the_stack(rec_
     y = yaml.safe_load(open(os.path.join(ROOT, "conf", "fithubert.yaml")))
     y["distiller"].update(dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0, encoder_layers=4,
                           init_conv_layers=False, init_encoder_layers=0, tr_layer_index=2, pred_layer_id="[2, 3]")
-    y["train"].update(distil_random_layer=0, accumulate_grad_batches=1, rec_loss_type=rec_type, sim_loss_weight=sim_w)
+    y["train"].update(distil_random_layer=0, random_layer_weight=0, accumulate_grad_batches=1, rec_loss_type=rec_type, sim_loss_weight=sim_w)
     tc = TeacherConfig.base("hubert")
     tc.encoder_layers = 4
     bad_cfg = copy.deepcopy(y)
@@ -649,6 +649,11 @@ def test_layerwise_distillation_behind_a_tr_conv_in_the_middle_of_the_stack(rec_
         W2V2Distil(bad_cfg, dtype="float32", device=DEV, teacher_cfg=tc, seed=0, teacher_dtype=torch.float32)
     task = W2V2Distil(y, dtype="float32", device=DEV, teacher_cfg=tc, seed=0, teacher_dtype=torch.float32)
     sm = task.student_model
+    # the TR conv at encoder.layers.2 is initialised like a Conv1d (uniform, fan-in bound), not as a GroupNorm scale (round 6: the
+    # ".2.weight" rule of reset_parameters turned it into all ones)
+    w_tr = sm.state_dict()["encoder.layers.2.weight"]
+    assert w_tr.dim() == 3 and float(w_tr.abs().max()) <= (w_tr.shape[1] * w_tr.shape[2]) ** -0.5 + 1e-6 and float(w_tr.std()) > 1e-3
+    assert float(sm.state_dict()["encoder.layers.2.bias"].abs().max()) > 0
     ds = SyntheticLibriDataset([12000, 10400], batch_size=2, seed=4)
     b = to_device(ds[0], DEV)
     sm.train()

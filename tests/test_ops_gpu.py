@@ -553,6 +553,56 @@ def test_attention_dropout_backward_matches_autograd_with_the_forward_mask(dt, w
     assert _rel(delta[bb, hh], dl_ref) < (1e-5 if dt == L.DT_F32 else 1e-2)
 
 
+@pytest.mark.parametrize("dh", [40, 64])
+def test_fused_attention_backward_persistent_walk(dh):
+    """Round 6: with at least two (batch, head) pairs per CU the fused backward (T <= 256, 16-bit) is ONE workgroup per CU walking a
+    contiguous range of pairs (attention.hip: attn_bwd_fused_kernel, grid (G, 1, 1)).  B = 43 x 12 heads = 516 pairs on 256 CUs: ranges
+    of 2 and 3 pairs.  (a) without dropout, bit for bit against the same utterances launched in two smaller batches (one pair per
+    workgroup); (b) with dropout -- whose index carries (b, h) -- against the fp32 two-pass kernels on the same inputs and mask, pair by
+    pair; (c) the bias gradient = column sums."""
+    torch.manual_seed(5)
+    B, H, T = 43, 12, 249
+    D = H * dh
+    lib = L.lib()
+    dt = L.DT_BF16
+    qkv = torch.randn(B, T, 3 * D, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(B, T, D, device=DEV).to(torch.bfloat16)
+    key_len = torch.randint(40, T + 1, (B,), device=DEV, dtype=torch.int32)
+    key_len[0] = T
+
+    def run(dtype, q, do, kl, nb, drop):
+        q, do = q.to(_tdt(dtype)).contiguous(), do.to(_tdt(dtype)).contiguous()
+        out = torch.empty(nb, T, D, device=DEV, dtype=_tdt(dtype))
+        lse = torch.empty(nb, H, T, device=DEV)
+        L.check(lib.fh_attention_forward(dtype, _p(q), _p(out), _p(lse), _p(kl), nb, T, H, dh, dh ** -0.5, drop, _st()), "attn")
+        dq = torch.full_like(q, float("nan"))
+        delta = torch.full((nb, H, T), float("nan"), device=DEV)
+        dbias = torch.zeros(3 * D, device=DEV)
+        L.check(lib.fh_attention_backward_bias(dtype, _p(q), _p(out), _p(do), _p(lse), _p(delta), _p(dq), _p(dbias), _p(kl), nb, T, H, dh,
+                                               dh ** -0.5, drop, None, _st()), "attn bwd")
+        return dq, delta, dbias
+
+    nodrop = L.drop()
+    full, dl_full, db_full = run(dt, qkv, dout, key_len, B, nodrop)
+    assert not torch.isnan(full.float()).any() and not torch.isnan(dl_full).any()
+    cut = 20
+    lo, dl_lo, db_lo = run(dt, qkv[:cut], dout[:cut], key_len[:cut].contiguous(), cut, nodrop)
+    hi, dl_hi, db_hi = run(dt, qkv[cut:], dout[cut:], key_len[cut:].contiguous(), B - cut, nodrop)
+    assert torch.equal(full[:cut], lo) and torch.equal(full[cut:], hi)
+    assert torch.equal(dl_full[:cut], dl_lo) and torch.equal(dl_full[cut:], dl_hi)
+    assert _rel(db_full, db_lo + db_hi) < 1e-5
+    assert (db_full.double() - full.double().sum(dim=(0, 1))).abs().max().item() < 3e-2 * db_full.abs().max().item()
+    drop = L.drop(0.2, 9, 4)
+    got, _, _ = run(dt, qkv, dout, key_len, B, drop)
+    want, _, _ = run(L.DT_F32, qkv, dout, key_len, B, drop)
+    assert not torch.isnan(got.float()).any()
+    err = (got.double() - want.double()).view(B, T, 3, H, dh).pow(2).sum(dim=(1, 4)).sqrt()      # [B][3][H]
+    ref = want.double().view(B, T, 3, H, dh).pow(2).sum(dim=(1, 4)).sqrt()
+    # the k gradient of a head is small against q / v (softmax shift invariance): scale by the head's largest third
+    worst = (err / ref.amax(dim=1, keepdim=True)).max().item()
+    assert worst < 4e-2, worst
+
+
 # ------------------------------------------------------------------------------------------ KD loss
 @pytest.mark.parametrize("dt", [L.DT_F32, L.DT_BF16])
 @pytest.mark.parametrize("tdt", [L.DT_F32, L.DT_BF16])
