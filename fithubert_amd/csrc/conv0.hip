@@ -189,6 +189,98 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(Conv0Args a, const flo
   }
 }
 
+// ---------------------------------------------------------------- forward pass 2 on the matrix pipe (16-bit outputs, K <= 10; round 6)
+// The pass above is bound by vector-ALU issue -- 10 FMAs of the conv + ~10 instructions of GroupNorm / GELU / packing per output, the
+// teacher's 512 channels at 0.85 of the issue slots (profiles/r05_kernel_pmc_shares.txt) -- while the matrix pipe idles.  Here the
+// 10-tap dot products run as ONE 16 x 16 x 32 MFMA per (16 frames x 16 channels): the reduction index holds three K-long segments,
+//     [ x_hi . w_hi | x_lo . w_hi | x_hi . w_lo ]      x = x_hi + x_lo,  w = w_hi + w_lo  split in the 16-bit type,
+// i.e. the fp32 product up to the dropped x_lo w_lo term and the second-order split residue (~2^-16 relative to |w||x|; the output is
+// rounded to 2^-9 / 2^-11 afterwards) with fp32 accumulation.  Per 256-frame chunk the waveform windows are expanded ONCE into
+// [frame][32] rows in LDS (the A operand: one ds_read_b128 per lane and frame tile, shared by all channel tiles).  A wave owns a block
+// of 128 channels as EIGHT B tiles whose columns are dealt (column n of tile m <-> channel 8 n + m): the accumulators then hold, per
+// lane, the 8 consecutive channels 8 n .. 8 n + 7 of four frames -- one 16-byte store per frame, 16 lanes = 256 contiguous bytes of
+// a row per instruction (with the channels of a tile in neighbouring COLUMNS a store instruction covered 16 rows in 16-byte pieces:
+// 2.61 ms per B = 256 launch of the teacher's 512 channels against 2.38 this way; the vector pass 2.93, statistics included).  What is
+// left on the vector ALU is affine + GELU + packing: the pass is bound by its 8.4 GB of stores now (3.9 TB/s; without them it takes
+// 0.62 ms).  Teacher forward 44.6 -> 43.9 ms at B = 256 (same box, three alternating rounds); the student's 128 channels are neutral.
+// The fp32 parity mode keeps the exact vector pass above; so does any K > 10 (3 K must fit the 32-deep MFMA).
+template <typename T, int NCB>   // NCB = 128-channel blocks = C0 / 128: 4 (one per wave, every frame tile) or 1 (the waves split the frame tiles)
+__global__ void __launch_bounds__(256) conv0_apply_mfma_kernel(Conv0Args a, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               T* __restrict__ y, int chunks_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sw = smem;
+  const int b = blockIdx.y;
+  const int swn = (((TCH - 1) * a.stride + a.K + MAXK) + 3) / 4 * 4;
+  T* xr = reinterpret_cast<T*>(smem + swn);   // [TCH][32]: x_hi(0..K) | x_lo(0..K) | x_hi(0..K) | zeros
+  const int K = a.K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+  const int cb0 = NCB == 4 ? wave * 128 : 0;                 // this wave's channel block
+  const int ts0 = NCB == 4 ? 0 : wave, tss = NCB == 4 ? 1 : 4;   // ... and frame tiles ts0, ts0 + tss, ...
+  // ---- once per workgroup (it walks chunks_per_wg chunks of ONE utterance): the split weight fragments and the GroupNorm affine.
+  // The C0 x K weights pass through LDS (coalesced loads; per-element global loads under the segment tests were 64 branchy,
+  // serialised round trips per workgroup)
+  for (int i = threadIdx.x; i < a.C0 * K; i += 256) smem[i] = a.w[i];
+  __syncthreads();
+  // B fragments: tile m, column n = lane & 15 <-> channel cb0 + 8 n + m; this lane's k = 8 q .. 8 q + 7 of  w_hi | w_hi | w_lo | 0
+  bf16x8 Wf[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int c = cb0 + 8 * n + m;
+    union { bf16x8 v; T e[8]; } u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * q + e;
+      const int seg = (k >= K) + (k >= 2 * K) + (k >= 3 * K), j = k - seg * K;
+      const float w = smem[c * K + (seg < 3 ? j : 0)];
+      const T hi = (T)w;
+      const T lo = (T)(w - (float)hi);
+      u.e[e] = seg < 2 ? hi : (seg == 2 ? lo : (T)0.f);
+    }
+    Wf[m] = u.v;
+  }
+  float sc[8], sh[8];   // this lane's 8 consecutive channels
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cb0 + 8 * n + e;
+    const float rs = rstd[b * a.C0 + c];
+    sc[e] = rs * a.gamma[c];
+    sh[e] = a.beta[c] - mean[b * a.C0 + c] * sc[e];
+  }
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(xr) + n * 64 + q * 16;
+  const int chunk_end = min(a.nchunk, ((int)blockIdx.x + 1) * chunks_per_wg);
+  for (int chunk = blockIdx.x * chunks_per_wg; chunk < chunk_end; ++chunk) {
+    __syncthreads();   // the previous chunk's rows (or the staged weights) have been read
+    const int nt = stage_wave(a, b, chunk, sw);
+    for (int i = threadIdx.x; i < TCH * 32; i += 256) {
+      const int t = i >> 5, k = i & 31;
+      const int seg = (k >= K) + (k >= 2 * K) + (k >= 3 * K), j = k - seg * K;
+      float x = 0.f;
+      if (t < nt && seg < 3) x = sw[t * a.stride + j];
+      const T hi = (T)x;
+      xr[i] = seg == 1 ? (T)(x - (float)hi) : hi;
+    }
+    __syncthreads();
+    T* ybase = y + ((long)b * a.T0 + (long)chunk * TCH + 4 * q) * a.C0 + cb0 + 8 * n;
+    for (int ts = ts0; ts < TCH / 16; ts += tss) {
+      if (16 * ts >= nt) break;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + ts * 16 * 64);   // A: row = frame 16 ts + n
+      f32x4 acc[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m] = mfma16<T>(xf, Wf[m], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {   // acc[m][i] = frame 16 ts + 4 q + i, channel cb0 + 8 n + m
+        float o[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          o[m] = gelu_t<T>(fmaf(acc[m][i], sc[m], sh[m]));
+        }
+        if (16 * ts + 4 * q + i < nt)
+          st16(ybase + (long)(16 * ts + i) * a.C0, pack16<T>(o));
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- backward, one pass over dy
 // With g[t] = dy[t] * gelu'(z[t]) and xh the normalised conv output, GroupNorm's backward is
 //   dv[t] = rstd * (gamma g[t] - m1 - xh[t] m2),   m1 = gamma mean_t g,  m2 = gamma mean_t (g xh),
@@ -460,6 +552,24 @@ int fh_conv0_fwd_launch(int dtype, const float* wave, const float* w, const floa
   // of its dependent LDS reads, and the wider thread halves the waves that hide it; FH_CONV0_WIDE=1 selects it for experiments
   static const bool wide_env = getenv("FH_CONV0_WIDE") && getenv("FH_CONV0_WIDE")[0] == '1';
   const bool wide = wide_env && C0 / 8 <= 256 && 256 % (C0 / 8) == 0;
+  // 16-bit outputs with K <= 10 and 128 or 512 channels: the conv on the matrix pipe (conv0_apply_mfma_kernel); FH_CONV0_MFMA=0 keeps
+  // the vector pass (A/B comparisons)
+  static const bool mfma_env = !(getenv("FH_CONV0_MFMA") && getenv("FH_CONV0_MFMA")[0] == '0');
+  if (dtype != 0 && mfma_env && K <= 10 && (C0 == 128 || C0 == 512)) {
+    size_t sm = smem_bytes(stride, K, false) - 256 * CV * sizeof(float) + (size_t)TCH * 32 * 2;
+    if (sm < (size_t)C0 * K * sizeof(float)) sm = (size_t)C0 * K * sizeof(float);   // the weights pass through the same LDS first
+    // a workgroup walks several chunks of one utterance (its weight fragments and GroupNorm affine are built once): as many as leave
+    // ~12 workgroups per CU in the grid, at most 8
+    int cpw = (int)((long)a.nchunk * B / (12L * 256));
+    cpw = cpw < 1 ? 1 : (cpw > 8 ? 8 : cpw);
+    const dim3 mgrid((a.nchunk + cpw - 1) / cpw, B);
+#define FH_C0_MFMA(T, NT) hipLaunchKernelGGL((conv0_apply_mfma_kernel<T, NT>), mgrid, block, sm, st, a, mean, rstd, (T*)y, cpw)
+    if (dtype == 2) { if (C0 == 128) FH_C0_MFMA(f16, 1); else FH_C0_MFMA(f16, 4); }
+    else { if (C0 == 128) FH_C0_MFMA(bf16, 1); else FH_C0_MFMA(bf16, 4); }
+#undef FH_C0_MFMA
+    FH_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == 0) { if (K == 10) FH_C0_APPLY(float, 10, 4); else FH_C0_APPLY(float, MAXK, 4); }
   else if (dtype == 2) { if (K == 10) FH_C0_APPLY(f16, 10, 4); else FH_C0_APPLY(f16, MAXK, 4); }
   else if (wide) { if (K == 10) FH_C0_APPLY(bf16, 10, 8); else FH_C0_APPLY(bf16, MAXK, 8); }
