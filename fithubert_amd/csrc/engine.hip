@@ -1444,8 +1444,7 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       g.ldc = (long)sd * cin; g.c_rpb = Ti; g.c_bstride = (long)Tin * cin;
       g.ep.gelu_aux = aux;
       g.ep.aux_factor = save_gelu_grad();
-      RC(fh_gemm_launch(g, dt, x.st));
-      RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, sd * (Ti - 1) + kk, x.st));
+      RC(fh_gemm_launch(g, dt, x.st));   // (the frames the conv does not reach were zeroed at the head of the backward: frontend_zero_unreached)
     } else if (getenv("FH_DGRAD_SPLIT")) {  // A/B aid: the two-product form (odd frames, then even frames with two segments)
       const int n_even = (2 * Ti <= Tin - 1) ? Ti + 1 : Ti;
       GemmParams g = fh_gemm_params();
@@ -1469,7 +1468,6 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       e.ep.gelu_aux = aux;
       e.ep.aux_factor = save_gelu_grad();
       RC(fh_gemm_launch(e, dt, x.st));
-      RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, n_even == Ti + 1 ? 2 * Ti + 1 : 2 * Ti, x.st));
     } else {  // k = 3, s = 2: dx[2u] = dz[u] . W_0 + dz[u-1] . W_2,  dx[2u+1] = dz[u] . W_1
       // ONE product: output row u holds the frame pair (2u, 2u+1) -- 2*Cin contiguous columns --, reduction segment 0 is dz[u]
       // against [W_0 | W_1], segment 1 is dz[u-1] against [W_2 | 0]: the zero half is never multiplied (Y.seg1_limit: the column
@@ -1488,7 +1486,6 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
       e.ep.aux_factor = save_gelu_grad();
       e.ep.tail_cols = 2 * n_even > Tin ? cin : 0;
       RC(fh_gemm_launch(e, dt, x.st));
-      if (2 * n_even < Tin) RC(fh_zero_rows_launch(dt, dst, B, Tin, cin, 2 * n_even, x.st));
     }
     if (i - 1 == 0) dy0 = dst;
   }
@@ -1496,6 +1493,32 @@ int backward_body(const Ctx& x, float* grads, const float* wave, const int* lens
                          x.W<float>(p.c0_mean), x.W<float>(p.c0_rstd), x.W<float2>(p.c0_scratch),
                          x.W<float2>(p.c0_scratch) + (long)B * fh_conv0_nchunk(s.T[0]) * c.conv_dim[0], grads + p.pl.conv_w[0],
                          grads + p.pl.gn_w, grads + p.pl.gn_b, B, s.S, c.conv_dim[0], c.conv_k[0], c.conv_stride[0], 1.0f, x.st, /*stats_ready: the forward's waveform sums are still in c0_scratch*/ 1));
+  return 0;
+}
+
+// The input frames a conv layer's data gradient does not reach (behind the last window of an utterance) must read as zeros downstream.
+// The dz buffers belong to the backward alone, so these B-row fills are issued at its HEAD (round 6): behind their GEMMs -- two launches
+// of a few KB on the main queue -- each waited 0.14 - 0.28 ms for a CU beside the weight-gradient stream's long workgroups
+// (tools/scratch/gap_report.py), on the critical path of the frontend backward.  Same rows as the branches of backward_body's layer loop.
+int frontend_zero_unreached(const Ctx& x) {
+  const Plan& p = x.p;
+  const fh_student_config& c = p.c;
+  const Shapes& s = p.sh;
+  const int nl = c.n_conv - 1, B = (int)s.B;
+  if (c.feature_grad_mult <= 0.f || nl < 1) return 0;
+  for (int i = nl; i >= 1; --i) {
+    if (i == 1 && p.c0_fused) break;   // dz[0] is never written: conv 0's sums come out of layer 1's data-gradient epilogue
+    const int cin = c.conv_dim[i - 1], kk = c.conv_k[i], sd = c.conv_stride[i];
+    const int Ti = s.T[i], Tin = s.T[i - 1];
+    void* dst = x.W<unsigned char>(i - 1 >= 1 ? p.dz[i - 1] : p.dz[0]);
+    int first;
+    if (kk == sd || (kk == 1 && sd == 1)) first = sd * (Ti - 1) + kk;
+    else {
+      const int n_even = (2 * Ti <= Tin - 1) ? Ti + 1 : Ti;
+      first = getenv("FH_DGRAD_SPLIT") ? (n_even == Ti + 1 ? 2 * Ti + 1 : 2 * Ti) : 2 * n_even;
+    }
+    if (first < Tin) RC(fh_zero_rows_launch(x.dt, dst, B, Tin, cin, first, x.st));
+  }
   return 0;
 }
 
@@ -1529,6 +1552,7 @@ int backward(const Ctx& x, float* grads, const float* wave, const int* lens, con
     float* wpart = reinterpret_cast<float*>(x.W<float2>(p.c0_scratch) + B * nchunk * p.c.conv_dim[0] + B * fh_conv0_ab_width(p.c.conv_dim[0]));
     rc = (int)hipMemsetAsync(wpart, 0, (size_t)fh_conv0_fused_wpart_floats((int)B, p.c.conv_dim[0]) * sizeof(float), x.st);
   }
+  if (!rc) rc = frontend_zero_unreached(x);
   if (!rc) rc = backward_body(x, grads, wave, lens, d_pred, d_hidden, d_cnn, d_qkv_last);
   const int j = g_wside.join(x.st);
   if (!rc) rc = j;
