@@ -19,6 +19,9 @@
 #include "kernels.h"
 #include "attn_frag.cuh"
 
+extern int fh_g_reserve_cus;                       // gemm.hip: CUs persistent launches leave to other streams' kernels
+int fh_stream_reserve_cus(hipStream_t st);
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -1229,7 +1232,11 @@ int bwd_fused_launch(const T* qkv, const T* out, const T* dout, const float* lse
     hipDeviceProp_t prop;
     ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
-  const dim3 grid = (persist && (long)B * H >= 2L * ncu) ? dim3(ncu, 1, 1) : dim3(1, H, B);
+  // (data-parallel runs hold CUs back for the collectives' kernels -- fh_gemm_reserve_cus / fh_gemm_stream_reserve_cus: a persistent
+  // workgroup owns its CU for the whole launch, so the walk leaves them free exactly as the streaming GEMM loop does)
+  const int sres = fh_stream_reserve_cus(st), res = sres > fh_g_reserve_cus ? sres : fh_g_reserve_cus;
+  const int pgrid = ncu - res > 8 ? ncu - res : 8;
+  const dim3 grid = (persist && (long)B * H >= 2L * pgrid) ? dim3(pgrid, 1, 1) : dim3(1, H, B);
   if (drop.p > 0.f) {
     set_lds(attn_bwd_fused_kernel<T, NDT, true>, smem);
     hipLaunchKernelGGL((attn_bwd_fused_kernel<T, NDT, true>), grid, dim3(512), smem, st, qkv, out, dout, lse, delta, dqkv, key_len,

@@ -590,6 +590,13 @@ def test_fused_attention_backward_persistent_walk(dh):
     hi, dl_hi, db_hi = run(dt, qkv[cut:], dout[cut:], key_len[cut:].contiguous(), B - cut, nodrop)
     assert torch.equal(full[:cut], lo) and torch.equal(full[cut:], hi)
     assert torch.equal(dl_full[:cut], dl_lo) and torch.equal(dl_full[cut:], dl_hi)
+    # the same walk with CUs held back for other streams' kernels (data-parallel runs: fh_gemm_reserve_cus): 216 workgroups, uneven ranges
+    prev = lib.fh_gemm_reserve_cus(40)
+    try:
+        held, dl_held, _ = run(dt, qkv, dout, key_len, B, nodrop)
+    finally:
+        lib.fh_gemm_reserve_cus(prev)
+    assert torch.equal(held, full) and torch.equal(dl_held, dl_full)
     assert _rel(db_full, db_lo + db_hi) < 1e-5
     assert (db_full.double() - full.double().sum(dim=(0, 1))).abs().max().item() < 3e-2 * db_full.abs().max().item()
     drop = L.drop(0.2, 9, 4)
