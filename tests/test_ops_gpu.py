@@ -553,8 +553,9 @@ def test_attention_dropout_backward_matches_autograd_with_the_forward_mask(dt, w
     assert _rel(delta[bb, hh], dl_ref) < (1e-5 if dt == L.DT_F32 else 1e-2)
 
 
+@pytest.mark.parametrize("dt", [L.DT_BF16, L.DT_F16])
 @pytest.mark.parametrize("dh", [40, 64])
-def test_fused_attention_backward_persistent_walk(dh):
+def test_fused_attention_backward_persistent_walk(dh, dt):
     """Round 6: with at least two (batch, head) pairs per CU the fused backward (T <= 256, 16-bit) is ONE workgroup per CU walking a
     contiguous range of pairs (attention.hip: attn_bwd_fused_kernel, grid (G, 1, 1)).  B = 43 x 12 heads = 516 pairs on 256 CUs: ranges
     of 2 and 3 pairs.  (a) without dropout, bit for bit against the same utterances launched in two smaller batches (one pair per
@@ -564,9 +565,8 @@ def test_fused_attention_backward_persistent_walk(dh):
     B, H, T = 43, 12, 249
     D = H * dh
     lib = L.lib()
-    dt = L.DT_BF16
-    qkv = torch.randn(B, T, 3 * D, device=DEV).to(torch.bfloat16)
-    dout = torch.randn(B, T, D, device=DEV).to(torch.bfloat16)
+    qkv = torch.randn(B, T, 3 * D, device=DEV).to(_tdt(dt))
+    dout = torch.randn(B, T, D, device=DEV).to(_tdt(dt))
     key_len = torch.randint(40, T + 1, (B,), device=DEV, dtype=torch.int32)
     key_len[0] = T
 
@@ -607,7 +607,7 @@ def test_fused_attention_backward_persistent_walk(dh):
     ref = want.double().view(B, T, 3, H, dh).pow(2).sum(dim=(1, 4)).sqrt()
     # the k gradient of a head is small against q / v (softmax shift invariance): scale by the head's largest third
     worst = (err / ref.amax(dim=1, keepdim=True)).max().item()
-    assert worst < 4e-2, worst
+    assert worst < (4e-2 if dt == L.DT_BF16 else 6e-3), worst
 
 
 # ------------------------------------------------------------------------------------------ KD loss
