@@ -65,8 +65,24 @@ __device__ __forceinline__ int fh_xcd_logical_block() {
   const int per = nwg >> 3, rem = nwg & 7, xcd = lin & 7;
   return (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (lin >> 3);
 }
+#ifdef FH_LD_NT   // (per translation unit, defined in front of this header: every 16-byte load of the unit is non-temporal -- norm.hip, loss.hip)
+__device__ __forceinline__ V16 ld16(const void* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+  const u32x4_ q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(p));
+  V16 v;
+  v.w[0] = q[0]; v.w[1] = q[1]; v.w[2] = q[2]; v.w[3] = q[3];
+  return v;
+}
+#else
 __device__ __forceinline__ V16 ld16(const void* p) { return *reinterpret_cast<const V16*>(p); }
+#endif
 __device__ __forceinline__ void st16(void* p, const V16& v) { *reinterpret_cast<V16*>(p) = v; }
+// non-temporal form (global_store_dwordx4 ... nt): for streamed outputs far larger than the caches that nothing re-reads soon
+__device__ __forceinline__ void st16_nt(void* p, const V16& v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+  const u32x4_ q = {v.w[0], v.w[1], v.w[2], v.w[3]};
+  __builtin_nontemporal_store(q, reinterpret_cast<u32x4_*>(p));
+}
 
 // unpack / pack a 16-byte vector into VEC floats
 template <typename T> __device__ __forceinline__ void unpack16(const V16& v, float* f);

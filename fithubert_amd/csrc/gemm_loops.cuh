@@ -2127,6 +2127,18 @@ __global__ void __launch_bounds__(512) gemm_8ph_kernel(const GemmParams p) {
 // reduction split are not offered this loop (stream_ok); a row tile cut by M masks its stores and drains them before the next tile
 // (an instruction without an active lane may be branched over, so their number is not known).
 constexpr int EPS_WAVE = 16 * EPB_ROW + 256;
+// Loop 8 writes its output with NON-TEMPORAL stores (global_store_dwordx4 ... nt; round 6): its tiles leave as 128 KB bursts that every CU
+// issues at about the same time, nothing re-reads a line before the launch ends, and the consumers' reads come from HBM either way (outputs
+// of 61 MB ... 4 GB against 32 MB of L2).  Same box, alternating, B = 256: student step 51.05 -> 50.18 ms, teacher forward 43.24 -> 42.00,
+// bench 92.74 -> 91.20 ms per step.  The same switch in the epilogues of loops 3 / 4 / 5 / 7, LayerNorm, the KD loss and the positional conv
+// measured neutral, in the attention kernels (whose outputs the next launch re-reads at once) +0.8 ms -- they keep plain stores; a non-temporal
+// LDS-DMA for the X rows of one-column-tile products (read once) cost the student step +0.8 ms.
+// (compile time on purpose: behind a run-time test the compiler merged the two stores and dropped the hint.)  -DFH_L8_PLAIN_STORES: A/B.
+#ifdef FH_L8_PLAIN_STORES
+#define FH_L8_ST(ptr, v) st16(ptr, v)
+#else
+#define FH_L8_ST(ptr, v) st16_nt(ptr, v)
+#endif
 __device__ __forceinline__ void glds4(const float* gsrc, unsigned dst) {  // 64 lanes x 4 B -> 256 contiguous bytes at LDS address dst
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -2221,8 +2233,8 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
         *reinterpret_cast<uint2*>(wp + n * 32) = pk;
       }
       const V16 t0 = ld16(lp), t1 = ld16(lp + 8 * EPB_ROW);
-      if (sv0) st16(reinterpret_cast<bf16*>(ep.preact) + base, t0);
-      if (sv1) st16(reinterpret_cast<bf16*>(ep.preact) + base1, t1);
+      if (sv0) FH_L8_ST(reinterpret_cast<bf16*>(ep.preact) + base, t0);
+      if (sv1) FH_L8_ST(reinterpret_cast<bf16*>(ep.preact) + base1, t1);
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -2241,8 +2253,8 @@ __device__ __forceinline__ int epilogue_stream16_t(const GemmParams& p, const Ac
       *reinterpret_cast<uint2*>(wp + n * 32) = pk;
     }
     const V16 t0 = ld16(lp), t1 = ld16(lp + 8 * EPB_ROW);
-    if (sv0) st16(reinterpret_cast<bf16*>(p.C) + base, t0);
-    if (sv1) st16(reinterpret_cast<bf16*>(p.C) + base1, t1);
+    if (sv0) FH_L8_ST(reinterpret_cast<bf16*>(p.C) + base, t0);
+    if (sv1) FH_L8_ST(reinterpret_cast<bf16*>(p.C) + base1, t1);
   }
   return full ? (M1 - M0) * (PRE ? 4 : 2) : -1;
 }

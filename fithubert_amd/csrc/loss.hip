@@ -7,6 +7,8 @@
 // HBM-bound: one pass reads pred and teacher once (16-byte vectors), writes dL/dpred, and produces
 // per-block fp32 partial sums; a one-block finisher adds the partials in a fixed order in fp64, so the
 // loss is bitwise reproducible (no float atomics) and accurate to the 1e-4 parity target.
+// Every 16-byte load of this unit is NON-TEMPORAL (round 6): the loss reads 2 x 2.35 GB exactly once (student step -0.1 ... -0.2 ms).
+#define FH_LD_NT 1
 #include "common.cuh"
 #include "kernels.h"
 
