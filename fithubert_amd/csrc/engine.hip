@@ -856,7 +856,9 @@ int forward(const Ctx& x, const float* wave, const int* lens, const fh_student_k
       g.C = x.at(p.s2, (long)l * Ms * D);
       g.M = (int)M2; g.N = D; g.Kseg = Fd; g.ldc = D;
       g.ep.bias = lp + p.pl.l_fc2_b;
-      g.ep.preact = x.at(p.f2, (long)l * Ms * D);
+      // fc2's output in front of dropout and residual = layer_results[i][2] of the reference's API; no loss and no backward reads it:
+      // the distillation hot path (fh_student_call.training == 2) does not store the 12 copies (0.73 GB per B = 256 step)
+      g.ep.preact = p.k.training == 2 ? nullptr : x.at(p.f2, (long)l * Ms * D);
       g.ep.drop = x.drop(c.dropout, site + 3);
       g.ep.residual = x.at(p.xa, (long)l * Ms * D);
       RC(fh_gemm_launch(g, dt, x.st));

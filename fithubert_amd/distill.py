@@ -420,13 +420,13 @@ class W2V2Distil:
         if fused_kd:
             if ev is not None:      # the teacher's hidden states are an operand of the forward now (one batch ahead: ready long before)
                 torch.cuda.current_stream(self.device).wait_event(ev)
-            ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed,
+            ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed, keep_fc2_out=False,
                                      kd=dict(teacher=hid, layer_w=self.layer_w, teacher_layer=self.teacher_layer,
                                              loss_type=0 if self.rec_loss_type == "mse" else 1,
                                              grad_scale=float(self.rec_loss_weight) * self.loss_scale))
             out, d_pred = ws.kd_out, ws.view("pred")
         else:
-            ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed)
+            ws = self.engine.forward(x, lengths, training=True, heads_on=self.student_model._heads_on, seed=step_seed, keep_fc2_out=False)
             if ev is not None:
                 torch.cuda.current_stream(self.device).wait_event(ev)
         if fused_kd:

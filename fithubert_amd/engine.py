@@ -272,16 +272,17 @@ class StudentEngine:
         return self.c.n_tasks == 0 and self.c.tr_factor > 0 and bool(heads_on)
 
     def forward(self, wave: torch.Tensor, sample_lengths=None, training: bool = False, heads_on: bool = True,
-                seed: int = 0, kd: Optional[dict] = None) -> Workspace:
+                seed: int = 0, kd: Optional[dict] = None, keep_fc2_out: bool = True) -> Workspace:
         """``kd`` (training only): dict(teacher=[Lt][B][Tt][P] tensor, layer_w, teacher_layer, loss_type=0, grad_scale=1.0) -- the
         layer-wise KD loss is then computed inside the projection heads' GEMM epilogue: ``ws.kd_out`` holds the fp64 loss vector
         [per-layer means..., weighted total] and ``ws.view("pred")`` d loss / d pred (pass it to ``backward(d_pred=...)``); the
         predictions themselves are never written."""
         assert wave.is_cuda and wave.dtype == torch.float32 and wave.dim() == 2 and wave.is_contiguous()
         B, S = wave.shape
-        if training and self.auto_tune and (self._shape_class(B, S) + (bool(heads_on),)) not in self._tuned:
-            self.autotune(B, S, bool(heads_on))
-        call = StudentCallC(B, S, int(training), int(heads_on), seed & 0xFFFFFFFF)
+        if training and self.auto_tune and (self._shape_class(B, S) + (bool(heads_on), bool(keep_fc2_out))) not in self._tuned:
+            self.autotune(B, S, bool(heads_on), bool(keep_fc2_out))
+        # keep_fc2_out=False (training only): the `f2` copies -- layer_results[i][2] of the module API, read by no loss -- are not stored
+        call = StudentCallC(B, S, (1 if keep_fc2_out else 2) if training else 0, int(heads_on), seed & 0xFFFFFFFF)
         nbytes = self.lib.fh_student_ws_bytes(C.byref(self.c), C.byref(call))
         if nbytes <= 0:
             raise RuntimeError(f"fh_student_ws_bytes failed ({nbytes}) for B={B}, S={S}")
@@ -322,16 +323,16 @@ class StudentEngine:
         lg = max(S, 1).bit_length() - 1
         return B, lg * 4 + (((S - (1 << lg)) * 4) >> lg)
 
-    def autotune(self, B: int, S: int, heads_on: bool = True) -> int:
+    def autotune(self, B: int, S: int, heads_on: bool = True, keep_fc2_out: bool = True) -> int:
         """Measure the GEMM main-loop candidates for every launch of a training step on [B, S] waveforms: one throw-away
         forward + backward on noise with fh_gemm_tune(1) (blocking; weight gradients go to a scratch buffer).  Returns the
         number of shape classes in the library's table."""
-        self._tuned.add(self._shape_class(B, S) + (heads_on,))
+        self._tuned.add(self._shape_class(B, S) + (heads_on, keep_fc2_out))   # (fc2 with / without its raw-output copy: two GEMM classes)
         torch.cuda.synchronize(self.device)
         self.lib.fh_gemm_tune(1)
         try:
             wave = 0.1 * torch.randn(B, S, device=self.device, dtype=torch.float32)
-            ws = self.forward(wave, None, training=True, heads_on=heads_on, seed=12345)
+            ws = self.forward(wave, None, training=True, heads_on=heads_on, seed=12345, keep_fc2_out=keep_fc2_out)
             scratch = torch.zeros_like(self.grads)
             if heads_on:
                 self.backward(ws, d_pred=(1e-3 * torch.randn_like(ws.view("pred"), dtype=torch.float32)).to(self.elem), grads=scratch)

@@ -342,7 +342,8 @@ typedef struct {
 /* per-call shape info */
 typedef struct {
   int B, S;        /* batch, samples */
-  int training;    /* dropout on, save activations for backward */
+  int training;    /* 0: eval; 1: dropout on, activations saved for the backward; 2: as 1 without the per-layer copies of fc2's raw output
+                    * (`f2` = layer_results[i][2] of modules/model.py: API surface that no loss and no backward reads -- the distillation hot path) */
   int heads_on;    /* 1: all layer-wise projection heads (distillation); 0: final_proj only (deployment) */
   uint32_t seed;   /* dropout seed of this step */
 } fh_student_call;

@@ -770,3 +770,35 @@ def test_ragged_pair_shortest_beside_a_ten_second_utterance_against_the_oracle()
         if e > 3e-3:
             bad.append((k, e))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bf16"])
+def test_hot_path_mode_without_fc2_copies_changes_nothing_else(dtype):
+    """fh_student_call.training == 2 (StudentEngine.forward(keep_fc2_out=False), what W2V2Distil.training_step runs): the per-layer copies
+    of fc2's raw output -- layer_results[i][2] of the module API, read by no loss and no backward -- are not stored (round 6); every
+    prediction and every gradient is that of the ordinary training forward (same dropout masks: same seed)."""
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "conf", "fithubert.yaml")))["distiller"]
+    cfg = dict(cfg, encoder_layers=2)
+    eng, sd = _engine(cfg, 3, dtype)
+    eng.auto_tune = False
+    wav = 0.5 * torch.randn(2, 16000, generator=torch.Generator().manual_seed(0)).to(DEV)
+    res = []
+    for keep in (True, False):
+        ws = eng.forward(wav, None, training=True, seed=5, keep_fc2_out=keep)
+        if not keep:
+            ws.view("f2").fill_(float("nan"))          # nothing downstream may read it
+        pred = ws.view("pred").clone()
+        d_pred = (1e-3 * torch.randn(pred.shape, generator=torch.Generator().manual_seed(1)).to(DEV)).to(eng.elem)
+        eng.grads.zero_()
+        eng.backward(ws, d_pred=d_pred)
+        torch.cuda.synchronize()
+        res.append((pred, ws.view("xo").clone(), eng.grads.clone()))
+    (p1, x1, g1), (p0, x0, g0) = res
+    assert torch.isfinite(g0).all()
+    if dtype == "float32":
+        assert torch.equal(p1, p0) and torch.equal(x1, x0)
+        # the weight gradients are fp32 atomic sums (launch-to-launch order): equal up to that
+        assert ((g1 - g0).norm() / g1.norm()).item() < 1e-5
+    else:   # (fc2 with and without its copy may take epilogue forms that round once / twice: the 16-bit tolerance of the other tests)
+        assert _rel_l2(p0.float(), p1.float()) < 5e-3 and _rel_l2(x0.float(), x1.float()) < 5e-3
+        assert ((g1 - g0).norm() / g1.norm()).item() < 2e-2

@@ -27,7 +27,7 @@ teacher = torch.randn(12, a.batch, Tp, 768, device=dev, dtype=torch.bfloat16)
 w = torch.full((12,), 0.1, device=dev); w[11] = 1.0
 tl = torch.arange(12, dtype=torch.int32, device=dev)
 def step(i):
-    ws = eng.forward(wav, None, training=True, seed=i + 1)
+    ws = eng.forward(wav, None, training=True, seed=i + 1, keep_fc2_out=os.environ.get('FH_KEEP_F2', '0') == '1')   # the hot path's mode (distill.training_step)
     out, dp = eng.kd_loss(ws, teacher, w, tl)
     eng.grads.zero_()
     eng.backward(ws, d_pred=dp)
